@@ -1,0 +1,251 @@
+#!/usr/bin/env python
+"""Pin the oracle against the reference and (re)generate tests/golden/*.  BUILD CONTAINER ONLY.
+
+Run from the repo root:   python oracle/pin/pin_against_reference.py
+
+It imports the reference from /root/reference (which never travels to the GPU box):
+
+  * ``ivideogpt.transformer.HeadModelWithAction`` + HF ``LlamaForCausalLM``  -> pins oracle/llama.py
+  * ``ivideogpt.vq_model.CompressiveVQModel`` (the reference's unmodified repo-owned code),
+    executed over a throw-away ``diffusers`` shim written to /tmp that re-exports
+    ``oracle.df_blocks``  -> pins oracle/vq_tokenizer.py (everything except the DF blocks).
+
+Every fixture holds only inputs + outputs produced BY THE REFERENCE CLASSES; weights are
+re-derived from (config, seed) by ``ivideogpt_amd.weights.random_*_state_dict``.
+"""
+import json
+import os
+import sys
+import textwrap
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+SHIM = "/tmp/ivg_df_shim"
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+from ivideogpt_amd import weights as W  # noqa: E402
+from oracle import llama as OL          # noqa: E402
+from oracle import vq_tokenizer as OT   # noqa: E402
+
+
+def write_shim():
+    files = {
+        "diffusers/__init__.py": "",
+        "diffusers/utils/__init__.py": """
+            from collections import OrderedDict
+            class BaseOutput(OrderedDict):
+                def __post_init__(self):
+                    for k, v in self.__dict__.items():
+                        self[k] = v
+            def is_torch_version(op, v):
+                return True
+        """,
+        "diffusers/utils/torch_utils.py": "def randn_tensor(*a, **k):\n    raise NotImplementedError\n",
+        "diffusers/utils/accelerate_utils.py": "def apply_forward_hook(f):\n    return f\n",
+        "diffusers/configuration_utils.py": """
+            import functools, inspect
+            class ConfigMixin:
+                pass
+            def register_to_config(init):
+                @functools.wraps(init)
+                def inner(self, *args, **kwargs):
+                    sig = inspect.signature(init)
+                    ba = sig.bind(self, *args, **kwargs); ba.apply_defaults()
+                    self.config = {k: v for k, v in ba.arguments.items() if k != 'self'}
+                    init(self, *args, **kwargs)
+                return inner
+        """,
+        "diffusers/models/__init__.py": "",
+        "diffusers/models/modeling_utils.py": "import torch.nn as nn\nclass ModelMixin(nn.Module):\n    pass\n",
+        "diffusers/models/activations.py": """
+            import torch.nn as nn
+            def get_activation(name):
+                assert name in ('silu', 'swish')
+                return nn.SiLU()
+        """,
+        "diffusers/models/attention_processor.py": "class SpatialNorm:\n    pass\n",
+        "diffusers/models/unets/__init__.py": "",
+        "diffusers/models/unets/unet_2d_blocks.py": """
+            from oracle.df_blocks import UNetMidBlock2D, get_down_block, get_up_block
+            class AutoencoderTinyBlock:
+                pass
+        """,
+        "diffusers/models/autoencoders/__init__.py": "",
+        "diffusers/models/autoencoders/vae.py": "from oracle.df_blocks import VectorQuantizer\n",
+        "torchvision_stub/torchvision/__init__.py": "",
+        "torchvision_stub/torchvision/models.py": "",
+    }
+    for rel, body in files.items():
+        p = os.path.join(SHIM, rel)
+        os.makedirs(os.path.dirname(p), exist_ok=True)
+        with open(p, "w") as f:
+            f.write(textwrap.dedent(body))
+
+
+def import_reference():
+    import transformers  # noqa: F401  resolve Llama BEFORE the torchvision stub is visible (SURVEY 8c trap)
+    from transformers import LlamaConfig, LlamaForCausalLM  # noqa: F401
+    write_shim()
+    sys.path.insert(0, SHIM)
+    sys.path.insert(0, REF)
+    from ivideogpt.transformer import HeadModelWithAction
+    sys.path.insert(0, os.path.join(SHIM, "torchvision_stub"))
+    from ivideogpt.vq_model import CompressiveVQModel
+    return CompressiveVQModel, HeadModelWithAction
+
+
+def save(name, **arrays):
+    os.makedirs(GOLD, exist_ok=True)
+    path = os.path.join(GOLD, name)
+    np.savez_compressed(path, **{k: (v.numpy() if torch.is_tensor(v) else v) for k, v in arrays.items()})
+    print(f"  wrote {os.path.relpath(path, ROOT)}  ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+# ----------------------------------------------------------------------------- tokenizer
+def seeded_pixels(seed, shape):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(0, 256, shape, generator=g).float() / 255.0   # u8-exact values, like real clips
+
+
+def pin_tokenizer(CompressiveVQModel, name, cfg, seed, B, T, codebook_std, ctx_override=None, subsample=1):
+    print(f"[tokenizer] {name}: {cfg}")
+    full = W.tokenizer_config(**cfg)
+    sd = W.random_tokenizer_state_dict(full, seed, codebook_std)
+    kw = {k: (list(v) if isinstance(v, tuple) else v) for k, v in full.items()}
+    nlev = len(full["block_out_channels"])
+    kw["down_block_types"], kw["up_block_types"] = ["DownEncoderBlock2D"] * nlev, ["UpDecoderBlock2D"] * nlev
+    kw["vq_embed_dim"] = None if cfg.get("vq_embed_dim") is None else cfg["vq_embed_dim"]
+    ref = CompressiveVQModel(**kw).eval()
+    ref.load_state_dict(sd, strict=True)            # proves the key schema == the reference's
+    n_ref = sum(p.numel() for p in ref.parameters())
+    assert n_ref == W.count_params(W.tokenizer_param_shapes(full)), "parameter count mismatch"
+    ora = OT.CompressiveVQRef(**full).eval()
+    ora.load_state_dict(sd, strict=True)
+    ctx = full["context_length"]
+    if ctx_override is not None:
+        ref.set_context_length(ctx_override); ora.set_context_length(ctx_override); ctx = ctx_override
+    res = full["resolution"]
+    px = seeded_pixels(seed + 1, (B, T, 3, res, res))
+    with torch.no_grad():
+        ids_ref, lab_ref = ref.tokenize(px, ctx)
+        ids_ora, lab_ora = ora.tokenize(px, ctx)
+        assert torch.equal(ids_ref, ids_ora) and torch.equal(lab_ref, lab_ora), "tokenize mismatch vs reference"
+        # detokenize a *perturbed* token sequence too (out-of-range dyn ids exercise the clamp, :234-236)
+        g = torch.Generator().manual_seed(seed + 2)
+        ids2 = ids_ref.clone()
+        vocab = full["num_vq_embeddings"] + full["num_dyn_embeddings"] + 2
+        flip = torch.rand(ids2.shape, generator=g) < 0.2
+        flip[:, :ctx * 257] = False                 # the reference does not clamp context ids (IndexError)
+        ids2[flip] = torch.randint(0, vocab, ids2.shape, generator=g)[flip]
+        rec_ref, rec_ora = ref.detokenize(ids_ref, ctx), ora.detokenize(ids_ref, ctx)
+        rec2_ref, rec2_ora = ref.detokenize(ids2, ctx), ora.detokenize(ids2, ctx)
+        assert torch.equal(rec_ref, rec_ora) and torch.equal(rec2_ref, rec2_ora), "detokenize mismatch vs reference"
+        # the F=1 cache path (mbrl/video_predictor.py:320-321)
+        one = ids_ref[:, :ctx * 257 + 16]
+        r1, cache = ref.detokenize(one, ctx, return_cache=True)
+        r1c = ref.detokenize(one, ctx, cache=cache)
+        assert torch.equal(r1, r1c)
+        st = ora.encode_stages(px, ctx)
+        zc = st["hq"].permute(0, 2, 3, 1).reshape(-1, full["vq_embed_dim"])
+        b0, b1, _ = OT.vq_margin(zc, sd["quantize.embedding.weight"], st["idx_c"])
+        print(f"  params {n_ref / 1e6:.3f} M, tokens {tuple(ids_ref.shape)}, latent std {zc.std():.3f}, "
+              f"min VQ margin {(b1 - b0).min():.2e}, median {(b1 - b0).median():.2e}")
+    save(f"tok_{name}.npz", config=json.dumps({k: (list(v) if isinstance(v, tuple) else v) for k, v in full.items()}),
+         seed=seed, codebook_std=codebook_std, context_length=ctx, pixels_u8=(px * 255).round().to(torch.uint8),
+         indices=ids_ref, labels=lab_ref, recon=rec_ref[..., ::subsample, ::subsample],
+         indices_perturbed=ids2, recon_perturbed=rec2_ref[..., ::subsample, ::subsample],
+         latent_ctx=st["hq"], latent_dyn=st["dq"], subsample=subsample)
+
+
+# ----------------------------------------------------------------------------- transformer
+def pin_llama(HeadModelWithAction, name, cfg, seed, B, ctx, F, action_dim):
+    from transformers import LlamaConfig, LlamaForCausalLM
+    print(f"[llama] {name}: {cfg}")
+    hf_cfg = LlamaConfig(**{**cfg, "hidden_act": "silu", "tie_word_embeddings": False, "attention_bias": False,
+                            "bos_token_id": 50256, "eos_token_id": 50256})
+    V, per = cfg["vocab_size"], 17
+    g = torch.Generator().manual_seed(seed + 10)
+    L0 = 257 * ctx
+    n_new = per * F - 1
+    prompt = torch.randint(0, 8192, (B, L0), generator=g)
+    prompt[:, -1] = V - 1
+    for c in range(1, ctx):
+        prompt[:, 257 * c - 1] = V - 2
+
+    # ---- action-free: HF LlamaForCausalLM
+    sd = W.random_llama_state_dict(cfg, seed)
+    hf = LlamaForCausalLM(hf_cfg).to(torch.float32).eval()
+    hf.load_state_dict(sd, strict=True)
+    ora = OL.LlamaRef(sd, cfg["num_hidden_layers"], cfg["num_attention_heads"], cfg["rms_norm_eps"],
+                      cfg["rope_theta"], cfg["max_position_embeddings"])
+    with torch.no_grad():
+        full = torch.cat([prompt, torch.randint(0, V, (B, 40), generator=g)], 1)
+        lg_ref = hf(input_ids=full).logits.float()
+        lg_ora = ora.logits(full)
+        err = (lg_ref - lg_ora).abs().max().item()
+        print(f"  teacher-forced logits: max|HF - oracle| = {err:.2e} (scale {lg_ref.abs().max():.2f})")
+        assert err < 2e-4
+        gen_ref = hf.generate(prompt, do_sample=False, max_new_tokens=n_new, pad_token_id=50256)
+        gen_ora = OL.generate_cached(ora, prompt, n_new)
+        assert torch.equal(gen_ref, gen_ora), "greedy action-free rollout mismatch vs HF generate"
+    save(f"llama_{name}_free.npz", config=json.dumps(cfg), seed=seed, prompt=prompt, teacher_ids=full,
+         teacher_logits_last=lg_ref[:, -2:], teacher_logits_sub=lg_ref[:, ::37, ::101], greedy=gen_ref)
+
+    # ---- action-conditioned: the reference's HeadModelWithAction (per-frame re-prefill)
+    sda = W.random_llama_state_dict(cfg, seed + 1, action_dim=action_dim)
+    llm = LlamaForCausalLM(hf_cfg).to(torch.float32).eval()
+    T = ctx + F
+    head = HeadModelWithAction(llm, action_dim=action_dim, prelude_tokens_num=L0 - 1, tokens_num_per_dyna=16,
+                               context=ctx, segment_length=T).eval()
+    head.load_state_dict(sda, strict=True)
+    action = torch.randn(B, T, action_dim, generator=g)
+    oraa = OL.LlamaRef(sda, cfg["num_hidden_layers"], cfg["num_attention_heads"], cfg["rms_norm_eps"],
+                       cfg["rope_theta"], cfg["max_position_embeddings"], prefix="llm.model.")
+    with torch.no_grad():
+        out_ref = head.generate(prompt, do_sample=False, max_new_tokens=n_new, action=action)
+        ae = torch.nn.functional.linear(action, sda["action_linear.weight"], sda["action_linear.bias"])
+        out_a = OL.generate_reference_algorithm(oraa, prompt, n_new, action_embeds=ae, ctx=ctx, sdf_token=V - 1)
+        out_b = OL.generate_cached(oraa, prompt, n_new, action_embeds=ae, ctx=ctx, sdf_token=V - 1)
+        assert torch.equal(out_ref, out_a), "oracle re-prefill algorithm != reference HeadModelWithAction.generate"
+        assert torch.equal(out_ref, out_b), "single-prefill cached algorithm != reference"
+        print(f"  action-conditioned greedy: {tuple(out_ref.shape)} tokens identical (re-prefill and cached)")
+    save(f"llama_{name}_act.npz", config=json.dumps(cfg), seed=seed + 1, action_dim=action_dim, prompt=prompt,
+         action=action, greedy=out_ref, ctx=ctx)
+
+
+def pin_param_counts():
+    n64 = W.count_params(W.tokenizer_param_shapes(W.CTX_VAE64))
+    n256 = W.count_params(W.tokenizer_param_shapes(W.CTX_VAE256))
+    ns = W.count_params(W.llama_param_shapes(W.LLAMA_SMALL))
+    nm = W.count_params(W.llama_param_shapes(W.LLAMA_MEDIUM))
+    print(f"[params] tokenizer64 {n64 / 1e6:.3f} M (README 114 M), tokenizer256 {n256 / 1e6:.3f} M (README 310 M), "
+          f"llama small {ns / 1e6:.2f} M (138 M), medium {nm / 1e6:.2f} M (436 M)")
+    assert abs(n64 / 1e6 - 114.16) < 0.01 and abs(n256 / 1e6 - 310.47) < 0.01 and abs(ns / 1e6 - 138.43) < 0.01
+
+
+def main():
+    torch.manual_seed(0)
+    CompressiveVQModel, HeadModelWithAction = import_reference()
+    pin_param_counts()
+    mini64 = dict(block_out_channels=(64, 128, 128), layers_per_block=1, latent_channels=64, num_vq_embeddings=512,
+                  num_dyn_embeddings=512, mid_block_add_attention=False, context_length=2, resolution=64,
+                  max_att_resolution=16)
+    pin_tokenizer(CompressiveVQModel, "mini64_ctx2", mini64, seed=11, B=2, T=4, codebook_std=0.4)
+    pin_tokenizer(CompressiveVQModel, "mini64_ctx1", mini64, seed=12, B=2, T=3, codebook_std=0.4, ctx_override=1)
+    mini256 = dict(block_out_channels=(64, 64, 64, 128, 192), layers_per_block=1, latent_channels=64,
+                   num_vq_embeddings=512, num_dyn_embeddings=512, mid_block_add_attention=False, context_length=2)
+    pin_tokenizer(CompressiveVQModel, "mini256_ctx2", mini256, seed=13, B=1, T=3, codebook_std=0.4, subsample=4)
+    tiny = dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                num_key_value_heads=2, rms_norm_eps=1e-6, rope_theta=10000.0, max_position_embeddings=1024,
+                vocab_size=16386)
+    pin_llama(HeadModelWithAction, "tiny_ctx2", tiny, seed=21, B=2, ctx=2, F=3, action_dim=4)
+    pin_llama(HeadModelWithAction, "tiny_ctx1", tiny, seed=23, B=3, ctx=1, F=4, action_dim=7)
+    print("all pins passed")
+
+
+if __name__ == "__main__":
+    main()

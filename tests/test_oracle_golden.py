@@ -1,0 +1,86 @@
+"""The oracle against the committed golden vectors (outputs of the REFERENCE classes, produced by
+oracle/pin/pin_against_reference.py in the build container).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import llama_fixture, oracle_llama, oracle_tokenizer, tokenizer_fixture
+
+
+@pytest.mark.parametrize("name", ["tok_mini64_ctx2.npz", "tok_mini64_ctx1.npz", "tok_mini256_ctx2.npz"])
+def test_tokenizer_oracle_matches_reference_vectors(name):
+    cfg, sd, ctx, px, g = tokenizer_fixture(name)
+    m = oracle_tokenizer(cfg, sd, ctx)
+    ids, labels = m.tokenize(px, ctx)
+    assert np.array_equal(ids.numpy(), g["indices"]), "VQ indices must be bit-exact"
+    assert np.array_equal(labels.numpy(), g["labels"])
+    s = int(g["subsample"])
+    rec = m.detokenize(torch.from_numpy(g["indices"]), ctx)[..., ::s, ::s]
+    rec2 = m.detokenize(torch.from_numpy(g["indices_perturbed"]), ctx)[..., ::s, ::s]
+    # same torch build on the same ISA reproduces bit-for-bit; allow fp32 round-off for other hosts
+    assert np.abs(rec.numpy() - g["recon"]).max() < 1e-4
+    assert np.abs(rec2.numpy() - g["recon_perturbed"]).max() < 1e-4
+    st = m.encode_stages(px, ctx)
+    assert np.abs(st["hq"].numpy() - g["latent_ctx"]).max() < 1e-4
+    assert np.abs(st["dq"].numpy() - g["latent_dyn"]).max() < 1e-4
+
+
+def test_token_layout_and_labels():
+    """compressive_vq_model.py:205-218: [256 ctx][scf][256 ctx][sdf][16 dyn]...; labels -100 over context."""
+    cfg, sd, ctx, px, g = tokenizer_fixture("tok_mini64_ctx2.npz")
+    ids, labels = g["indices"], g["labels"]
+    nvq, ndyn = cfg["num_vq_embeddings"], cfg["num_dyn_embeddings"]
+    scf, sdf = nvq + ndyn, nvq + ndyn + 1
+    F = px.shape[1] - ctx
+    assert ids.shape[1] == 257 * ctx - 1 + 17 * F
+    assert (ids[:, 256] == scf).all() and (ids[:, 513] == sdf).all() and (ids[:, 530] == sdf).all()
+    assert ((ids[:, :256] >= 0) & (ids[:, :256] < nvq)).all()
+    assert ((ids[:, 514:530] >= nvq) & (ids[:, 514:530] < nvq + ndyn)).all()
+    assert (labels[:, :514] == -100).all() and np.array_equal(labels[:, 514:], ids[:, 514:])
+
+
+@pytest.mark.parametrize("name", ["llama_tiny_ctx2_free.npz", "llama_tiny_ctx1_free.npz"])
+def test_llama_oracle_matches_hf_vectors(name):
+    from oracle.llama import generate_cached
+    cfg, sd, g = llama_fixture(name)
+    m = oracle_llama(cfg, sd)
+    lg = m.logits(torch.from_numpy(g["teacher_ids"]))
+    assert np.abs(lg[:, -2:].numpy() - g["teacher_logits_last"]).max() < 2e-4
+    assert np.abs(lg[:, ::37, ::101].numpy() - g["teacher_logits_sub"]).max() < 2e-4
+    prompt = torch.from_numpy(g["prompt"])
+    out = generate_cached(m, prompt, g["greedy"].shape[1] - prompt.shape[1])
+    assert np.array_equal(out.numpy(), g["greedy"])
+
+
+@pytest.mark.parametrize("name", ["llama_tiny_ctx2_act.npz", "llama_tiny_ctx1_act.npz"])
+def test_action_conditioned_oracle_matches_reference_vectors(name):
+    from oracle.llama import generate_cached, generate_reference_algorithm
+    cfg, sd, g = llama_fixture(name)
+    m = oracle_llama(cfg, sd, prefix="llm.model.")
+    prompt, action, ctx = torch.from_numpy(g["prompt"]), torch.from_numpy(g["action"]), int(g["ctx"])
+    ae = torch.nn.functional.linear(action, sd["action_linear.weight"], sd["action_linear.bias"])
+    n_new = g["greedy"].shape[1] - prompt.shape[1]
+    sdf = cfg["vocab_size"] - 1
+    a = generate_reference_algorithm(m, prompt, n_new, action_embeds=ae, ctx=ctx, sdf_token=sdf)
+    b = generate_cached(m, prompt, n_new, action_embeds=ae, ctx=ctx, sdf_token=sdf)
+    assert np.array_equal(a.numpy(), g["greedy"]) and np.array_equal(b.numpy(), g["greedy"])
+
+
+def test_sampler_restatement_properties():
+    """explicit-uniform top-k sampler: greedy == argmax; u->0 picks the lowest kept id; only kept ids drawn."""
+    from oracle.llama import sample_from_logits
+    g = torch.Generator().manual_seed(0)
+    lg = torch.randn(8, 16386, generator=g) * 3
+    assert torch.equal(sample_from_logits(lg, 100, None), lg.argmax(-1))
+    kth = lg.topk(100, -1).values[:, -1:]
+    lowest_kept = (lg >= kth).float().argmax(-1)
+    assert torch.equal(sample_from_logits(lg, 100, torch.zeros(8)), lowest_kept)
+    for _ in range(5):
+        t = sample_from_logits(lg, 100, torch.rand(8, generator=g))
+        assert (lg.gather(1, t[:, None]) >= kth).all()
+    # empirical frequencies follow softmax over the kept set
+    row = lg[:1].expand(4000, -1)
+    t = sample_from_logits(row, 100, torch.rand(4000, generator=g))
+    p = torch.softmax(lg[0].masked_fill(lg[0] < kth[0], float("-inf")), -1)
+    top = p.argmax()
+    assert abs((t == top).float().mean().item() - p[top].item()) < 0.03
