@@ -1,0 +1,171 @@
+/* libivg -- C ABI of the MI355X-native iVideoGPT prediction engine (gfx950 / ROCm).
+ *
+ * The reference (thuml/iVideoGPT) has no FFI layer: its drop-in boundary is the Python object API of
+ *   CompressiveVQModel.{tokenize, detokenize, set_context_length}   ivideogpt/vq_model/compressive_vq_model.py:154-277
+ *   LlamaForCausalLM.generate / HeadModelWithAction.generate       ivideogpt/transformer/action_model.py:56-121
+ * (SURVEY.md 8b).  Each entry point below replaces one of those methods; the Python mirror of the
+ * reference classes (ivideogpt_amd/*.py) binds them with ctypes, and INTEGRATION.md shows the stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative ivg_status otherwise; ivg_last_error(engine) holds the text;
+ *   - all data pointers are DEVICE pointers owned by the caller (e.g. torch tensor data_ptr()); the engine borrows
+ *     them for the duration of the call; weight tensors passed to ivg_create must stay alive until ivg_destroy;
+ *   - work is enqueued on the caller's HIP stream and is asynchronous; no host synchronisation inside, except
+ *     ivg_create / ivg_destroy / ivg_profile_read;
+ *   - an engine is bound to one device and is not thread-safe (one engine per process per GPU);
+ *   - token ids are int64, pixels are float32 or bfloat16 planar (B, T, 3, H, W) in [0, 1].
+ */
+#ifndef IVG_H_
+#define IVG_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ivg_engine ivg_engine;
+typedef struct ivg_cache ivg_cache;
+typedef void* ivg_stream; /* hipStream_t */
+
+enum ivg_dtype { IVG_F32 = 0, IVG_BF16 = 1 };
+
+enum ivg_status {
+  IVG_OK = 0,
+  IVG_ERR_INVALID = -1,   /* bad argument / shape (the reference raises AssertionError here) */
+  IVG_ERR_MISSING = -2,   /* a weight tensor is missing from the table */
+  IVG_ERR_HIP = -3,       /* a HIP call or kernel launch failed */
+  IVG_ERR_CAPACITY = -4   /* batch / frames exceed what the engine was created for */
+};
+
+/* A named weight tensor (device pointer).  Names are the checkpoint keys of the reference
+ * (SURVEY.md Appendix C); layouts are the packed ones produced by ivideogpt_amd/packing.py. */
+typedef struct {
+  const char* name;
+  const void* data;
+  int32_t dtype;
+  int32_t ndim;
+  int64_t shape[4];
+} ivg_tensor;
+
+typedef struct {
+  /* ---- tokenizer (CompressiveVQModel.__init__ kwargs, compressive_vq_model.py:36-60); n_levels = 0: no tokenizer */
+  int32_t n_levels;
+  int32_t block_out_channels[8];
+  int32_t layers_per_block;
+  int32_t latent_channels;
+  int32_t vq_embed_dim;
+  int32_t num_vq_embeddings;
+  int32_t num_dyn_embeddings;
+  int32_t norm_num_groups;
+  int32_t mid_block_add_attention;
+  int32_t context_length;
+  int32_t max_att_resolution;
+  int32_t resolution;
+  int32_t patch_size;
+  /* ---- transformer (HF LlamaConfig); num_layers = 0: no transformer */
+  int32_t hidden_size;
+  int32_t intermediate_size;
+  int32_t num_layers;
+  int32_t num_heads;
+  int32_t vocab_size;
+  int32_t max_position_embeddings;
+  float rms_norm_eps;
+  int32_t action_dim;      /* 0: action-free LlamaForCausalLM; >0: HeadModelWithAction */
+  int32_t reward_head;     /* 1: reward_linear present */
+  /* ---- arithmetic types */
+  int32_t encode_dtype;    /* tokenize path (default IVG_F32: VQ indices must match the fp32 reference) */
+  int32_t decode_dtype;    /* detokenize path */
+  int32_t llm_dtype;       /* transformer */
+  /* ---- capacity the workspace / KV cache are sized for */
+  int32_t max_batch;       /* trajectories per call */
+  int32_t max_frames;      /* frames per clip (T) */
+  int32_t max_seq;         /* KV-cache length (0: max_position_embeddings) */
+} ivg_config;
+
+int ivg_create(const ivg_config* cfg, const ivg_tensor* weights, int n_weights, int device, ivg_engine** out);
+void ivg_destroy(ivg_engine* e);
+const char* ivg_last_error(const ivg_engine* e);   /* e may be NULL: error of the last failed ivg_create */
+const char* ivg_version(void);
+
+/* CompressiveVQModel.set_context_length (compressive_vq_model.py:154-158): keeps the LAST k frames of kv_pos_emb. */
+int ivg_set_context_length(ivg_engine* e, int context_length);
+
+/* CompressiveVQModel.tokenize (compressive_vq_model.py:164-220).
+ * pixels (B, T, 3, H, W); ids_out / labels_out int64 (B, 257*ctx - 1 + 17*(T - ctx)); labels_out may be NULL. */
+int ivg_tokenize(ivg_engine* e, const void* pixels, int pixel_dtype, int B, int T, int64_t* ids_out, int64_t* labels_out,
+                 ivg_stream stream);
+
+/* Context-only fast path for prediction: what predict.py:53-54 / vp/ivideogpt_interface.py:158-169 /
+ * mbrl/video_predictor.py:281-283 obtain by tokenizing zero-padded clips and slicing [:, :257*ctx].
+ * pixels (B, T >= ctx, 3, H, W): only the first ctx frames are read.  ids_out int64 (B, ids_stride >= 257*ctx):
+ * columns [0, 257*ctx) are written (context tokens, scf separators, trailing sdf). */
+int ivg_encode_context(ivg_engine* e, const void* pixels, int pixel_dtype, int B, int T, int64_t* ids_out, int64_t ids_stride,
+                       ivg_stream stream);
+
+/* CompressiveVQModel.detokenize (compressive_vq_model.py:222-277).
+ * ids int64 (B, 257*ctx - 1 + 17*F); pixels_out float32 (B, ctx + F, 3, H, W), unclamped.
+ * cache: NULL, or a handle from ivg_cache_create.  cache_mode 1 = fill it (return_cache=True), 2 = reuse it
+ * (cache=...): context frames are then not decoded again (their pixels are copied from the cache). */
+int ivg_detokenize(ivg_engine* e, const int64_t* ids, int B, int F, float* pixels_out, ivg_cache* cache, int cache_mode,
+                   ivg_stream stream);
+int ivg_cache_create(ivg_engine* e, int B, ivg_cache** out);
+void ivg_cache_destroy(ivg_engine* e, ivg_cache* c);
+
+/* LlamaForCausalLM.generate (predict.py:57-69) when actions == NULL: every new token is sampled;
+ * HeadModelWithAction.generate (action_model.py:56-121) when actions != NULL: the action embedding is added to the
+ * i-th sdf slot (action index i + ctx - 1) and the sdf after every 16 tokens is forced.
+ *   prompt   int64 (B, L0) row stride prompt_stride, L0 = 257*ctx
+ *   actions  float32 (B, act_T, action_dim) or NULL;  ctx = context length (only used with actions)
+ *   uniforms float32 (B, n_new) in [0,1) or NULL (NULL = greedy argmax); column j-1 drives new token j
+ *   ids_out  int64 (B, L0 + n_new): prompt followed by the new tokens
+ *   reward_out float32 (B) or NULL: reward_linear(last hidden state of the final step) (mbrl/video_predictor.py:311-313) */
+int ivg_generate(ivg_engine* e, const int64_t* prompt, int64_t prompt_stride, int B, int L0, int n_new, const float* actions,
+                 int act_T, int ctx, const float* uniforms, int top_k, int64_t* ids_out, float* reward_out, ivg_stream stream);
+
+/* Teacher-forced logits (LlamaForCausalLM.forward / HeadModelWithAction.forward, action_model.py:154-185):
+ * ids int64 (B, L); actions as above or NULL (added on every sdf slot 257*ctx - 1 + 17*i < L); logits_out float32 (B, L, vocab). */
+int ivg_logits(ivg_engine* e, const int64_t* ids, int B, int L, const float* actions, int act_T, int ctx, float* logits_out,
+               ivg_stream stream);
+
+/* ---- measurement hooks (bench.py): time one kernel class with HIP events on the launching stream */
+enum ivg_kernel_class { IVG_K_IGEMM_BF16 = 0, IVG_K_IGEMM_F32 = 1, IVG_K_COUNT = 2 };
+typedef struct {
+  int64_t launches;
+  double total_ms;      /* sum of per-launch durations (hipEventElapsedTime) */
+  double total_flops;   /* algorithmic: 2 * M * N * K per launch */
+  double total_bytes;   /* algorithmic: operands read once + output written once */
+} ivg_profile_stats;
+int ivg_profile_enable(ivg_engine* e, int kernel_class, int enable);
+int ivg_profile_read(ivg_engine* e, int kernel_class, ivg_profile_stats* out);   /* synchronises, then resets */
+
+/* ---- op-level entry points (unit parity tests call the kernels through these) */
+typedef struct {
+  const void* X; const void* W; void* Y; const void* R; const float* bias;
+  int32_t Nimg, Hin, Win, Cin, ldx, Hout, Wout, KH, KW, stride, pad, ups, N, ldw;
+  int64_t c_img, c_pix, c_ch, c_grp_stride;
+  int32_t c_grp, flags;
+  float alpha;
+  int32_t nb0, nb1, nb2;
+  int64_t sa[3], sw[3], sy[3];
+} ivg_igemm_args;
+int ivg_op_igemm(const ivg_igemm_args* a, int dtype, ivg_stream stream);
+int ivg_op_skinny(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy, int splits, int flags,
+                  int dtype, ivg_stream stream);
+int ivg_op_groupnorm(const void* X, void* Y, void* ws /* >= N*chunks*groups*16 B */, const float* gamma, const float* beta,
+                     const float* pos, int N, int P, int C, int groups, float eps, int silu, int dtype, ivg_stream stream);
+int ivg_op_softmax(const float* S, void* P, int64_t rows, int Lq, int Lk, int lds, int ldp, int causal, int dtype,
+                   ivg_stream stream);
+int ivg_op_vq_argmin(const float* z, const float* codebook, float* ee_ws /* n_e floats */, int64_t* out, int R, int n_e,
+                     ivg_stream stream);
+int ivg_op_add_rmsnorm(void* x, const float* part, int splits, const float* w, void* out, int M, int H, float eps, int dtype,
+                       ivg_stream stream);
+int ivg_op_conv_in(const void* video, int video_dtype, const float* w, const float* bias, void* Y, int dtype, int N, int per,
+                   int T_total, int t0, int H, int W, int C0, ivg_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IVG_H_ */

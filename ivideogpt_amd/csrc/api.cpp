@@ -1,0 +1,456 @@
+// C ABI of libivg (include/ivg.h): engine construction from a named weight table, workspace planning,
+// the tokenize / generate / detokenize entry points and the op-level hooks used by the parity tests.
+#include <cstdlib>
+#include <cstring>
+
+#include "engine_impl.h"
+
+using namespace ivg;
+
+static thread_local std::string g_create_err;
+
+namespace ivg {
+
+size_t dtype_size(DType d) { return d == BF16 ? 2 : 4; }
+
+struct Lookup {
+  ivg_engine* e;
+  bool ok = true;
+  const ivg_tensor* find(const std::string& name, int dtype, int64_t numel) {
+    auto it = e->wmap.find(name);
+    if (it == e->wmap.end()) { if (ok) e->err = "missing weight tensor '" + name + "'"; ok = false; return nullptr; }
+    const ivg_tensor& t = it->second;
+    int64_t n = 1;
+    for (int i = 0; i < t.ndim; ++i) n *= t.shape[i];
+    if (t.dtype != dtype || n != numel) {
+      if (ok) e->err = "weight tensor '" + name + "' has dtype " + std::to_string(t.dtype) + " / " + std::to_string(n) +
+                       " elements, expected dtype " + std::to_string(dtype) + " / " + std::to_string(numel);
+      ok = false;
+      return nullptr;
+    }
+    return &t;
+  }
+  const void* data(const std::string& name, int dtype, int64_t numel) {
+    const ivg_tensor* t = find(name, dtype, numel);
+    return t ? t->data : nullptr;
+  }
+  const float* f32(const std::string& name, int64_t numel) { return (const float*)data(name, IVG_F32, numel); }
+  ConvW conv(const std::string& n, int cin, int cout, int k, DType dt) {
+    ConvW c; c.cin = cin; c.cout = cout; c.k = k;
+    c.w = data(n + ".weight", (int)dt, (int64_t)cout * k * k * cin);
+    c.b = f32(n + ".bias", cout);
+    return c;
+  }
+  NormW norm(const std::string& n, int C) { NormW r; r.g = f32(n + ".weight", C); r.b = f32(n + ".bias", C); return r; }
+  ResnetW resnet(const std::string& n, int cin, int cout, DType dt) {
+    ResnetW r; r.cin = cin; r.cout = cout;
+    r.n1 = norm(n + ".norm1", cin); r.c1 = conv(n + ".conv1", cin, cout, 3, dt);
+    r.n2 = norm(n + ".norm2", cout); r.c2 = conv(n + ".conv2", cout, cout, 3, dt);
+    r.has_sc = cin != cout;
+    if (r.has_sc) r.sc = conv(n + ".conv_shortcut", cin, cout, 1, dt);
+    return r;
+  }
+  AttnW attn(const std::string& n, int C, DType dt) {
+    AttnW a; a.gn = norm(n + ".group_norm", C);
+    a.q = conv(n + ".to_q", C, C, 1, dt); a.k = conv(n + ".to_k", C, C, 1, dt);
+    a.v = conv(n + ".to_v", C, C, 1, dt); a.o = conv(n + ".to_out.0", C, C, 1, dt);
+    return a;
+  }
+  XAttW xatt(const std::string& n, int C, int side, int ctx0, DType dt) {
+    XAttW x; x.C = C; x.side = side; x.kv_rows = ctx0 * side * side;
+    x.kvn = norm(n + ".kv_norm", C); x.qn = norm(n + ".q_norm", C);
+    x.kv_pos = f32(n + ".kv_pos_emb", (int64_t)x.kv_rows * C);
+    x.q_pos = f32(n + ".q_pos_emb", (int64_t)side * side * C);
+    const char* w = (const char*)data(n + ".att.in_proj_weight", (int)dt, (int64_t)3 * C * C);
+    const float* b = f32(n + ".att.in_proj_bias", 3 * C);
+    auto part = [&](int i) { ConvW c; c.cin = C; c.cout = C; c.k = 1; c.w = w ? w + (size_t)i * C * C * dtype_size(dt) : nullptr; c.b = b ? b + i * C : nullptr; return c; };
+    x.q = part(0); x.k = part(1); x.v = part(2);
+    x.o = conv(n + ".att.out_proj", C, C, 1, dt);
+    return x;
+  }
+};
+
+int build_tokenizer(ivg_engine* e) {
+  const ivg_config& c = e->cfg;
+  const int nl = c.n_levels, lpb = c.layers_per_block, lat = c.latent_channels, dim = c.vq_embed_dim, p = c.patch_size;
+  const int* ch = c.block_out_channels;
+  Lookup L{e};
+  auto encoder = [&](const std::string& n, bool attn, bool cond, TrunkW& t) {
+    const DType dt = e->enc_dt;
+    t.conv_in_raw_w = L.f32(n + ".conv_in.weight", (int64_t)ch[0] * 27);
+    t.conv_in.b = L.f32(n + ".conv_in.bias", ch[0]);
+    int prev = ch[0], res = c.resolution;
+    for (int i = 0; i < nl; ++i) {
+      std::vector<ResnetW> blk;
+      for (int j = 0; j < lpb; ++j) blk.push_back(L.resnet(n + ".down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), j == 0 ? prev : ch[i], ch[i], dt));
+      t.blocks.push_back(blk);
+      ConvW ds;
+      if (i != nl - 1) { ds = L.conv(n + ".down_blocks." + std::to_string(i) + ".downsamplers.0.conv", ch[i], ch[i], 3, dt); res /= 2; }
+      t.resample.push_back(ds);
+      if (cond && res <= c.max_att_resolution)
+        t.xatt.push_back(L.xatt(n + ".cross_att_blocks." + std::to_string(t.xatt.size()), ch[i], res, c.context_length, dt));
+      prev = ch[i];
+    }
+    t.mid0 = L.resnet(n + ".mid_block.resnets.0", ch[nl - 1], ch[nl - 1], dt);
+    t.mid1 = L.resnet(n + ".mid_block.resnets.1", ch[nl - 1], ch[nl - 1], dt);
+    t.has_attn = attn;
+    if (attn) t.attn = L.attn(n + ".mid_block.attentions.0", ch[nl - 1], dt);
+    t.norm_out = L.norm(n + ".conv_norm_out", ch[nl - 1]);
+    t.conv_out = L.conv(n + ".conv_out", ch[nl - 1], lat, 3, dt);
+  };
+  auto decoder = [&](const std::string& n, bool attn, bool cond, TrunkW& t) {
+    const DType dt = e->dec_dt;
+    const int top = ch[nl - 1];
+    t.conv_in = L.conv(n + ".conv_in", lat, top, 3, dt);
+    t.mid0 = L.resnet(n + ".mid_block.resnets.0", top, top, dt);
+    t.mid1 = L.resnet(n + ".mid_block.resnets.1", top, top, dt);
+    t.has_attn = attn;
+    if (attn) t.attn = L.attn(n + ".mid_block.attentions.0", top, dt);
+    int prev = top, res = 16;
+    if (cond) t.xatt.push_back(L.xatt(n + ".cross_att_blocks.0", top, 16, c.context_length, dt));
+    for (int i = 0; i < nl; ++i) {
+      const int co = ch[nl - 1 - i];
+      std::vector<ResnetW> blk;
+      for (int j = 0; j < lpb + 1; ++j) blk.push_back(L.resnet(n + ".up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), j == 0 ? prev : co, co, dt));
+      t.blocks.push_back(blk);
+      ConvW us;
+      if (i != nl - 1) { us = L.conv(n + ".up_blocks." + std::to_string(i) + ".upsamplers.0.conv", co, co, 3, dt); res *= 2; }
+      t.resample.push_back(us);
+      if (cond && res <= c.max_att_resolution)
+        t.xatt.push_back(L.xatt(n + ".cross_att_blocks." + std::to_string(t.xatt.size()), co, res, c.context_length, dt));
+      prev = co;
+    }
+    t.norm_out = L.norm(n + ".conv_norm_out", ch[0]);
+    t.conv_out = L.conv(n + ".conv_out", ch[0], 3, 3, dt);
+  };
+  encoder("encoder", c.mid_block_add_attention != 0, false, e->enc);
+  encoder("cond_encoder", true, true, e->cenc);
+  decoder("decoder", c.mid_block_add_attention != 0, false, e->dec);
+  decoder("cond_decoder", true, true, e->cdec);
+  e->quant_conv = L.conv("quant_conv", lat, dim, 1, e->enc_dt);
+  e->quant_linear = L.conv("quant_linear", lat, dim, p, e->enc_dt);  // [dim][p*p*lat] with (ph, pw, c) feature order
+  e->post_quant_conv = L.conv("post_quant_conv", dim, lat, 1, e->dec_dt);
+  e->post_quant_linear = L.conv("post_quant_linear", dim, lat * p * p, 1, e->dec_dt);
+  e->cb_c = L.f32("quantize.embedding.weight", (int64_t)c.num_vq_embeddings * dim);
+  e->cb_d = L.f32("dynamics_quantize.embedding.weight", (int64_t)c.num_dyn_embeddings * dim);
+  return L.ok ? 0 : IVG_ERR_MISSING;
+}
+
+int build_transformer(ivg_engine* e) {
+  const ivg_config& c = e->cfg;
+  const DType dt = e->llm_dt;
+  const int H = c.hidden_size, I = c.intermediate_size, V = c.vocab_size;
+  Lookup L{e};
+  e->heads = c.num_heads; e->hd = H / c.num_heads;
+  e->Lmax = c.max_seq > 0 ? c.max_seq : c.max_position_embeddings;
+  e->layers.clear();
+  for (int l = 0; l < c.num_layers; ++l) {
+    const std::string b = "llm.layers." + std::to_string(l) + ".";
+    LayerW w;
+    w.ln1 = L.f32(b + "ln1", H); w.ln2 = L.f32(b + "ln2", H);
+    w.wqkv = L.data(b + "wqkv", (int)dt, (int64_t)3 * H * H);
+    w.wo = L.data(b + "wo", (int)dt, (int64_t)H * H);
+    w.wgu = L.data(b + "wgu", (int)dt, (int64_t)2 * I * H);
+    w.wdown = L.data(b + "wdown", (int)dt, (int64_t)H * I);
+    e->layers.push_back(w);
+  }
+  e->embed = L.data("llm.embed", (int)dt, (int64_t)V * H);
+  e->lm_head = L.data("llm.lm_head", (int)dt, (int64_t)V * H);
+  e->final_norm = L.f32("llm.norm", H);
+  e->rope_cos = L.f32("llm.rope_cos", (int64_t)c.max_position_embeddings * (e->hd / 2));
+  e->rope_sin = L.f32("llm.rope_sin", (int64_t)c.max_position_embeddings * (e->hd / 2));
+  if (c.action_dim > 0) {
+    e->act_w = L.f32("llm.action_linear.weight", (int64_t)H * c.action_dim);
+    e->act_b = L.f32("llm.action_linear.bias", H);
+  }
+  if (c.reward_head) {
+    e->rew_w = L.f32("llm.reward_linear.weight", H);
+    e->rew_b = L.f32("llm.reward_linear.bias", 1);
+  }
+  return L.ok ? 0 : IVG_ERR_MISSING;
+}
+
+// ---- measurement hooks
+void Run::prof_begin(DType dt, double flops, double bytes) {
+  ProfClass& pc = e->prof[dt == BF16 ? IVG_K_IGEMM_BF16 : IVG_K_IGEMM_F32];
+  if (!pc.enabled) return;
+  ProfSlot s;
+  if (!pc.pool.empty()) { s = pc.pool.back(); pc.pool.pop_back(); }
+  else { if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return; }
+  s.flops = flops; s.bytes = bytes;
+  (void)hipEventRecord(s.a, st);
+  pc.used.push_back(s);
+}
+void Run::prof_end(DType dt) {
+  ProfClass& pc = e->prof[dt == BF16 ? IVG_K_IGEMM_BF16 : IVG_K_IGEMM_F32];
+  if (!pc.enabled || pc.used.empty()) return;
+  (void)hipEventRecord(pc.used.back().b, st);
+}
+
+}  // namespace ivg
+
+#define API_CK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { e->err = std::string(#x) + ": " + hipGetErrorString(_e); return IVG_ERR_HIP; } } while (0)
+
+static int plan_and_allocate(ivg_engine* e) {
+  const ivg_config& c = e->cfg;
+  e->ws.planning = true; e->ws.off = 0; e->ws.high = 0;
+  Run r{e, nullptr, true};
+  const int B = c.max_batch, T = c.max_frames;
+  if (c.n_levels > 0) {
+    const int saved = e->ctx;
+    for (int ctx = 1; ctx <= c.context_length; ++ctx) {  // any context length set_context_length may select later
+      e->ctx = ctx;
+      if (T > ctx) {
+        int rc = r.tokenize(nullptr, F32, B, T, nullptr, 257 * ctx - 1 + 17 * (T - ctx), nullptr, false); if (rc) return rc;
+        rc = r.detokenize(nullptr, B, T - ctx, nullptr, nullptr, 0); if (rc) return rc;
+      }
+    }
+    e->ctx = saved;
+  }
+  if (c.num_layers > 0) {
+    const int Lpre = std::min(e->Lmax, 257 * std::max(1, c.context_length));
+    int rc = r.generate(nullptr, 0, B, Lpre, 1, nullptr, 0, 1, nullptr, 0, nullptr, nullptr); if (rc) return rc;
+  }
+  e->ws.cap = e->ws.high + (1 << 20);
+  API_CK(hipMalloc((void**)&e->ws.base, e->ws.cap));
+  e->ws.planning = false; e->ws.off = 0;
+  return 0;
+}
+
+extern "C" {
+
+const char* ivg_version(void) { return "libivg 0.1 (gfx950)"; }
+
+const char* ivg_last_error(const ivg_engine* e) { return e ? e->err.c_str() : g_create_err.c_str(); }
+
+void ivg_destroy(ivg_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  (void)hipDeviceSynchronize();
+  for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
+  for (int k = 0; k < IVG_K_COUNT; ++k) {
+    for (auto& s : e->prof[k].used) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+    for (auto& s : e->prof[k].pool) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+  }
+  if (e->ws.base) (void)hipFree(e->ws.base);
+  if (e->ee_c) (void)hipFree(e->ee_c);
+  if (e->ee_d) (void)hipFree(e->ee_d);
+  if (e->kv) (void)hipFree(e->kv);
+  if (e->vt) (void)hipFree(e->vt);
+  if (e->gen_buf) (void)hipFree(e->gen_buf);
+  delete e;
+}
+
+int ivg_create(const ivg_config* cfg, const ivg_tensor* weights, int n_weights, int device, ivg_engine** out) {
+  if (!cfg || !out) { g_create_err = "ivg_create: null argument"; return IVG_ERR_INVALID; }
+  ivg_engine* e = new ivg_engine();
+  e->cfg = *cfg; e->device = device;
+  auto bail = [&](int code) { g_create_err = e->err; ivg_destroy(e); return code; };
+  if (hipSetDevice(device) != hipSuccess) { e->err = "hipSetDevice failed (no MI355X visible?)"; return bail(IVG_ERR_HIP); }
+  const char* ng = getenv("IVG_NO_GRAPH");
+  e->use_graph = !(ng && ng[0] == '1');
+  e->enc_dt = (DType)cfg->encode_dtype; e->dec_dt = (DType)cfg->decode_dtype; e->llm_dt = (DType)cfg->llm_dtype;
+  e->ctx = cfg->context_length > 0 ? cfg->context_length : 1;
+  for (int i = 0; i < n_weights; ++i) e->wmap[weights[i].name] = weights[i];
+  if (cfg->max_batch <= 0 || cfg->max_frames <= 0) { e->err = "ivg_create: max_batch / max_frames must be positive"; return bail(IVG_ERR_INVALID); }
+  if (cfg->n_levels > 0) {
+    const ivg_config& c = *cfg;
+    if (c.n_levels > 8 || c.vq_embed_dim != 64 || c.patch_size != 4 || (c.resolution >> (c.n_levels - 1)) != 16 || c.latent_channels % 32 != 0) {
+      e->err = "ivg_create: unsupported tokenizer geometry (needs vq_embed_dim 64, patch 4, 16x16 latent grid)"; return bail(IVG_ERR_INVALID);
+    }
+    int rc = build_tokenizer(e); if (rc) return bail(rc);
+    if (hipMalloc((void**)&e->ee_c, (size_t)c.num_vq_embeddings * 4) != hipSuccess || hipMalloc((void**)&e->ee_d, (size_t)c.num_dyn_embeddings * 4) != hipSuccess) {
+      e->err = "hipMalloc failed"; return bail(IVG_ERR_HIP);
+    }
+    if (launch_sqnorm_rows(e->cb_c, e->ee_c, c.num_vq_embeddings, c.vq_embed_dim, nullptr) || launch_sqnorm_rows(e->cb_d, e->ee_d, c.num_dyn_embeddings, c.vq_embed_dim, nullptr)) {
+      e->err = "codebook norm kernel failed to launch (is this a gfx950 device?)"; return bail(IVG_ERR_HIP);
+    }
+  }
+  if (cfg->num_layers > 0) {
+    int rc = build_transformer(e); if (rc) return bail(rc);
+    const int kb = std::min(cfg->max_batch, 128);
+    const size_t kvb = (size_t)cfg->num_layers * 2 * kb * e->heads * e->Lmax * e->hd * dtype_size(e->llm_dt);
+    const size_t vtb = (size_t)kb * e->heads * e->hd * ((e->Lmax + 63) / 64 * 64) * dtype_size(e->llm_dt);
+    e->gen_bytes = gen_buffer_bytes(e);
+    if (hipMalloc((void**)&e->kv, kvb) != hipSuccess || hipMalloc((void**)&e->vt, vtb) != hipSuccess || hipMalloc((void**)&e->gen_buf, e->gen_bytes) != hipSuccess) {
+      e->err = "hipMalloc of the KV cache failed"; return bail(IVG_ERR_HIP);
+    }
+    (void)hipMemset(e->vt, 0, vtb);
+    (void)hipMemset(e->gen_buf, 0, e->gen_bytes);
+  }
+  int rc = plan_and_allocate(e);
+  if (rc) return bail(rc);
+  if (hipDeviceSynchronize() != hipSuccess) { e->err = "device error during engine construction"; return bail(IVG_ERR_HIP); }
+  *out = e;
+  return IVG_OK;
+}
+
+int ivg_set_context_length(ivg_engine* e, int k) {
+  if (!e) return IVG_ERR_INVALID;
+  if (k < 1 || k > e->cfg.context_length) return e->fail(IVG_ERR_INVALID, "set_context_length: k must be in [1, pretrained context_length]");
+  e->ctx = k;
+  return IVG_OK;
+}
+
+static int check_tok(ivg_engine* e, int B, int T, const char* who) {
+  if (e->cfg.n_levels <= 0) return e->fail(IVG_ERR_INVALID, std::string(who) + ": engine was created without a tokenizer");
+  if (B <= 0 || B > e->cfg.max_batch || T > e->cfg.max_frames)
+    return e->fail(IVG_ERR_CAPACITY, std::string(who) + ": batch " + std::to_string(B) + " x " + std::to_string(T) + " frames exceeds the capacity the engine was created with (" +
+                   std::to_string(e->cfg.max_batch) + " x " + std::to_string(e->cfg.max_frames) + ")");
+  return 0;
+}
+
+int ivg_tokenize(ivg_engine* e, const void* pixels, int pixel_dtype, int B, int T, int64_t* ids_out, int64_t* labels_out, ivg_stream stream) {
+  if (!e) return IVG_ERR_INVALID;
+  IVG_TRY(check_tok(e, B, T, "tokenize"));
+  if (T < e->ctx + 1) return e->fail(IVG_ERR_INVALID, "tokenize: needs at least one future frame (T >= context_length + 1)");
+  Run r{e, (hipStream_t)stream, false};
+  e->ws.off = 0;
+  return r.tokenize(pixels, (DType)pixel_dtype, B, T, ids_out, 257L * e->ctx - 1 + 17L * (T - e->ctx), labels_out, false);
+}
+
+int ivg_encode_context(ivg_engine* e, const void* pixels, int pixel_dtype, int B, int T, int64_t* ids_out, int64_t ids_stride, ivg_stream stream) {
+  if (!e) return IVG_ERR_INVALID;
+  IVG_TRY(check_tok(e, B, std::min(T, e->cfg.max_frames), "encode_context"));
+  if (T < e->ctx || ids_stride < 257L * e->ctx) return e->fail(IVG_ERR_INVALID, "encode_context: T < context_length or ids_stride < 257*ctx");
+  Run r{e, (hipStream_t)stream, false};
+  e->ws.off = 0;
+  return r.tokenize(pixels, (DType)pixel_dtype, B, T, ids_out, ids_stride, nullptr, true);
+}
+
+int ivg_detokenize(ivg_engine* e, const int64_t* ids, int B, int F, float* pixels_out, ivg_cache* cache, int cache_mode, ivg_stream stream) {
+  if (!e) return IVG_ERR_INVALID;
+  IVG_TRY(check_tok(e, B, e->ctx + F, "detokenize"));
+  if (F < 0) return e->fail(IVG_ERR_INVALID, "detokenize: token count does not match 257*ctx - 1 + 17*F");
+  Run r{e, (hipStream_t)stream, false};
+  e->ws.off = 0;
+  return r.detokenize(ids, B, F, pixels_out, cache, cache ? cache_mode : 0);
+}
+
+int ivg_cache_create(ivg_engine* e, int B, ivg_cache** out) {
+  if (!e || !out || e->cfg.n_levels <= 0) return IVG_ERR_INVALID;
+  const ivg_config& c = e->cfg;
+  ivg_cache* k = new ivg_cache();
+  k->B = B;
+  const int ctx = c.context_length, res = c.resolution, nl = c.n_levels;
+  if (hipMalloc((void**)&k->ctx_pixels, (size_t)B * ctx * 3 * res * res * 4) != hipSuccess) { delete k; return e->fail(IVG_ERR_HIP, "hipMalloc failed"); }
+  // same order as decoder_feature_plan: [1] then every up level whose side <= max_att
+  auto add = [&](int side, int C) { void* p = nullptr; if (hipMalloc(&p, (size_t)B * ctx * side * side * C * dtype_size(e->dec_dt)) == hipSuccess) k->feat.push_back(p); };
+  add(16, c.block_out_channels[nl - 1]);
+  int s = 16;
+  for (int i = 0; i < nl; ++i) { if (i != nl - 1) s *= 2; if (s <= c.max_att_resolution) add(s, c.block_out_channels[nl - 1 - i]); }
+  *out = k;
+  return IVG_OK;
+}
+
+void ivg_cache_destroy(ivg_engine* e, ivg_cache* c) {
+  if (!c) return;
+  if (e) (void)hipSetDevice(e->device);
+  (void)hipDeviceSynchronize();
+  if (c->ctx_pixels) (void)hipFree(c->ctx_pixels);
+  for (void* p : c->feat) (void)hipFree(p);
+  delete c;
+}
+
+int ivg_generate(ivg_engine* e, const int64_t* prompt, int64_t prompt_stride, int B, int L0, int n_new, const float* actions, int act_T,
+                 int ctx, const float* uniforms, int top_k, int64_t* ids_out, float* reward_out, ivg_stream stream) {
+  if (!e) return IVG_ERR_INVALID;
+  if (e->cfg.num_layers <= 0) return e->fail(IVG_ERR_INVALID, "generate: engine was created without a transformer");
+  if (B <= 0 || n_new < 1 || L0 < 1 || L0 + n_new > e->Lmax)
+    return e->fail(IVG_ERR_CAPACITY, "generate: sequence of " + std::to_string(L0 + n_new) + " tokens exceeds the KV cache (" + std::to_string(e->Lmax) + ")");
+  if (actions && (e->cfg.action_dim <= 0 || !e->act_w)) return e->fail(IVG_ERR_INVALID, "generate: actions given but the model is action-free");
+  if (actions && (act_T > e->cfg.max_frames || ((n_new + 1) / 17) + ctx - 1 > act_T)) return e->fail(IVG_ERR_INVALID, "generate: action tensor too short / longer than max_frames");
+  Run r{e, (hipStream_t)stream, false};
+  e->ws.off = 0;
+  return r.generate(prompt, prompt_stride, B, L0, n_new, actions, act_T, ctx, uniforms, top_k, ids_out, reward_out);
+}
+
+int ivg_logits(ivg_engine* e, const int64_t* ids, int B, int L, const float* actions, int act_T, int ctx, float* logits_out, ivg_stream stream) {
+  if (!e) return IVG_ERR_INVALID;
+  if (e->cfg.num_layers <= 0) return e->fail(IVG_ERR_INVALID, "logits: engine was created without a transformer");
+  if (B <= 0 || B > std::min(e->cfg.max_batch, 128) || L > e->Lmax) return e->fail(IVG_ERR_CAPACITY, "logits: batch or length exceeds capacity");
+  Run r{e, (hipStream_t)stream, false};
+  e->ws.off = 0;
+  // capacity check of the workspace for this (B, L): plan first
+  {
+    Run p{e, nullptr, true};
+    const size_t save_high = e->ws.high;
+    e->ws.planning = true; e->ws.high = 0; e->ws.off = 0;
+    p.prefill(nullptr, 0, B, L, nullptr, 0, ctx, true, (float*)1, nullptr, nullptr);
+    const size_t need = e->ws.high;
+    e->ws.planning = false; e->ws.high = save_high; e->ws.off = 0;
+    if (need > e->ws.cap) return e->fail(IVG_ERR_CAPACITY, "logits: workspace too small for this (B, L)");
+  }
+  const void* act_emb = nullptr;
+  if (actions) {
+    if (e->cfg.action_dim <= 0 || !e->act_w) return e->fail(IVG_ERR_INVALID, "logits: actions given but the model is action-free");
+    char* buf = (char*)e->ws.alloc((size_t)B * act_T * e->cfg.hidden_size * dtype_size(e->llm_dt));
+    int rc = launch_action_embed(actions, e->act_w, e->act_b, buf, e->llm_dt, B * act_T, e->cfg.action_dim, e->cfg.hidden_size, (hipStream_t)stream);
+    if (rc) return e->fail(IVG_ERR_HIP, "action_embed launch failed");
+    act_emb = buf;
+  }
+  return r.prefill(ids, L, B, L, act_emb, act_T, ctx, true, logits_out, nullptr, nullptr);
+}
+
+int ivg_profile_enable(ivg_engine* e, int k, int enable) {
+  if (!e || k < 0 || k >= IVG_K_COUNT) return IVG_ERR_INVALID;
+  e->prof[k].enabled = enable != 0;
+  return IVG_OK;
+}
+
+int ivg_profile_read(ivg_engine* e, int k, ivg_profile_stats* out) {
+  if (!e || !out || k < 0 || k >= IVG_K_COUNT) return IVG_ERR_INVALID;
+  API_CK(hipDeviceSynchronize());
+  ProfClass& pc = e->prof[k];
+  out->launches = 0; out->total_ms = 0; out->total_flops = 0; out->total_bytes = 0;
+  for (auto& s : pc.used) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { out->launches++; out->total_ms += ms; out->total_flops += s.flops; out->total_bytes += s.bytes; }
+    pc.pool.push_back(s);
+  }
+  pc.used.clear();
+  return IVG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- op-level hooks
+int ivg_op_igemm(const ivg_igemm_args* a, int dtype, ivg_stream stream) {
+  IgemmArgs g;
+  g.X = a->X; g.W = a->W; g.Y = a->Y; g.R = a->R; g.bias = a->bias;
+  g.Nimg = a->Nimg; g.Hin = a->Hin; g.Win = a->Win; g.Cin = a->Cin; g.ldx = a->ldx; g.Hout = a->Hout; g.Wout = a->Wout;
+  g.KH = a->KH; g.KW = a->KW; g.stride = a->stride; g.pad = a->pad; g.ups = a->ups; g.N = a->N; g.ldw = a->ldw;
+  g.c_img = a->c_img; g.c_pix = a->c_pix; g.c_ch = a->c_ch; g.c_grp = a->c_grp; g.c_grp_stride = a->c_grp_stride;
+  g.flags = a->flags; g.alpha = a->alpha; g.nb0 = a->nb0; g.nb1 = a->nb1; g.nb2 = a->nb2;
+  for (int i = 0; i < 3; ++i) { g.sa[i] = a->sa[i]; g.sw[i] = a->sw[i]; g.sy[i] = a->sy[i]; }
+  return launch_igemm(g, (DType)dtype, (hipStream_t)stream) ? IVG_ERR_HIP : IVG_OK;
+}
+
+int ivg_op_skinny(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy, int splits, int flags, int dtype, ivg_stream stream) {
+  SkinnyArgs s; s.X = X; s.W = W; s.Y = Y; s.M = M; s.N = N; s.K = K; s.ldx = ldx; s.ldw = ldw; s.ldy = ldy; s.splits = splits; s.flags = flags;
+  return launch_skinny(s, (DType)dtype, (hipStream_t)stream) ? IVG_ERR_HIP : IVG_OK;
+}
+
+int ivg_op_groupnorm(const void* X, void* Y, void* ws, const float* gamma, const float* beta, const float* pos, int N, int P, int C, int groups,
+                     float eps, int silu, int dtype, ivg_stream stream) {
+  return launch_groupnorm(X, Y, ws, gamma, beta, pos, N, P, C, groups, eps, silu, (DType)dtype, (hipStream_t)stream) ? IVG_ERR_HIP : IVG_OK;
+}
+
+int ivg_op_softmax(const float* S, void* P, int64_t rows, int Lq, int Lk, int lds, int ldp, int causal, int dtype, ivg_stream stream) {
+  return launch_softmax(S, P, rows, Lq, Lk, lds, ldp, causal, (DType)dtype, (hipStream_t)stream) ? IVG_ERR_HIP : IVG_OK;
+}
+
+int ivg_op_vq_argmin(const float* z, const float* codebook, float* ee_ws, int64_t* out, int R, int n_e, ivg_stream stream) {
+  if (launch_sqnorm_rows(codebook, ee_ws, n_e, 64, (hipStream_t)stream)) return IVG_ERR_HIP;
+  TokMap mp{1, 1, 1, 0, 1};  // identity: row r -> out[r]
+  return launch_vq_argmin(z, codebook, ee_ws, out, mp, 0, R, n_e, (hipStream_t)stream) ? IVG_ERR_HIP : IVG_OK;
+}
+
+int ivg_op_add_rmsnorm(void* x, const float* part, int splits, const float* w, void* out, int M, int H, float eps, int dtype, ivg_stream stream) {
+  return launch_add_rmsnorm(x, H, part, splits, w, out, M, H, eps, (DType)dtype, (hipStream_t)stream) ? IVG_ERR_HIP : IVG_OK;
+}
+
+int ivg_op_conv_in(const void* video, int video_dtype, const float* w, const float* bias, void* Y, int dtype, int N, int per, int T_total, int t0,
+                   int H, int W, int C0, ivg_stream stream) {
+  return launch_conv_in(video, (DType)video_dtype, w, bias, Y, (DType)dtype, N, per, T_total, t0, H, W, C0, (hipStream_t)stream) ? IVG_ERR_HIP : IVG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,89 @@
+// Engine: owns the workspace arena, KV cache and the layer graphs of the tokenizer and transformer.
+#pragma once
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/ivg.h"
+#include "ops.h"
+
+namespace ivg {
+
+struct Arena {
+  char* base = nullptr;
+  size_t cap = 0, off = 0, high = 0;
+  bool planning = true;  // planning pass: no memory, only the high-water mark
+  void* alloc(size_t bytes) {
+    off = (off + 255) & ~(size_t)255;
+    void* p = planning ? (void*)(uintptr_t)(0x1000 + off) : (void*)(base + off);
+    off += bytes;
+    if (off > high) high = off;
+    return p;
+  }
+  size_t mark() const { return off; }
+  void reset(size_t m) { off = m; }
+};
+
+struct ConvW { const void* w = nullptr; const float* b = nullptr; int cin = 0, cout = 0, k = 1; };
+struct NormW { const float* g = nullptr; const float* b = nullptr; };
+struct ResnetW { NormW n1, n2; ConvW c1, c2, sc; bool has_sc = false; int cin = 0, cout = 0; };
+struct AttnW { NormW gn; ConvW q, k, v, o; };
+struct XAttW { NormW kvn, qn; const float* kv_pos = nullptr; const float* q_pos = nullptr; int kv_rows = 0;
+               ConvW q, k, v, o; int C = 0, side = 0; };
+struct TrunkW {  // encoder or decoder
+  const float* conv_in_raw_w = nullptr;  // encoders: fp32 [C0][3][3][3]
+  ConvW conv_in;                          // decoders: packed (latent -> C)
+  std::vector<std::vector<ResnetW>> blocks;
+  std::vector<ConvW> resample;            // down/up-sampler conv of each level (cin = 0: none)
+  ResnetW mid0, mid1;
+  bool has_attn = false;
+  AttnW attn;
+  NormW norm_out;
+  ConvW conv_out;
+  std::vector<XAttW> xatt;
+};
+struct LayerW { const float* ln1; const float* ln2; const void* wqkv; const void* wo; const void* wgu; const void* wdown; };
+
+struct Feature { void* p = nullptr; int side = 0, C = 0; };
+
+struct ProfSlot { hipEvent_t a, b; double flops, bytes; };
+struct ProfClass { bool enabled = false; std::vector<ProfSlot> used; std::vector<ProfSlot> pool; };
+
+}  // namespace ivg
+
+struct ivg_cache {
+  int B = 0;
+  float* ctx_pixels = nullptr;             // [B][ctx][3][H][W]
+  std::vector<void*> feat;                  // un-repeated per-trajectory context decoder features (NHWC)
+  bool filled = false;
+};
+
+struct ivg_engine {
+  ivg_config cfg;
+  int device = 0;
+  std::string err;
+  std::unordered_map<std::string, ivg_tensor> wmap;
+  ivg::Arena ws;
+  int ctx = 1;  // current context length (set_context_length)
+  ivg::DType enc_dt, dec_dt, llm_dt;
+  // tokenizer
+  ivg::TrunkW enc, cenc, dec, cdec;
+  ivg::ConvW quant_conv, post_quant_conv, quant_linear, post_quant_linear;
+  const float* cb_c = nullptr; const float* cb_d = nullptr;
+  float* ee_c = nullptr; float* ee_d = nullptr;
+  // transformer
+  std::vector<ivg::LayerW> layers;
+  const void* embed = nullptr; const void* lm_head = nullptr; const float* final_norm = nullptr;
+  const float* rope_cos = nullptr; const float* rope_sin = nullptr;
+  const float* act_w = nullptr; const float* act_b = nullptr; const float* rew_w = nullptr; const float* rew_b = nullptr;
+  int heads = 0, hd = 0, Lmax = 0;
+  char* kv = nullptr;        // [layers][2][Bmax][heads][Lmax][hd]
+  char* vt = nullptr;        // [Bmax][heads][hd][Lmax] transposed V scratch for the prefill
+  char* gen_buf = nullptr;   // persistent decode-step buffers (fixed addresses -> graph replay)
+  size_t gen_bytes = 0;
+  std::unordered_map<std::string, hipGraphExec_t> graphs;
+  bool use_graph = true;
+  ivg::ProfClass prof[IVG_K_COUNT];
+
+  int fail(int code, const std::string& msg) { err = msg; return code; }
+};

@@ -1,0 +1,53 @@
+// Per-call execution context shared by tokenizer.cpp / transformer.cpp / api.cpp.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "engine.h"
+
+namespace ivg {
+
+#define IVG_TRY(x) do { int _r = (x); if (_r != 0) return _r; } while (0)
+
+struct Run {
+  ivg_engine* e;
+  hipStream_t st;
+  bool planning;  // true: only walk the allocation plan (no launches) to size the workspace
+
+  // ---- primitives (tokenizer.cpp)
+  int conv(DType dt, const void* X, int N, int H, int W, const ConvW& c, void* Y, int stride, int ups, const void* Rres, int flags,
+           int out_f32);
+  int gemm(DType dt, const IgemmArgs& a, double flops, double bytes);
+  int linear(DType dt, const void* X, long rows, const ConvW& c, void* Y, const void* Rres, int flags, int out_f32);
+  int gnorm(DType dt, const void* X, void* Y, int N, int P, int C, const NormW& n, float eps, int silu, const float* pos);
+  int resnet(DType dt, const void* x, int N, int H, int W, const ResnetW& r, void* out);
+  int self_attention(DType dt, const void* x, int N, int P, int C, const AttnW& a, void* out);
+  int xatt_project_kv(DType dt, const void* feat, int B, const XAttW& x, void* Kp, void* VpT);
+  int cross_attention(DType dt, const void* z, int B, int F, const XAttW& x, const void* Kp, const void* VpT, void* out);
+  int encoder_trunk(const TrunkW& w, const void* pixels, DType pix_dt, int B, int per, int T_total, int t0,
+                    std::vector<Feature>* keep, const std::vector<Feature>* cond, void* latent);
+  int decoder_trunk(const TrunkW& w, const void* z, int B, int per, int T_total, int t0, std::vector<Feature>* keep,
+                    const std::vector<Feature>* cond, float* out_pixels);
+  int tokenize(const void* pixels, DType pix_dt, int B, int T, int64_t* ids, int64_t ids_stride, int64_t* labels, bool ctx_only);
+  int detokenize(const int64_t* ids, int B, int F, float* out_pixels, ivg_cache* cache, int cache_mode);
+
+  // ---- transformer (transformer.cpp)
+  int prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const void* act_emb, int act_T, int ctx, bool all_slots,
+              float* logits_all /* [B][L][V] or null */, float* logits_last /* [B][V] or null */, void* hidden_last);
+  int decode_step(int B, const SampleArgs& sa);
+  int generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, int n_new, const float* actions, int act_T, int ctx,
+               const float* uniforms, int top_k, int64_t* ids_out, float* reward_out);
+
+  // ---- measurement
+  void prof_begin(DType dt, double flops, double bytes);
+  void prof_end(DType dt);
+};
+
+size_t dtype_size(DType d);
+int build_tokenizer(ivg_engine* e);
+int build_transformer(ivg_engine* e);
+size_t gen_buffer_bytes(const ivg_engine* e);
+
+}  // namespace ivg

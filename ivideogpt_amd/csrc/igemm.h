@@ -1,0 +1,59 @@
+// Implicit-GEMM convolution / batched GEMM on MFMA (gfx950).  See igemm.hip.
+#pragma once
+#include "common.h"
+
+namespace ivg {
+
+enum IgemmFlags : int {
+  IG_BIAS_N = 1,     // + bias[n]           (fp32)
+  IG_BIAS_M = 2,     // + bias[m]           (fp32; used by the transposed V projection)
+  IG_RESIDUAL = 4,   // + R[m][n]           (element type T, same addressing as the output)
+  IG_SILU = 8,       // silu(.) after bias/residual
+  IG_GLU = 16,       // weight rows packed [16 gate | 16 up] per 32: out[m][j] = silu(gate) * up, N_out = N/2
+  IG_OUT_F32 = 32,   // output is fp32 regardless of T (attention scores, logits, final pixels)
+};
+
+// Y[z](m, n) = epi( alpha * sum_k A[z](m, k) * W[z][n][k] )
+//   A(m, k): gathered from an NHWC activation tensor  X[img][ih][iw][c]  (pixel stride ldx):
+//            m -> (img, oh, ow);  k -> (kh, kw, c);  ih = oh*stride + kh - pad  (ups: ih = (oh + kh - 1) >> 1)
+//   W[n][k]: weights, K contiguous (row stride ldw), K ordered (kh, kw, c)
+//   Y addressing: base + (img / c_grp) * c_grp_stride + (img % c_grp) * c_img + pix * c_pix + n * c_ch
+// A plain row-major GEMM is the 1x1 case with Hin = Hout = 1, Win = Wout = M.
+struct IgemmArgs {
+  const void* X = nullptr;
+  const void* W = nullptr;
+  void* Y = nullptr;
+  const void* R = nullptr;
+  const float* bias = nullptr;
+  int Nimg = 1, Hin = 1, Win = 1, Cin = 0, ldx = 0;
+  int Hout = 1, Wout = 1;
+  int KH = 1, KW = 1, stride = 1, pad = 0, ups = 0;
+  int N = 0, ldw = 0;
+  long c_img = 0, c_pix = 0, c_ch = 1;
+  int c_grp = 1;
+  long c_grp_stride = 0;
+  int flags = 0;
+  float alpha = 1.0f;
+  // batch z = (z0 * nb1 + z1) * nb2 + z2 ; element strides per operand
+  int nb0 = 1, nb1 = 1, nb2 = 1;
+  long sa[3] = {0, 0, 0}, sw[3] = {0, 0, 0}, sy[3] = {0, 0, 0};
+};
+
+// dtype = element type of X / W / R (and of Y unless IG_OUT_F32).  Returns hipError_t as int.
+int launch_igemm(const IgemmArgs& a, DType dtype, hipStream_t stream);
+
+// Skinny GEMM for the autoregressive decode steps (M <= 128 rows, weights streamed once):
+//   Y[m][n] = epi( sum_k X[m][k] * W[n][k] ),  X row stride ldx, W row stride ldw.
+// splits > 1: writes fp32 partials P[s][m][n] (consumer sums them in fixed order); no epilogue.
+struct SkinnyArgs {
+  const void* X = nullptr;
+  const void* W = nullptr;
+  void* Y = nullptr;       // T, or fp32 when IG_OUT_F32 / splits > 1
+  int M = 0, N = 0, K = 0, ldx = 0, ldw = 0, ldy = 0;
+  int splits = 1;
+  int flags = 0;           // IG_GLU | IG_OUT_F32
+};
+int launch_skinny(const SkinnyArgs& a, DType dtype, hipStream_t stream);
+int skinny_pick_splits(int N, int K, DType dtype);
+
+}  // namespace ivg

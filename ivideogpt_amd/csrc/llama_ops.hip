@@ -1,0 +1,396 @@
+// Transformer-side kernels that are not GEMMs (SURVEY.md 2.4 K11, K15, K16 decode, K18, K19).
+// All step-dependent scalars (cache length, index of the token being decided) live in a device-side
+// StepState so the whole per-token kernel sequence has constant arguments and can be captured once
+// into a hipGraph and replayed for every generated token.
+#include "ops.h"
+
+namespace ivg {
+
+// ------------------------------------------------------------------------------------------------ embedding
+template <typename T>
+__global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ ids, long id_stride, const T* __restrict__ E,
+                                                    T* __restrict__ x, int L, int H) {
+  constexpr int VEC = Traits<T>::VEC;
+  const int row = blockIdx.x;  // b * L + l
+  const int b = row / L, l = row - b * L;
+  const long id = ids[(long)b * id_stride + l];
+  const T* src = E + id * H;
+  T* dst = x + (long)row * H;
+  for (int c = threadIdx.x * VEC; c < H; c += 256 * VEC) *(Chunk16*)(dst + c) = *(const Chunk16*)(src + c);
+}
+
+int launch_embed(const int64_t* ids, long id_stride, const void* E, void* x, DType dt, int B, int L, int H, hipStream_t st) {
+  if (B * L <= 0) return 0;
+  if (dt == BF16) hipLaunchKernelGGL(embed_kernel<bf16_t>, dim3(B * L), dim3(256), 0, st, ids, id_stride, (const bf16_t*)E, (bf16_t*)x, L, H);
+  else hipLaunchKernelGGL(embed_kernel<float>, dim3(B * L), dim3(256), 0, st, ids, id_stride, (const float*)E, (float*)x, L, H);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ RoPE + KV append
+// thread = (row m = b*L + l, head h, pair i < hd/2).  HF rotate_half convention:
+//   out[i] = x[i]*cos - x[i+hd/2]*sin ;  out[i+hd/2] = x[i+hd/2]*cos + x[i]*sin
+template <typename T>
+__global__ __launch_bounds__(256) void rope_kv_kernel(T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
+                                                      T* __restrict__ vt, int ldvt, const float* __restrict__ cosT,
+                                                      const float* __restrict__ sinT, int B, int L, int heads, int hd, int Lmax,
+                                                      const StepState* __restrict__ state, int pos0) {
+  const int half = hd / 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)B * L * heads * half;
+  if (idx >= total) return;
+  const int i = (int)(idx % half);
+  long t = idx / half;
+  const int h = (int)(t % heads); t /= heads;
+  const int l = (int)(t % L);
+  const int b = (int)(t / L);
+  const int base_pos = state ? state->pos : pos0;
+  const int pos = base_pos + l;
+  const int H = heads * hd;
+  T* row = qkv + ((long)b * L + l) * 3 * H;
+  const float c = cosT[(long)pos * half + i], s = sinT[(long)pos * half + i];
+  T* q = row + h * hd;
+  const float q1 = to_f32(q[i]), q2 = to_f32(q[i + half]);
+  q[i] = from_f32<T>(q1 * c - q2 * s);
+  q[i + half] = from_f32<T>(q2 * c + q1 * s);
+  const T* k = row + H + h * hd;
+  const float k1 = to_f32(k[i]), k2 = to_f32(k[i + half]);
+  T* kdst = kc + (((long)b * heads + h) * Lmax + pos) * hd;
+  kdst[i] = from_f32<T>(k1 * c - k2 * s);
+  kdst[i + half] = from_f32<T>(k2 * c + k1 * s);
+  const T* v = row + 2 * H + h * hd;
+  T* vdst = vc + (((long)b * heads + h) * Lmax + pos) * hd;
+  const T v1 = v[i], v2 = v[i + half];
+  vdst[i] = v1;
+  vdst[i + half] = v2;
+  if (vt) {
+    T* tb = vt + ((long)b * heads + h) * hd * ldvt;
+    tb[(long)i * ldvt + l] = v1;
+    tb[(long)(i + half) * ldvt + l] = v2;
+  }
+}
+
+int launch_rope_kv(void* qkv, void* kc, void* vc, void* vt, int ldvt, const float* cosT, const float* sinT, int B, int L,
+                   int heads, int hd, int Lmax, const StepState* state, int pos0, DType dt, hipStream_t st) {
+  const long total = (long)B * L * heads * (hd / 2);
+  if (total <= 0) return 0;
+  dim3 g(cdiv(total, 256));
+  if (dt == BF16)
+    hipLaunchKernelGGL(rope_kv_kernel<bf16_t>, g, dim3(256), 0, st, (bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc, (bf16_t*)vt, ldvt, cosT,
+                       sinT, B, L, heads, hd, Lmax, state, pos0);
+  else
+    hipLaunchKernelGGL(rope_kv_kernel<float>, g, dim3(256), 0, st, (float*)qkv, (float*)kc, (float*)vc, (float*)vt, ldvt, cosT, sinT,
+                       B, L, heads, hd, Lmax, state, pos0);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ decode attention
+// One workgroup per (b, head).  HBM-bound stream of the K and V rows of the cache (coalesced: LPK lanes
+// share one row, 16 bytes each).  Two passes over LDS-held scores -> deterministic reduction order.
+template <typename T>
+__global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ qkv, const T* __restrict__ kc,
+                                                          const T* __restrict__ vc, T* __restrict__ out, int heads, int hd,
+                                                          int Lmax, const StepState* __restrict__ state) {
+  constexpr int VEC = Traits<T>::VEC;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lpk = hd / VEC;          // lanes per key row (8 for bf16 hd=64, 16 for fp32)
+  const int gpb = 256 / lpk;         // key groups per workgroup
+  float* sc = (float*)smem;          // [Lmax] scores
+  float* red = sc + Lmax;            // [gpb][hd] partial outputs
+  __shared__ float sred[8];
+  const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int sub = tid % lpk, grp = tid / lpk;
+  const int n_keys = state->pos + 1;  // keys 0..pos (the current token was appended by rope_kv)
+  const int H = heads * hd;
+  const float scale = rsqrtf((float)hd);
+  float qf[VEC];
+  {
+    const T* q = qkv + (long)b * 3 * H + h * hd + sub * VEC;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) qf[j] = to_f32(q[j]);
+  }
+  const T* kb = kc + ((long)b * heads + h) * Lmax * hd;
+  const T* vb = vc + ((long)b * heads + h) * Lmax * hd;
+  // pass A: scores
+  for (int t0 = 0; t0 < n_keys; t0 += gpb) {
+    const int t = t0 + grp;
+    float d = 0.f;
+    if (t < n_keys) {
+      const Chunk16 raw = *(const Chunk16*)(kb + (long)t * hd + sub * VEC);
+      if constexpr (sizeof(T) == 2) {
+        const bf16x8 kk = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) d = fmaf(qf[j], (float)kk[j], d);
+      } else {
+        const f32x4 kk = __builtin_bit_cast(f32x4, raw);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) d = fmaf(qf[j], kk[j], d);
+      }
+    }
+    for (int o = 1; o < lpk; o <<= 1) d += __shfl_xor(d, o, 64);
+    if (t < n_keys && sub == 0) sc[t] = d * scale;
+  }
+  __syncthreads();
+  // pass B: softmax statistics
+  float mx = -INFINITY;
+  for (int t = tid; t < n_keys; t += 256) mx = fmaxf(mx, sc[t]);
+  mx = wave_max(mx);
+  if (lane == 0) sred[wv] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
+  float sum = 0.f;
+  for (int t = tid; t < n_keys; t += 256) { const float e = expf(sc[t] - mx); sc[t] = e; sum += e; }
+  sum = wave_sum(sum);
+  if (lane == 0) sred[4 + wv] = sum;
+  __syncthreads();
+  sum = (sred[4] + sred[5]) + (sred[6] + sred[7]);
+  // pass C: weighted V sum; group `grp` takes keys grp, grp+gpb, ...
+  float of[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) of[j] = 0.f;
+  for (int t = grp; t < n_keys; t += gpb) {
+    const float pw = sc[t];
+    const Chunk16 raw = *(const Chunk16*)(vb + (long)t * hd + sub * VEC);
+    if constexpr (sizeof(T) == 2) {
+      const bf16x8 vv = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) of[j] = fmaf(pw, (float)vv[j], of[j]);
+    } else {
+      const f32x4 vv = __builtin_bit_cast(f32x4, raw);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) of[j] = fmaf(pw, vv[j], of[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) red[grp * hd + sub * VEC + j] = of[j];
+  __syncthreads();
+  if (tid < hd) {
+    float a = 0.f;
+    for (int g = 0; g < gpb; ++g) a += red[g * hd + tid];
+    out[(long)b * H + h * hd + tid] = from_f32<T>(a / sum);
+  }
+}
+
+int launch_decode_attn(const void* qkv, const void* kc, const void* vc, void* out, int B, int heads, int hd, int Lmax,
+                       const StepState* state, DType dt, hipStream_t st) {
+  const int vec = dt == BF16 ? 8 : 4;
+  if (hd % vec != 0 || hd > 256 || 256 % (hd / vec) != 0) return (int)hipErrorInvalidValue;
+  const int gpb = 256 / (hd / vec);
+  const size_t smem = (size_t)(Lmax + gpb * hd) * sizeof(float);
+  dim3 g(B * heads);
+  if (dt == BF16)
+    hipLaunchKernelGGL(decode_attn_kernel<bf16_t>, g, dim3(256), smem, st, (const bf16_t*)qkv, (const bf16_t*)kc, (const bf16_t*)vc,
+                       (bf16_t*)out, heads, hd, Lmax, state);
+  else
+    hipLaunchKernelGGL(decode_attn_kernel<float>, g, dim3(256), smem, st, (const float*)qkv, (const float*)kc, (const float*)vc,
+                       (float*)out, heads, hd, Lmax, state);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ sampling
+// One workgroup per trajectory.  Restates HF TopKLogitsWarper(top_k) + softmax + one draw as an
+// explicit-uniform inverse CDF over the kept tokens in ascending id order (oracle/llama.py
+// sample_from_logits); uniforms == null -> greedy argmax (lowest id on ties).  Then embeds the decided
+// token as the next input row and (forced sdf slots) adds the action embedding.
+__device__ __forceinline__ unsigned f2key(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotone: larger float -> larger key
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sample_embed_kernel(SampleArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* lg = (float*)smem;  // [V]
+  __shared__ int hist[256];
+  __shared__ unsigned s_prefix;
+  __shared__ int s_k;
+  __shared__ float s_f[8];
+  __shared__ int s_i[8];
+  __shared__ double s_d[256];
+  __shared__ long s_tok;
+  __shared__ double s_target;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int j = a.state->j;
+  const int V = a.V;
+  const bool forced = a.forced_period > 0 && (j % a.forced_period) == 0;
+  long tok = 0;
+  if (forced) {
+    tok = a.forced_token;
+  } else {
+    const float* src = a.logits + (long)b * V;
+    float mx = -INFINITY;
+    int mi = 0x7fffffff;
+    for (int i = tid; i < V; i += 256) {
+      const float v = src[i];
+      lg[i] = v;
+      if (v > mx) { mx = v; mi = i; }  // ascending i per thread: first max kept
+    }
+    // (max, lowest index) reduction
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(mx, o, 64);
+      const int oi = __shfl_xor(mi, o, 64);
+      if (ov > mx || (ov == mx && oi < mi)) { mx = ov; mi = oi; }
+    }
+    if (lane == 0) { s_f[wv] = mx; s_i[wv] = mi; }
+    __syncthreads();
+    mx = s_f[0]; mi = s_i[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) if (s_f[w] > mx || (s_f[w] == mx && s_i[w] < mi)) { mx = s_f[w]; mi = s_i[w]; }
+    if (a.uniforms == nullptr) {
+      tok = mi;
+    } else {
+      // ---- k-th largest key by 4-pass radix select (8 bits per pass, from the top)
+      if (tid == 0) { s_prefix = 0u; s_k = a.top_k < V ? a.top_k : V; }
+      for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        hist[tid] = 0;
+        __syncthreads();
+        const unsigned prefix = s_prefix;
+        const unsigned mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (int i = tid; i < V; i += 256) {
+          const unsigned key = f2key(lg[i]);
+          if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+          int k = s_k, d = 255;
+          for (; d > 0; --d) { if (hist[d] >= k) break; k -= hist[d]; }
+          s_prefix = prefix | ((unsigned)d << shift);
+          s_k = k;
+        }
+        __syncthreads();
+      }
+      const unsigned thr = s_prefix;  // key of the k-th largest logit; everything >= thr is kept (ties included)
+      // ---- inverse CDF in ascending id order, fp64 accumulation (matches the oracle's double cumsum)
+      const int seg = (V + 255) / 256;
+      const int i0 = tid * seg, i1 = min(V, i0 + seg);
+      double part = 0.0;
+      for (int i = i0; i < i1; ++i)
+        if (f2key(lg[i]) >= thr) part += exp((double)(lg[i] - mx));
+      s_d[tid] = part;
+      __syncthreads();
+      if (tid == 0) {  // serial exclusive scan over 256 partials (fixed order)
+        double run = 0.0;
+        for (int t = 0; t < 256; ++t) { const double p = s_d[t]; s_d[t] = run; run += p; }
+        s_d[0] = 0.0;
+        // total kept mass and target
+        const double target = (double)a.uniforms[(long)b * a.n_uni + (j - 1)] * run;
+        s_tok = -1;
+        s_target = target;
+      }
+      __syncthreads();
+      const double target = s_target;
+      // my segment contains the crossing iff excl <= target < excl + part  (cdf > target first happens inside)
+      const double excl = s_d[tid];
+      if (part > 0.0 && excl <= target && target < excl + part) {
+        double run = excl;
+        long found = -1;
+        for (int i = i0; i < i1; ++i) {
+          if (f2key(lg[i]) >= thr) {
+            run += exp((double)(lg[i] - mx));
+            if (run > target) { found = i; break; }
+          }
+        }
+        if (found < 0) {  // rounding at the segment edge: take the segment's last kept token
+          for (int i = i1 - 1; i >= i0; --i) if (f2key(lg[i]) >= thr) { found = i; break; }
+        }
+        s_tok = found;
+      }
+      __syncthreads();
+      tok = s_tok;
+      if (tok < 0) tok = mi;  // unreachable for u in [0,1): defensive
+    }
+  }
+  if (tid == 0) a.ids_out[(long)b * a.ids_stride + a.L0 + (j - 1)] = (int64_t)tok;
+  // ---- next input embedding
+  constexpr int VEC = Traits<T>::VEC;
+  const T* src = (const T*)a.E + tok * a.H;
+  T* dst = (T*)a.x + (long)b * a.H;
+  const T* act = nullptr;
+  if (forced && a.act) act = (const T*)a.act + ((long)b * a.act_T + (j / a.forced_period + a.ctx - 1)) * a.H;
+  for (int c = tid; c < a.H; c += 256) {
+    float v = to_f32(src[c]);
+    if (act) v = to_f32(from_f32<T>(v + to_f32(act[c])));
+    dst[c] = from_f32<T>(v);
+  }
+  (void)VEC;
+}
+
+int launch_sample_embed(const SampleArgs& a, int B, DType dt, hipStream_t st) {
+  const size_t smem = (size_t)a.V * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)sample_embed_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    hipFuncSetAttribute((const void*)sample_embed_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    attr_set = true;
+  }
+  if (smem > 96 * 1024) return (int)hipErrorInvalidValue;
+  if (dt == BF16) hipLaunchKernelGGL(sample_embed_kernel<bf16_t>, dim3(B), dim3(256), smem, st, a);
+  else hipLaunchKernelGGL(sample_embed_kernel<float>, dim3(B), dim3(256), smem, st, a);
+  return (int)hipGetLastError();
+}
+
+__global__ void step_advance_kernel(StepState* s) { s->pos += 1; s->j += 1; }
+__global__ void state_set_kernel(StepState* s, int pos, int j) { s->pos = pos; s->j = j; }
+
+int launch_step_advance(StepState* state, hipStream_t st) {
+  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, st, state);
+  return (int)hipGetLastError();
+}
+int launch_state_set(StepState* state, int pos, int j, hipStream_t st) {
+  hipLaunchKernelGGL(state_set_kernel, dim3(1), dim3(1), 0, st, state, pos, j);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ small heads
+template <typename T>
+__global__ __launch_bounds__(256) void action_embed_kernel(const float* __restrict__ act, const float* __restrict__ W,
+                                                           const float* __restrict__ bias, T* __restrict__ out, int A, int H) {
+  const int row = blockIdx.x;
+  for (int c = threadIdx.x; c < H; c += 256) {
+    float s = 0.f;
+    for (int k = 0; k < A; ++k) s = fmaf(act[(long)row * A + k], W[(long)c * A + k], s);
+    out[(long)row * H + c] = from_f32<T>(s + bias[c]);
+  }
+}
+
+int launch_action_embed(const float* act, const float* W, const float* bias, void* out, DType dt, int BT, int A, int H,
+                        hipStream_t st) {
+  if (BT <= 0) return 0;
+  if (dt == BF16) hipLaunchKernelGGL(action_embed_kernel<bf16_t>, dim3(BT), dim3(256), 0, st, act, W, bias, (bf16_t*)out, A, H);
+  else hipLaunchKernelGGL(action_embed_kernel<float>, dim3(BT), dim3(256), 0, st, act, W, bias, (float*)out, A, H);
+  return (int)hipGetLastError();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_rows_kernel(T* __restrict__ x, long xs, const T* __restrict__ add, long as, int H) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < H; c += 256) x[b * xs + c] = from_f32<T>(to_f32(x[b * xs + c]) + to_f32(add[b * as + c]));
+}
+
+int launch_add_rows(void* x, long x_stride, const void* add, long add_stride, int B, int H, DType dt, hipStream_t st) {
+  if (B <= 0) return 0;
+  if (dt == BF16) hipLaunchKernelGGL(add_rows_kernel<bf16_t>, dim3(B), dim3(256), 0, st, (bf16_t*)x, x_stride, (const bf16_t*)add, add_stride, H);
+  else hipLaunchKernelGGL(add_rows_kernel<float>, dim3(B), dim3(256), 0, st, (float*)x, x_stride, (const float*)add, add_stride, H);
+  return (int)hipGetLastError();
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void rowdot_kernel(const T* __restrict__ h, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, float* __restrict__ out, int H) {
+  const int b = blockIdx.x;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < H; c += 64) s = fmaf(to_f32(h[(long)b * H + c]), w[c], s);
+  s = wave_sum(s);
+  if (threadIdx.x == 0) out[b] = s + bias[0];
+}
+
+int launch_rowdot(const void* h, const float* w, const float* bias, float* out, int B, int H, DType dt, hipStream_t st) {
+  if (B <= 0) return 0;
+  if (dt == BF16) hipLaunchKernelGGL(rowdot_kernel<bf16_t>, dim3(B), dim3(64), 0, st, (const bf16_t*)h, w, bias, out, H);
+  else hipLaunchKernelGGL(rowdot_kernel<float>, dim3(B), dim3(64), 0, st, (const float*)h, w, bias, out, H);
+  return (int)hipGetLastError();
+}
+
+}  // namespace ivg

@@ -1,0 +1,81 @@
+// Host-side launchers of every hand-written kernel (all return hipError_t as int, 0 = ok).
+#pragma once
+#include "common.h"
+#include "igemm.h"
+
+namespace ivg {
+
+// ---- norm.hip
+int gn_num_chunks(int P);
+// GroupNorm over [N][P][C] (stats per (n, group) over P*C/groups values), optional SiLU and position embedding
+// pos[P][C] (fp32).  part_ws: N * gn_num_chunks(P) * groups double2 of scratch.
+int launch_groupnorm(const void* X, void* Y, void* part_ws, const float* gamma, const float* beta, const float* pos,
+                     int N, int P, int C, int groups, float eps, int silu, DType dt, hipStream_t st);
+// x[M][H] += sum_s part[s][M][H] (in place, T);  out = rmsnorm(x) * w   (out may be null: residual update only)
+int launch_add_rmsnorm(void* x, long x_stride, const float* part, int splits, const float* w, void* out, int M, int H, float eps,
+                       DType dt, hipStream_t st);
+int launch_softmax(const float* S, void* Pm, long rows, int Lq, int Lk, int lds, int ldp, int causal, DType dt, hipStream_t st);
+
+// ---- conv_small.hip
+// First conv of the encoders: reads frames straight from the (B, T, 3, H, W) video (planar, fp32 or bf16),
+// writes NHWC.  Image n of the launch is frame (n / per) * T_total + t0 + (n % per) of the clip tensor.
+int launch_conv_in(const void* video, DType video_dt, const float* w /*[C0][3][3][3]*/, const float* bias, void* Y, DType dt,
+                   int N, int per, int T_total, int t0, int H, int W, int C0, hipStream_t st);
+
+// ---- vq.hip
+// token row r = (g, i): g = r / tpf is a global frame, i = r % tpf;  b = g / nf, f = g % nf
+//   -> element  b * stride + start + f * fstride + i  of the int64 token matrix (compressive_vq_model.py:205-215)
+struct TokMap {
+  int tpf, nf;
+  long stride;
+  int start, fstride;
+};
+int launch_sqnorm_rows(const float* E, float* out, int rows, int dim, hipStream_t st);
+// out[map(r)] = argmin_j dist(z_r, e_j) + offset;  z fp32 [R][64];  lowest index on ties
+int launch_vq_argmin(const float* z, const float* E, const float* ee, int64_t* out, const TokMap& map, int64_t offset, int R,
+                     int n_e, hipStream_t st);
+// Y[r][:] = E[clamp(ids[map(r)] - sub, 0, n_e - 1)][:]  (codebook fp32 -> T)
+int launch_gather_rows(const int64_t* ids, const TokMap& map, const float* E, void* Y, DType dt, int R, int dim, int64_t sub,
+                       int n_e, hipStream_t st);
+// un-patchify: q[M*np*np][p*p*C] with feature order (ph, pw, c) -> NHWC [M][np*p][np*p][C]   (compressive_vq_model.py:247-250)
+int launch_unpatchify(const void* q, void* out, DType dt, int M, int np, int C, int p, hipStream_t st);
+// special tokens (scf / sdf slots) and labels (-100 over the context part)                    (compressive_vq_model.py:205-218)
+int launch_finish_tokens(int64_t* ids, long stride, int64_t* labels, int B, int L, int ctx, int64_t scf, int64_t sdf, hipStream_t st);
+int launch_cast(const void* src, DType sdt, void* dst, DType ddt, long n, hipStream_t st);
+
+// ---- llama_ops.hip
+struct StepState {  // device-resident per-generate state (so one captured step graph can be replayed)
+  int pos;          // number of tokens already in the KV cache (= position of the token being fed)
+  int j;            // 1-based index of the NEW token being decided at this step
+};
+// x[b][:] = E[tok[b]] (+ act[b][slot][:] when add_act), T
+int launch_embed(const int64_t* ids, long id_stride, const void* E, void* x, DType dt, int B, int L, int H, hipStream_t st);
+// RoPE on q,k of qkv[M][3H] (in place) and append k,v to the cache [B][heads][Lmax][hd]; position of row (b, l) = pos0 + l
+// (pos0 from *state when state != null).  vt (optional): transposed V scratch [B][heads][hd][ldvt] for the prefill P.V GEMM.
+int launch_rope_kv(void* qkv, void* kc, void* vc, void* vt, int ldvt, const float* cosT, const float* sinT, int B, int L,
+                   int heads, int hd, int Lmax, const StepState* state, int pos0, DType dt, hipStream_t st);
+// single-token attention against the cache: out[b][h*hd..] = softmax(q.K^T / sqrt(hd)) V over positions [0, *pos]
+int launch_decode_attn(const void* qkv, const void* kc, const void* vc, void* out, int B, int heads, int hd, int Lmax,
+                       const StepState* state, DType dt, hipStream_t st);
+// token decision + embedding of the decided token (+ action embedding on forced sdf slots) + state advance
+struct SampleArgs {
+  const float* logits; int V;            // [B][V] fp32 (row stride V)
+  const float* uniforms; int n_uni;      // [B][n_uni] or null (greedy)
+  int top_k;
+  int64_t* ids_out; long ids_stride; int L0;   // ids_out[b*ids_stride + L0 + j - 1] = token j
+  int forced_period; int64_t forced_token;     // j % period == 0 -> forced token (0 = never)
+  const void* E; void* x; int H;               // next input embedding x[b][:] (T)
+  const void* act; int act_T; int ctx;         // act[B][act_T][H] (T) or null: added on forced slots with index j/period + ctx - 1
+  StepState* state;
+};
+int launch_sample_embed(const SampleArgs& a, int B, DType dt, hipStream_t st);
+int launch_step_advance(StepState* state, hipStream_t st);
+int launch_state_set(StepState* state, int pos, int j, hipStream_t st);
+// y[b][t][:] = W[H][A] a[b][t][:] + bias  (tiny; fp32 in, T out)
+int launch_action_embed(const float* act, const float* W, const float* bias, void* out, DType dt, int BT, int A, int H,
+                        hipStream_t st);
+int launch_add_rows(void* x, long x_stride, const void* add, long add_stride, int B, int H, DType dt, hipStream_t st);
+// r[b] = dot(h[b], w) + bias   (reward head)
+int launch_rowdot(const void* h, const float* w, const float* bias, float* out, int B, int H, DType dt, hipStream_t st);
+
+}  // namespace ivg

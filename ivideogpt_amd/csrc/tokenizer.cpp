@@ -1,0 +1,499 @@
+// Layer graphs of the compressive tokenizer on the hand-written kernels.
+//
+// Follows (structure only; all arithmetic is in the .hip kernels):
+//   Encoder.forward            ivideogpt/vq_model/vae.py:141-195
+//   ConditionalEncoder.forward ivideogpt/vq_model/conditional_vae.py:108-132
+//   Decoder.forward            ivideogpt/vq_model/vae.py:298-371
+//   ConditionalDecoder.forward ivideogpt/vq_model/conditional_vae.py:186-212
+//   CrossAttentionBlock        ivideogpt/vq_model/conditional_vae.py:38-55
+//   tokenize / detokenize      ivideogpt/vq_model/compressive_vq_model.py:164-277
+// MI355X-first differences from the reference's op sequence (results identical):
+//   * activations live in NHWC, so a feature map already IS the [tokens, C] matrix attention needs;
+//   * context features are never repeated F times (compressive_vq_model.py:176-187, 257-266): the
+//     cross-attention K / V projections are computed once per trajectory and shared by its F frames
+//     through batch strides of 0;
+//   * nearest-x2 upsampling, the stride-2 right/bottom zero pad and 4x4 patchify are index arithmetic
+//     inside the implicit-GEMM gather, never materialised.
+#include "engine_impl.h"
+
+namespace ivg {
+
+#define CK(x) do { int _e = (x); if (_e != 0) return R.e->fail(IVG_ERR_HIP, std::string(#x) + " failed: hip error " + std::to_string(_e)); } while (0)
+
+static size_t esz(DType d) { return d == BF16 ? 2 : 4; }
+
+// -------------------------------------------------------------------------------------------- primitive wrappers
+int Run::conv(DType dt, const void* X, int N, int H, int W, const ConvW& c, void* Y, int stride, int ups, const void* Rres, int flags,
+              int out_f32) {
+  Run& R = *this;
+  const int k = c.k;
+  int Ho, Wo, pad;
+  if (ups) { Ho = 2 * H; Wo = 2 * W; pad = 1; }
+  else if (stride == 2) { Ho = H / 2; Wo = W / 2; pad = 0; }       // F.pad(0,1,0,1) + stride-2 conv, padding 0
+  else if (stride == k && k > 1) { Ho = H / k; Wo = W / k; pad = 0; }  // patchify conv (quant_linear)
+  else { Ho = H; Wo = W; pad = (k - 1) / 2; }
+  IgemmArgs a;
+  a.X = X; a.W = c.w; a.Y = Y; a.R = Rres; a.bias = c.b;
+  a.Nimg = N; a.Hin = H; a.Win = W; a.Cin = c.cin; a.ldx = c.cin; a.Hout = Ho; a.Wout = Wo;
+  a.KH = k; a.KW = k; a.stride = stride; a.pad = pad; a.ups = ups;
+  a.N = c.cout; a.ldw = k * k * c.cin;
+  a.c_img = (long)Ho * Wo * c.cout; a.c_pix = c.cout; a.c_ch = 1;
+  a.flags = flags | (c.b ? IG_BIAS_N : 0) | (Rres ? IG_RESIDUAL : 0) | (out_f32 ? IG_OUT_F32 : 0);
+  if (planning) return 0;
+  prof_begin(dt, 2.0 * N * Ho * Wo * (double)c.cout * k * k * c.cin,
+             (double)esz(dt) * ((double)N * H * W * c.cin + (double)c.cout * k * k * c.cin) + (double)(out_f32 ? 4 : esz(dt)) * N * Ho * Wo * c.cout);
+  CK(launch_igemm(a, dt, st));
+  prof_end(dt);
+  return 0;
+}
+
+int Run::gemm(DType dt, const IgemmArgs& a, double flops, double bytes) {
+  Run& R = *this;
+  if (planning) return 0;
+  prof_begin(dt, flops, bytes);
+  CK(launch_igemm(a, dt, st));
+  prof_end(dt);
+  return 0;
+}
+
+int Run::linear(DType dt, const void* X, long rows, const ConvW& c, void* Y, const void* Rres, int flags, int out_f32) {
+  // rows x cin  ->  rows x cout, all dense row-major
+  IgemmArgs a;
+  a.X = X; a.W = c.w; a.Y = Y; a.R = Rres; a.bias = c.b;
+  a.Nimg = 1; a.Hin = 1; a.Win = (int)rows; a.Cin = c.cin; a.ldx = c.cin; a.Hout = 1; a.Wout = (int)rows;
+  a.N = c.cout; a.ldw = c.cin;
+  a.c_img = 0; a.c_pix = c.cout; a.c_ch = 1;
+  a.flags = flags | (c.b ? IG_BIAS_N : 0) | (Rres ? IG_RESIDUAL : 0) | (out_f32 ? IG_OUT_F32 : 0);
+  return gemm(dt, a, 2.0 * rows * c.cin * (double)c.cout,
+              (double)esz(dt) * ((double)rows * c.cin + (double)c.cout * c.cin) + (double)(out_f32 ? 4 : esz(dt)) * rows * c.cout);
+}
+
+int Run::gnorm(DType dt, const void* X, void* Y, int N, int P, int C, const NormW& n, float eps, int silu, const float* pos) {
+  Run& R = *this;
+  const int groups = e->cfg.norm_num_groups;
+  const size_t m = e->ws.mark();
+  void* part = e->ws.alloc((size_t)N * gn_num_chunks(P) * groups * sizeof(double) * 2);
+  int rc = 0;
+  if (!planning) rc = launch_groupnorm(X, Y, part, n.g, n.b, pos, N, P, C, groups, eps, silu, dt, st);
+  e->ws.reset(m);  // stream-ordered: the next user of this scratch runs after these kernels
+  CK(rc);
+  return 0;
+}
+
+// x [N,H,W,cin] -> out [N,H,W,cout]
+int Run::resnet(DType dt, const void* x, int N, int H, int W, const ResnetW& r, void* out) {
+  Run& R = *this;
+  const size_t m = e->ws.mark();
+  const size_t px = (size_t)N * H * W;
+  void* t = e->ws.alloc(px * std::max(r.cin, r.cout) * esz(dt));
+  void* h = e->ws.alloc(px * r.cout * esz(dt));
+  IVG_TRY(gnorm(dt, x, t, N, H * W, r.cin, r.n1, 1e-6f, 1, nullptr));
+  IVG_TRY(conv(dt, t, N, H, W, r.c1, h, 1, 0, nullptr, 0, 0));
+  IVG_TRY(gnorm(dt, h, t, N, H * W, r.cout, r.n2, 1e-6f, 1, nullptr));
+  const void* res = x;
+  if (r.has_sc) {
+    IVG_TRY(conv(dt, x, N, H, W, r.sc, out, 1, 0, nullptr, 0, 0));
+    res = out;  // in-place residual: every element is read then written by the same thread
+  }
+  IVG_TRY(conv(dt, t, N, H, W, r.c2, out, 1, 0, res, 0, 0));
+  e->ws.reset(m);
+  return 0;
+}
+
+// diffusers Attention with one head of dim C: x [N, P tokens, C] -> out
+int Run::self_attention(DType dt, const void* x, int N, int P, int C, const AttnW& a, void* out) {
+  Run& R = *this;
+  const size_t m = e->ws.mark();
+  const size_t tok = (size_t)N * P;
+  void* t = e->ws.alloc(tok * C * esz(dt));
+  void* q = e->ws.alloc(tok * C * esz(dt));
+  void* k = e->ws.alloc(tok * C * esz(dt));
+  void* vT = e->ws.alloc(tok * C * esz(dt));
+  void* o = e->ws.alloc(tok * C * esz(dt));
+  float* S = (float*)e->ws.alloc((size_t)N * P * P * sizeof(float));
+  void* Pm = e->ws.alloc((size_t)N * P * P * esz(dt));
+  IVG_TRY(gnorm(dt, x, t, N, P, C, a.gn, 1e-6f, 0, nullptr));
+  IVG_TRY(linear(dt, t, tok, a.q, q, nullptr, 0, 0));
+  IVG_TRY(linear(dt, t, tok, a.k, k, nullptr, 0, 0));
+  {  // V^T[n][c][tok] = Wv[c][:] . t[n][tok][:] + bv[c]
+    IgemmArgs g;
+    g.X = a.v.w; g.W = t; g.Y = vT; g.bias = a.v.b;
+    g.Nimg = 1; g.Hin = 1; g.Win = C; g.Cin = C; g.ldx = C; g.Hout = 1; g.Wout = C;
+    g.N = P; g.ldw = C; g.c_pix = P; g.c_ch = 1;
+    g.flags = IG_BIAS_M;
+    g.nb0 = N; g.sa[0] = 0; g.sw[0] = (long)P * C; g.sy[0] = (long)C * P;
+    IVG_TRY(gemm(dt, g, 2.0 * tok * C * (double)C, (double)esz(dt) * (2.0 * tok * C + (double)C * C)));
+  }
+  {  // S = Q K^T / sqrt(C)
+    IgemmArgs g;
+    g.X = q; g.W = k; g.Y = S;
+    g.Nimg = 1; g.Hin = 1; g.Win = P; g.Cin = C; g.ldx = C; g.Hout = 1; g.Wout = P;
+    g.N = P; g.ldw = C; g.c_pix = P; g.c_ch = 1; g.flags = IG_OUT_F32; g.alpha = 1.0f / sqrtf((float)C);
+    g.nb0 = N; g.sa[0] = (long)P * C; g.sw[0] = (long)P * C; g.sy[0] = (long)P * P;
+    IVG_TRY(gemm(dt, g, 2.0 * N * (double)P * P * C, (double)esz(dt) * 2.0 * tok * C + 4.0 * N * P * P));
+  }
+  if (!planning) CK(launch_softmax(S, Pm, (long)N * P, P, P, P, P, 0, dt, st));
+  {  // O = P V
+    IgemmArgs g;
+    g.X = Pm; g.W = vT; g.Y = o;
+    g.Nimg = 1; g.Hin = 1; g.Win = P; g.Cin = P; g.ldx = P; g.Hout = 1; g.Wout = P;
+    g.N = C; g.ldw = P; g.c_pix = C; g.c_ch = 1;
+    g.nb0 = N; g.sa[0] = (long)P * P; g.sw[0] = (long)C * P; g.sy[0] = (long)P * C;
+    IVG_TRY(gemm(dt, g, 2.0 * N * (double)P * P * C, (double)esz(dt) * ((double)N * P * P + 2.0 * tok * C)));
+  }
+  IVG_TRY(linear(dt, o, tok, a.o, out, x, 0, 0));
+  e->ws.reset(m);
+  return 0;
+}
+
+// Per-trajectory K / V^T projections of the context feature (once per trajectory, shared by its F frames).
+// feat [B][ctx*side*side][C] (NHWC frames of one trajectory are contiguous) -> Kp [B][kv][C], VpT [B][C][kv]
+int Run::xatt_project_kv(DType dt, const void* feat, int B, const XAttW& x, void* Kp, void* VpT) {
+  Run& R = *this;
+  const int C = x.C, kv = e->ctx * x.side * x.side;
+  const size_t m = e->ws.mark();
+  void* kvn = e->ws.alloc((size_t)B * kv * C * esz(dt));
+  const float* pos = x.kv_pos + (size_t)(x.kv_rows - kv) * C;  // set_context_length keeps the LAST k frames' rows
+  IVG_TRY(gnorm(dt, feat, kvn, B, kv, C, x.kvn, 1e-5f, 0, pos));
+  IVG_TRY(linear(dt, kvn, (long)B * kv, x.k, Kp, nullptr, 0, 0));
+  IgemmArgs g;
+  g.X = x.v.w; g.W = kvn; g.Y = VpT; g.bias = x.v.b;
+  g.Nimg = 1; g.Hin = 1; g.Win = C; g.Cin = C; g.ldx = C; g.Hout = 1; g.Wout = C;
+  g.N = kv; g.ldw = C; g.c_pix = kv; g.c_ch = 1; g.flags = IG_BIAS_M;
+  g.nb0 = B; g.sa[0] = 0; g.sw[0] = (long)kv * C; g.sy[0] = (long)C * kv;
+  IVG_TRY(gemm(dt, g, 2.0 * B * (double)kv * C * C, (double)esz(dt) * (2.0 * B * kv * C + (double)C * C)));
+  e->ws.reset(m);
+  return 0;
+}
+
+// z [B*F][P][C] (P = side^2 query tokens per frame) attends to its trajectory's context: out = silu(z + MHA(...))
+int Run::cross_attention(DType dt, const void* z, int B, int F, const XAttW& x, const void* Kp, const void* VpT, void* out) {
+  Run& R = *this;
+  const int C = x.C, P = x.side * x.side, kv = e->ctx * P, nh = 4, hd = C / nh;
+  const long M = (long)B * F;
+  const size_t m = e->ws.mark();
+  void* qn = e->ws.alloc((size_t)M * P * C * esz(dt));
+  void* q = e->ws.alloc((size_t)M * P * C * esz(dt));
+  void* o = e->ws.alloc((size_t)M * P * C * esz(dt));
+  float* S = (float*)e->ws.alloc((size_t)M * nh * P * kv * sizeof(float));
+  void* Pm = e->ws.alloc((size_t)M * nh * P * kv * esz(dt));
+  IVG_TRY(gnorm(dt, z, qn, (int)M, P, C, x.qn, 1e-5f, 0, x.q_pos));
+  IVG_TRY(linear(dt, qn, M * P, x.q, q, nullptr, 0, 0));
+  {  // S[b][f][h] = Q_h K_h^T / sqrt(hd)
+    IgemmArgs g;
+    g.X = q; g.W = Kp; g.Y = S;
+    g.Nimg = 1; g.Hin = 1; g.Win = P; g.Cin = hd; g.ldx = C; g.Hout = 1; g.Wout = P;
+    g.N = kv; g.ldw = C; g.c_pix = kv; g.c_ch = 1; g.flags = IG_OUT_F32; g.alpha = 1.0f / sqrtf((float)hd);
+    g.nb0 = B; g.nb1 = F; g.nb2 = nh;
+    g.sa[0] = (long)F * P * C; g.sa[1] = (long)P * C; g.sa[2] = hd;
+    g.sw[0] = (long)kv * C; g.sw[1] = 0; g.sw[2] = hd;
+    g.sy[0] = (long)F * nh * P * kv; g.sy[1] = (long)nh * P * kv; g.sy[2] = (long)P * kv;
+    IVG_TRY(gemm(dt, g, 2.0 * M * nh * (double)P * kv * hd, (double)esz(dt) * (M * P * C + (double)B * kv * C) + 4.0 * M * nh * P * kv));
+  }
+  if (!planning) CK(launch_softmax(S, Pm, M * nh * P, P, kv, kv, kv, 0, dt, st));
+  {  // O[b][f][:, h*hd..] = P V_h
+    IgemmArgs g;
+    g.X = Pm; g.W = VpT; g.Y = o;
+    g.Nimg = 1; g.Hin = 1; g.Win = P; g.Cin = kv; g.ldx = kv; g.Hout = 1; g.Wout = P;
+    g.N = hd; g.ldw = kv; g.c_pix = C; g.c_ch = 1;
+    g.nb0 = B; g.nb1 = F; g.nb2 = nh;
+    g.sa[0] = (long)F * nh * P * kv; g.sa[1] = (long)nh * P * kv; g.sa[2] = (long)P * kv;
+    g.sw[0] = (long)C * kv; g.sw[1] = 0; g.sw[2] = (long)hd * kv;
+    g.sy[0] = (long)F * P * C; g.sy[1] = (long)P * C; g.sy[2] = hd;
+    IVG_TRY(gemm(dt, g, 2.0 * M * nh * (double)P * kv * hd, (double)esz(dt) * ((double)M * nh * P * kv + (double)B * kv * C + M * P * C)));
+  }
+  IVG_TRY(linear(dt, o, M * P, x.o, out, z, IG_SILU, 0));
+  e->ws.reset(m);
+  return 0;
+}
+
+// -------------------------------------------------------------------------------------------- encoders
+// Plain or conditional encoder trunk.  frames: images [N] = clip frames (t0 .. t0+per) of B trajectories.
+// cond != null: conditional encoder, cross-attending to cond features (index = level + 1).
+// keep != null: plain encoder; keep[i] (i = feature index) receives persistent copies of the features that
+// a conditional pass will need.  latent: [N,16,16,latent] in dt.
+int Run::encoder_trunk(const TrunkW& w, const void* pixels, DType pix_dt, int B, int per, int T_total, int t0,
+                       std::vector<Feature>* keep, const std::vector<Feature>* cond, void* latent) {
+  Run& R = *this;
+  const DType dt = e->enc_dt;
+  const ivg_config& c = e->cfg;
+  const int N = B * per, nl = c.n_levels;
+  int side = c.resolution;
+  size_t max_el = 0;
+  {
+    int s = side;
+    for (int i = 0; i < nl; ++i) {
+      max_el = std::max(max_el, (size_t)s * s * c.block_out_channels[i]);
+      if (i > 0) max_el = std::max(max_el, (size_t)s * s * c.block_out_channels[i - 1]);
+      if (i != nl - 1) s /= 2;
+    }
+  }
+  const size_t m = e->ws.mark();
+  // cross-attention K/V of every site first (persist for the whole trunk)
+  std::vector<void*> Kp, Vp;
+  if (cond) {
+    int s = side, k = 0;
+    for (int i = 0; i < nl; ++i) {
+      if (i != nl - 1) s /= 2;
+      if (s <= c.max_att_resolution) {
+        const XAttW& x = w.xatt[k++];
+        const int kv = e->ctx * x.side * x.side;
+        void* kp = e->ws.alloc((size_t)B * kv * x.C * esz(dt));
+        void* vp = e->ws.alloc((size_t)B * kv * x.C * esz(dt));
+        IVG_TRY(xatt_project_kv(dt, (*cond)[i + 1].p, B, x, kp, vp));
+        Kp.push_back(kp); Vp.push_back(vp);
+      }
+    }
+  }
+  void* a = e->ws.alloc((size_t)N * max_el * esz(dt));
+  void* b = e->ws.alloc((size_t)N * max_el * esz(dt));
+  if (!planning)
+    CK(launch_conv_in(pixels, pix_dt, w.conv_in_raw_w, w.conv_in.b, a, dt, N, per, T_total, t0, side, side, c.block_out_channels[0], st));
+  int k = 0;
+  for (int i = 0; i < nl; ++i) {
+    for (size_t j = 0; j < w.blocks[i].size(); ++j) {
+      IVG_TRY(resnet(dt, a, N, side, side, w.blocks[i][j], b));
+      std::swap(a, b);
+    }
+    if (i != nl - 1) {
+      IVG_TRY(conv(dt, a, N, side, side, w.resample[i], b, 2, 0, nullptr, 0, 0));
+      std::swap(a, b);
+      side /= 2;
+    }
+    const int C = c.block_out_channels[i];
+    if (cond && side <= c.max_att_resolution) {
+      IVG_TRY(cross_attention(dt, a, B, per, w.xatt[k], Kp[k], Vp[k], b));
+      std::swap(a, b);
+      ++k;
+    }
+    if (keep && (*keep)[i + 1].p && !planning)
+      CK((int)hipMemcpyAsync((*keep)[i + 1].p, a, (size_t)N * side * side * C * esz(dt), hipMemcpyDeviceToDevice, st));
+  }
+  const int C = c.block_out_channels[nl - 1];
+  IVG_TRY(resnet(dt, a, N, side, side, w.mid0, b)); std::swap(a, b);
+  if (w.has_attn) { IVG_TRY(self_attention(dt, a, N, side * side, C, w.attn, b)); std::swap(a, b); }
+  IVG_TRY(resnet(dt, a, N, side, side, w.mid1, b)); std::swap(a, b);
+  IVG_TRY(gnorm(dt, a, b, N, side * side, C, w.norm_out, 1e-6f, 1, nullptr));
+  IVG_TRY(conv(dt, b, N, side, side, w.conv_out, latent, 1, 0, nullptr, 0, 0));
+  e->ws.reset(m);
+  return 0;
+}
+
+// which encoder features the conditional encoder needs (index = level + 1), with their geometry
+static void encoder_feature_plan(const ivg_config& c, std::vector<Feature>& f) {
+  f.assign(c.n_levels + 2, Feature());
+  int s = c.resolution;
+  for (int i = 0; i < c.n_levels; ++i) {
+    if (i != c.n_levels - 1) s /= 2;
+    if (s <= c.max_att_resolution) { f[i + 1].side = s; f[i + 1].C = c.block_out_channels[i]; }
+  }
+}
+
+int Run::tokenize(const void* pixels, DType pix_dt, int B, int T, int64_t* ids, int64_t ids_stride, int64_t* labels, bool ctx_only) {
+  Run& R = *this;
+  const ivg_config& c = e->cfg;
+  const DType dt = e->enc_dt;
+  const int ctx = e->ctx, F = T - ctx, lat = c.latent_channels, dim = c.vq_embed_dim;
+  const int64_t nvq = c.num_vq_embeddings, ndyn = c.num_dyn_embeddings;
+  const size_t m = e->ws.mark();
+  std::vector<Feature> feats;
+  encoder_feature_plan(c, feats);
+  if (!ctx_only)
+    for (auto& f : feats)
+      if (f.side) f.p = e->ws.alloc((size_t)B * ctx * f.side * f.side * f.C * esz(dt));
+  const int N = B * ctx;
+  void* h = e->ws.alloc((size_t)N * 256 * lat * esz(dt));
+  IVG_TRY(encoder_trunk(e->enc, pixels, pix_dt, B, ctx, T, 0, ctx_only ? nullptr : &feats, nullptr, h));
+  float* hq = (float*)e->ws.alloc((size_t)N * 256 * dim * sizeof(float));
+  IVG_TRY(conv(dt, h, N, 16, 16, e->quant_conv, hq, 1, 0, nullptr, 0, 1));
+  if (!planning) {
+    TokMap mp{256, ctx, ids_stride, 0, 257};
+    CK(launch_vq_argmin(hq, e->cb_c, e->ee_c, ids, mp, 0, N * 256, (int)nvq, st));
+  }
+  int L = 257 * ctx;
+  if (!ctx_only) {
+    const int M = B * F;
+    void* d = e->ws.alloc((size_t)M * 256 * lat * esz(dt));
+    IVG_TRY(encoder_trunk(e->cenc, pixels, pix_dt, B, F, T, ctx, nullptr, &feats, d));
+    float* dq = (float*)e->ws.alloc((size_t)M * 16 * dim * sizeof(float));
+    IVG_TRY(conv(dt, d, M, 16, 16, e->quant_linear, dq, c.patch_size, 0, nullptr, 0, 1));  // 4x4 / stride-4 conv == patchify + Linear
+    if (!planning) {
+      TokMap mp{16, F, ids_stride, 257 * ctx, 17};
+      CK(launch_vq_argmin(dq, e->cb_d, e->ee_d, ids, mp, nvq, M * 16, (int)ndyn, st));
+    }
+    L = 257 * ctx - 1 + 17 * F;
+  }
+  if (!planning) {
+    if (ids_stride != L && labels) return e->fail(IVG_ERR_INVALID, "labels need a dense token matrix");
+    CK(launch_finish_tokens(ids, ids_stride, labels, B, L, ctx, nvq + ndyn, nvq + ndyn + 1, st));
+  }
+  e->ws.reset(m);
+  return 0;
+}
+
+// -------------------------------------------------------------------------------------------- decoders
+static void decoder_feature_plan(const ivg_config& c, std::vector<Feature>& f) {
+  // features: [conv_in out, mid out, each up level out]; the conditional decoder uses [1] and [i+2] where side <= max_att
+  f.assign(c.n_levels + 2, Feature());
+  const int nl = c.n_levels;
+  int s = 16;
+  f[1].side = 16; f[1].C = c.block_out_channels[nl - 1];
+  for (int i = 0; i < nl; ++i) {
+    if (i != nl - 1) s *= 2;
+    if (s <= c.max_att_resolution) { f[i + 2].side = s; f[i + 2].C = c.block_out_channels[nl - 1 - i]; }
+  }
+}
+
+// z [N,16,16,latent] -> pixels written (fp32, planar) into out_pixels frames (b, t0 + n % per)
+int Run::decoder_trunk(const TrunkW& w, const void* z, int B, int per, int T_total, int t0, std::vector<Feature>* keep,
+                       const std::vector<Feature>* cond, float* out_pixels) {
+  Run& R = *this;
+  const DType dt = e->dec_dt;
+  const ivg_config& c = e->cfg;
+  const int N = B * per, nl = c.n_levels;
+  const int res = c.resolution;
+  size_t max_el = 0;
+  {
+    int s = 16;
+    for (int i = 0; i < nl; ++i) {
+      const int C = c.block_out_channels[nl - 1 - i];
+      const int Cp = c.block_out_channels[nl - 1 - (i > 0 ? i - 1 : 0)];
+      max_el = std::max(max_el, (size_t)s * s * std::max(C, Cp));
+      if (i != nl - 1) { s *= 2; max_el = std::max(max_el, (size_t)s * s * C); }
+    }
+  }
+  const size_t m = e->ws.mark();
+  std::vector<void*> Kp, Vp;
+  if (cond) {
+    for (size_t k = 0; k < w.xatt.size(); ++k) {
+      const XAttW& x = w.xatt[k];
+      const int kv = e->ctx * x.side * x.side;
+      void* kp = e->ws.alloc((size_t)B * kv * x.C * esz(dt));
+      void* vp = e->ws.alloc((size_t)B * kv * x.C * esz(dt));
+      // site 0 uses cond[1]; site k>0 belongs to the k-th up level whose output side <= max_att: cond[i+2]
+      int fi = 1;
+      if (k > 0) {
+        int s = 16, seen = 0;
+        for (int i = 0; i < nl; ++i) {
+          if (i != nl - 1) s *= 2;
+          if (s <= c.max_att_resolution) { ++seen; if (seen == (int)k) { fi = i + 2; break; } }
+        }
+      }
+      IVG_TRY(xatt_project_kv(dt, (*cond)[fi].p, B, x, kp, vp));
+      Kp.push_back(kp); Vp.push_back(vp);
+    }
+  }
+  void* a = e->ws.alloc((size_t)N * max_el * esz(dt));
+  void* b = e->ws.alloc((size_t)N * max_el * esz(dt));
+  int side = 16;
+  const int Ctop = c.block_out_channels[nl - 1];
+  IVG_TRY(conv(dt, z, N, side, side, w.conv_in, a, 1, 0, nullptr, 0, 0));
+  IVG_TRY(resnet(dt, a, N, side, side, w.mid0, b)); std::swap(a, b);
+  if (w.has_attn) { IVG_TRY(self_attention(dt, a, N, side * side, Ctop, w.attn, b)); std::swap(a, b); }
+  IVG_TRY(resnet(dt, a, N, side, side, w.mid1, b)); std::swap(a, b);
+  if (keep && (*keep)[1].p && !planning)
+    CK((int)hipMemcpyAsync((*keep)[1].p, a, (size_t)N * side * side * Ctop * esz(dt), hipMemcpyDeviceToDevice, st));
+  int k = 0;
+  if (cond) { IVG_TRY(cross_attention(dt, a, B, per, w.xatt[0], Kp[0], Vp[0], b)); std::swap(a, b); k = 1; }
+  for (int i = 0; i < nl; ++i) {
+    const int C = c.block_out_channels[nl - 1 - i];
+    for (size_t j = 0; j < w.blocks[i].size(); ++j) {
+      IVG_TRY(resnet(dt, a, N, side, side, w.blocks[i][j], b));
+      std::swap(a, b);
+    }
+    if (i != nl - 1) {
+      IVG_TRY(conv(dt, a, N, side, side, w.resample[i], b, 1, 1, nullptr, 0, 0));  // nearest x2 folded into the gather
+      std::swap(a, b);
+      side *= 2;
+    }
+    if (cond && side <= c.max_att_resolution) {
+      IVG_TRY(cross_attention(dt, a, B, per, w.xatt[k], Kp[k], Vp[k], b));
+      std::swap(a, b);
+      ++k;
+    }
+    if (keep && (*keep)[i + 2].p && !planning)
+      CK((int)hipMemcpyAsync((*keep)[i + 2].p, a, (size_t)N * side * side * C * esz(dt), hipMemcpyDeviceToDevice, st));
+  }
+  const int C0 = c.block_out_channels[0];
+  IVG_TRY(gnorm(dt, a, b, N, side * side, C0, w.norm_out, 1e-6f, 1, nullptr));
+  {  // conv_out straight into the planar (B, T, 3, H, W) float32 clip
+    IgemmArgs g;
+    g.X = b; g.W = w.conv_out.w; g.Y = out_pixels + (long)t0 * 3 * res * res; g.bias = w.conv_out.b;
+    g.Nimg = N; g.Hin = side; g.Win = side; g.Cin = C0; g.ldx = C0; g.Hout = side; g.Wout = side;
+    g.KH = 3; g.KW = 3; g.stride = 1; g.pad = 1;
+    g.N = 3; g.ldw = 9 * C0;
+    g.c_img = 3L * res * res; g.c_pix = 1; g.c_ch = (long)res * res;
+    g.c_grp = per; g.c_grp_stride = (long)T_total * 3 * res * res;
+    g.flags = IG_BIAS_N | IG_OUT_F32;
+    IVG_TRY(gemm(dt, g, 2.0 * N * side * side * 27.0 * C0, (double)esz(dt) * N * side * side * C0 + 4.0 * N * 3 * side * side));
+  }
+  e->ws.reset(m);
+  return 0;
+}
+
+int Run::detokenize(const int64_t* ids, int B, int F, float* out_pixels, ivg_cache* cache, int cache_mode) {
+  Run& R = *this;
+  const ivg_config& c = e->cfg;
+  const DType dt = e->dec_dt;
+  const int ctx = e->ctx, T = ctx + F, lat = c.latent_channels, dim = c.vq_embed_dim, p = c.patch_size;
+  const long L = 257L * ctx - 1 + 17L * F;
+  const int res = c.resolution;
+  const size_t m = e->ws.mark();
+  std::vector<Feature> feats;
+  decoder_feature_plan(c, feats);
+  const bool use_cache = cache && cache_mode == 2;
+  if (use_cache && (!cache->filled || cache->B != B)) return e->fail(IVG_ERR_INVALID, "detokenize: cache is empty or was made for another batch size");
+  {
+    size_t fi = 0;
+    for (auto& f : feats) {
+      if (!f.side) continue;
+      const size_t bytes = (size_t)B * ctx * f.side * f.side * f.C * esz(dt);
+      if (cache && cache_mode) {
+        if (!planning) {
+          if (fi >= cache->feat.size()) return e->fail(IVG_ERR_INVALID, "detokenize: cache layout mismatch");
+          f.p = cache->feat[fi];
+        }
+        ++fi;
+      } else {
+        f.p = e->ws.alloc(bytes);
+      }
+    }
+  }
+  if (!use_cache) {
+    const int N = B * ctx;
+    void* qc = e->ws.alloc((size_t)N * 256 * dim * esz(dt));
+    void* q2 = e->ws.alloc((size_t)N * 256 * lat * esz(dt));
+    if (!planning) {
+      TokMap mp{256, ctx, L, 0, 257};
+      CK(launch_gather_rows(ids, mp, e->cb_c, qc, dt, N * 256, dim, 0, c.num_vq_embeddings, st));
+    }
+    IVG_TRY(conv(dt, qc, N, 16, 16, e->post_quant_conv, q2, 1, 0, nullptr, 0, 0));
+    IVG_TRY(decoder_trunk(e->dec, q2, B, ctx, T, 0, &feats, nullptr, out_pixels));
+    if (cache && cache_mode == 1 && !planning) {
+      // keep the decoded context frames: rows (b, t < ctx) of out_pixels
+      CK((int)hipMemcpy2DAsync(cache->ctx_pixels, (size_t)ctx * 3 * res * res * 4, out_pixels, (size_t)T * 3 * res * res * 4,
+                               (size_t)ctx * 3 * res * res * 4, B, hipMemcpyDeviceToDevice, st));
+      cache->filled = true;
+    }
+  } else if (!planning) {
+    CK((int)hipMemcpy2DAsync(out_pixels, (size_t)T * 3 * res * res * 4, cache->ctx_pixels, (size_t)ctx * 3 * res * res * 4,
+                             (size_t)ctx * 3 * res * res * 4, B, hipMemcpyDeviceToDevice, st));
+  }
+  if (F > 0) {
+    const int M = B * F;
+    void* qd = e->ws.alloc((size_t)M * 16 * dim * esz(dt));
+    void* q2 = e->ws.alloc((size_t)M * 16 * p * p * lat * esz(dt));
+    void* z = e->ws.alloc((size_t)M * 256 * lat * esz(dt));
+    if (!planning) {
+      TokMap mp{16, F, L, 257 * ctx, 17};
+      CK(launch_gather_rows(ids, mp, e->cb_d, qd, dt, M * 16, dim, c.num_vq_embeddings, c.num_dyn_embeddings, st));
+    }
+    IVG_TRY(linear(dt, qd, (long)M * 16, e->post_quant_linear, q2, nullptr, 0, 0));
+    if (!planning) CK(launch_unpatchify(q2, z, dt, M, 16 / p, lat, p, st));
+    IVG_TRY(decoder_trunk(e->cdec, z, B, F, T, ctx, nullptr, &feats, out_pixels));
+  }
+  e->ws.reset(m);
+  return 0;
+}
+
+}  // namespace ivg

@@ -1,0 +1,274 @@
+// Llama-style autoregressive transformer over video tokens on the hand-written kernels.
+//
+// Replaces (structure only; arithmetic is in the .hip kernels):
+//   HF LlamaForCausalLM.forward / GenerationMixin._sample          
+//   HeadModelWithAction.generate / .forward                        ivideogpt/transformer/action_model.py:56-121,154-205
+// MI355X-first differences from the reference's op sequence (token-identical):
+//   * ONE prefill + KV-cached single-token steps even in the action-conditioned mode (the reference
+//     re-prefills the whole prefix for every future frame, action_model.py:101-110);
+//   * a decode step is a fixed sequence of ~100 kernels whose step-dependent scalars live in device
+//     memory, captured once into a hipGraph and replayed for every generated token -- no host sync,
+//     no per-step Python;
+//   * decode GEMMs stream each weight matrix once (HBM-bound), split-K partials are folded into the
+//     next fused residual-add + RMSNorm kernel in a fixed order (deterministic).
+#include "engine_impl.h"
+
+namespace ivg {
+
+#define CK(x) do { int _e = (x); if (_e != 0) return e->fail(IVG_ERR_HIP, std::string(#x) + " failed: hip error " + std::to_string(_e)); } while (0)
+
+static size_t esz(DType d) { return d == BF16 ? 2 : 4; }
+static size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct GenBuf {  // persistent decode-step buffers (fixed addresses so the captured step graph can be replayed)
+  StepState* state; char* x; char* xn; char* qkv; char* attn; char* act; float* part_o; float* part_d; float* logits;
+  int64_t* ids; float* uni; char* act_emb; int so, sd, Bc, ids_ld;
+};
+
+static int gen_chunk(const ivg_engine* e) { return std::min(e->cfg.max_batch, 128); }
+
+static void gen_layout(const ivg_engine* e, GenBuf& g, char* base, size_t* total) {
+  const ivg_config& c = e->cfg;
+  const DType dt = e->llm_dt;
+  const int Bc = gen_chunk(e), H = c.hidden_size, I = c.intermediate_size, V = c.vocab_size;
+  g.Bc = Bc;
+  g.so = skinny_pick_splits(H, H, dt);
+  g.sd = skinny_pick_splits(H, I, dt);
+  g.ids_ld = e->Lmax;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off = rup(off + bytes, 256); return p; };
+  g.state = (StepState*)take(sizeof(StepState));
+  g.x = take((size_t)Bc * H * esz(dt));
+  g.xn = take((size_t)Bc * H * esz(dt));
+  g.qkv = take((size_t)Bc * 3 * H * esz(dt));
+  g.attn = take((size_t)Bc * H * esz(dt));
+  g.act = take((size_t)Bc * I * esz(dt));
+  g.part_o = (float*)take((size_t)g.so * Bc * H * 4);
+  g.part_d = (float*)take((size_t)g.sd * Bc * H * 4);
+  g.logits = (float*)take((size_t)Bc * V * 4);
+  g.ids = (int64_t*)take((size_t)Bc * g.ids_ld * 8);
+  g.uni = (float*)take((size_t)Bc * g.ids_ld * 4);
+  g.act_emb = take((size_t)Bc * std::max(1, c.max_frames) * H * esz(dt));
+  *total = off;
+}
+
+size_t gen_buffer_bytes(const ivg_engine* e) {
+  GenBuf g;
+  size_t t = 0;
+  gen_layout(e, g, nullptr, &t);
+  return t;
+}
+
+static char* kc_ptr(const ivg_engine* e, int layer, int which) {
+  const size_t per = (size_t)gen_chunk(e) * e->heads * e->Lmax * e->hd * esz(e->llm_dt);
+  return e->kv + ((size_t)layer * 2 + which) * per;
+}
+
+// -------------------------------------------------------------------------------------------- prefill
+int Run::prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const void* act_emb, int act_T, int ctx, bool all_slots,
+                 float* logits_all, float* logits_last, void* hidden_last) {
+  const ivg_config& c = e->cfg;
+  const DType dt = e->llm_dt;
+  const int H = c.hidden_size, I = c.intermediate_size, V = c.vocab_size, heads = e->heads, hd = e->hd, Lmax = e->Lmax;
+  const long M = (long)B * L;
+  const int Lp = (int)rup(L, 64);
+  const size_t m = e->ws.mark();
+  char* x = (char*)e->ws.alloc((size_t)M * H * esz(dt));
+  char* xn = (char*)e->ws.alloc((size_t)M * H * esz(dt));
+  char* qkv = (char*)e->ws.alloc((size_t)M * 3 * H * esz(dt));
+  char* attn = (char*)e->ws.alloc((size_t)M * H * esz(dt));
+  char* act = (char*)e->ws.alloc((size_t)M * I * esz(dt));
+  float* S = (float*)e->ws.alloc((size_t)B * heads * L * Lp * 4);
+  char* Pm = (char*)e->ws.alloc((size_t)B * heads * L * Lp * esz(dt));
+  if (!planning) {
+    CK(launch_embed(ids, ids_stride, e->embed, x, dt, B, L, H, st));
+    if (act_emb) {  // action embedding on the sdf slot(s): slot i (position 257*ctx - 1 + 17*i) gets action i + ctx - 1
+      for (int i = 0;; ++i) {
+        const int pos = 257 * ctx - 1 + 17 * i;
+        if (pos >= L || i + ctx - 1 >= act_T) break;
+        CK(launch_add_rows(x + (size_t)pos * H * esz(dt), (long)L * H, (const char*)act_emb + (size_t)(i + ctx - 1) * H * esz(dt),
+                           (long)act_T * H, B, H, dt, st));
+        if (!all_slots) break;
+      }
+    }
+  }
+  for (int l = 0; l < c.num_layers; ++l) {
+    const LayerW& w = e->layers[l];
+    if (!planning) CK(launch_add_rmsnorm(x, H, nullptr, 0, w.ln1, xn, (int)M, H, c.rms_norm_eps, dt, st));
+    ConvW wq; wq.w = w.wqkv; wq.cin = H; wq.cout = 3 * H;
+    IVG_TRY(linear(dt, xn, M, wq, qkv, nullptr, 0, 0));
+    if (!planning)
+      CK(launch_rope_kv(qkv, kc_ptr(e, l, 0), kc_ptr(e, l, 1), e->vt, Lp, e->rope_cos, e->rope_sin, B, L, heads, hd, Lmax, nullptr, 0, dt, st));
+    {  // S[b][h] = Q K^T / sqrt(hd)
+      IgemmArgs g;
+      g.X = qkv; g.W = kc_ptr(e, l, 0); g.Y = S;
+      g.Nimg = 1; g.Hin = 1; g.Win = L; g.Cin = hd; g.ldx = 3 * H; g.Hout = 1; g.Wout = L;
+      g.N = L; g.ldw = hd; g.c_pix = Lp; g.c_ch = 1; g.flags = IG_OUT_F32; g.alpha = 1.0f / sqrtf((float)hd);
+      g.nb0 = B; g.nb1 = heads;
+      g.sa[0] = (long)L * 3 * H; g.sa[1] = hd;
+      g.sw[0] = (long)heads * Lmax * hd; g.sw[1] = (long)Lmax * hd;
+      g.sy[0] = (long)heads * L * Lp; g.sy[1] = (long)L * Lp;
+      IVG_TRY(gemm(dt, g, 2.0 * B * heads * (double)L * L * hd, (double)esz(dt) * 2.0 * M * H + 4.0 * B * heads * L * Lp));
+    }
+    if (!planning) CK(launch_softmax(S, Pm, (long)B * heads * L, L, L, Lp, Lp, 1, dt, st));
+    {  // attn[b][:, h*hd..] = P V
+      IgemmArgs g;
+      g.X = Pm; g.W = e->vt; g.Y = attn;
+      g.Nimg = 1; g.Hin = 1; g.Win = L; g.Cin = Lp; g.ldx = Lp; g.Hout = 1; g.Wout = L;
+      g.N = hd; g.ldw = Lp; g.c_pix = H; g.c_ch = 1;
+      g.nb0 = B; g.nb1 = heads;
+      g.sa[0] = (long)heads * L * Lp; g.sa[1] = (long)L * Lp;
+      g.sw[0] = (long)heads * hd * Lp; g.sw[1] = (long)hd * Lp;
+      g.sy[0] = (long)L * H; g.sy[1] = hd;
+      IVG_TRY(gemm(dt, g, 2.0 * B * heads * (double)L * Lp * hd, (double)esz(dt) * ((double)B * heads * L * Lp + 2.0 * M * H)));
+    }
+    ConvW wo; wo.w = w.wo; wo.cin = H; wo.cout = H;
+    IVG_TRY(linear(dt, attn, M, wo, x, x, 0, 0));  // in-place residual
+    if (!planning) CK(launch_add_rmsnorm(x, H, nullptr, 0, w.ln2, xn, (int)M, H, c.rms_norm_eps, dt, st));
+    {  // act = silu(gate) * up   (weights packed [16 gate | 16 up] per 32 rows)
+      IgemmArgs g;
+      g.X = xn; g.W = w.wgu; g.Y = act;
+      g.Nimg = 1; g.Hin = 1; g.Win = (int)M; g.Cin = H; g.ldx = H; g.Hout = 1; g.Wout = (int)M;
+      g.N = 2 * I; g.ldw = H; g.c_pix = I; g.c_ch = 1; g.flags = IG_GLU;
+      IVG_TRY(gemm(dt, g, 2.0 * M * (double)H * 2 * I, (double)esz(dt) * ((double)M * H + 2.0 * I * H + (double)M * I)));
+    }
+    ConvW wd; wd.w = w.wdown; wd.cin = I; wd.cout = H;
+    IVG_TRY(linear(dt, act, M, wd, x, x, 0, 0));
+  }
+  if (logits_all) {
+    if (!planning) CK(launch_add_rmsnorm(x, H, nullptr, 0, e->final_norm, xn, (int)M, H, c.rms_norm_eps, dt, st));
+    ConvW wl; wl.w = e->lm_head; wl.cin = H; wl.cout = V;
+    IVG_TRY(linear(dt, xn, M, wl, logits_all, nullptr, 0, 1));
+  }
+  if (logits_last && !planning) {
+    // final norm of the last position of every sequence -> hidden_last [B][H]; logits by the skinny GEMM
+    CK(launch_add_rmsnorm(x + (size_t)(L - 1) * H * esz(dt), (long)L * H, nullptr, 0, e->final_norm, hidden_last, B, H,
+                          c.rms_norm_eps, dt, st));
+    SkinnyArgs s;
+    s.X = hidden_last; s.W = e->lm_head; s.Y = logits_last; s.M = B; s.N = V; s.K = H; s.ldx = H; s.ldw = H; s.ldy = V;
+    s.flags = IG_OUT_F32;
+    CK(launch_skinny(s, dt, st));
+  }
+  e->ws.reset(m);
+  return 0;
+}
+
+// -------------------------------------------------------------------------------------------- one decode step
+// decide token j (sample / forced), embed it, run it through the layers against the KV cache, produce the
+// logits for token j+1, advance the device-side state.
+static int step_body(ivg_engine* e, hipStream_t st, const GenBuf& g, int B, const SampleArgs& sa, bool forward) {
+  const ivg_config& c = e->cfg;
+  const DType dt = e->llm_dt;
+  const int H = c.hidden_size, I = c.intermediate_size, V = c.vocab_size;
+  CK(launch_sample_embed(sa, B, dt, st));
+  if (!forward) return 0;
+  const float* pending = nullptr;
+  int pend_s = 0;
+  for (int l = 0; l < c.num_layers; ++l) {
+    const LayerW& w = e->layers[l];
+    CK(launch_add_rmsnorm(g.x, H, pending, pend_s, w.ln1, g.xn, B, H, c.rms_norm_eps, dt, st));
+    SkinnyArgs s;
+    s.X = g.xn; s.W = w.wqkv; s.Y = g.qkv; s.M = B; s.N = 3 * H; s.K = H; s.ldx = H; s.ldw = H; s.ldy = 3 * H;
+    CK(launch_skinny(s, dt, st));
+    CK(launch_rope_kv(g.qkv, kc_ptr(e, l, 0), kc_ptr(e, l, 1), nullptr, 0, e->rope_cos, e->rope_sin, B, 1, e->heads, e->hd, e->Lmax,
+                      g.state, 0, dt, st));
+    CK(launch_decode_attn(g.qkv, kc_ptr(e, l, 0), kc_ptr(e, l, 1), g.attn, B, e->heads, e->hd, e->Lmax, g.state, dt, st));
+    SkinnyArgs o;
+    o.X = g.attn; o.W = w.wo; o.Y = g.part_o; o.M = B; o.N = H; o.K = H; o.ldx = H; o.ldw = H; o.ldy = H; o.splits = g.so;
+    o.flags = IG_OUT_F32;
+    CK(launch_skinny(o, dt, st));
+    CK(launch_add_rmsnorm(g.x, H, g.part_o, g.so, w.ln2, g.xn, B, H, c.rms_norm_eps, dt, st));
+    SkinnyArgs u;
+    u.X = g.xn; u.W = w.wgu; u.Y = g.act; u.M = B; u.N = 2 * I; u.K = H; u.ldx = H; u.ldw = H; u.ldy = I; u.flags = IG_GLU;
+    CK(launch_skinny(u, dt, st));
+    SkinnyArgs d;
+    d.X = g.act; d.W = w.wdown; d.Y = g.part_d; d.M = B; d.N = H; d.K = I; d.ldx = I; d.ldw = I; d.ldy = H; d.splits = g.sd;
+    d.flags = IG_OUT_F32;
+    CK(launch_skinny(d, dt, st));
+    pending = g.part_d; pend_s = g.sd;
+  }
+  CK(launch_add_rmsnorm(g.x, H, pending, pend_s, e->final_norm, g.xn, B, H, c.rms_norm_eps, dt, st));
+  SkinnyArgs lm;
+  lm.X = g.xn; lm.W = e->lm_head; lm.Y = g.logits; lm.M = B; lm.N = V; lm.K = H; lm.ldx = H; lm.ldw = H; lm.ldy = V;
+  lm.flags = IG_OUT_F32;
+  CK(launch_skinny(lm, dt, st));
+  CK(launch_step_advance(g.state, st));
+  return 0;
+}
+
+int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, int n_new, const float* actions, int act_T, int ctx,
+                  const float* uniforms, int top_k, int64_t* ids_out, float* reward_out) {
+  const ivg_config& c = e->cfg;
+  const DType dt = e->llm_dt;
+  const int H = c.hidden_size, V = c.vocab_size;
+  GenBuf g;
+  size_t tot = 0;
+  gen_layout(e, g, e->gen_buf, &tot);
+  const long Ltot = (long)L0 + n_new;
+  if (planning) {
+    return prefill(nullptr, 0, std::min(B, g.Bc), L0, nullptr, 0, ctx, false, nullptr, nullptr, nullptr);
+  }
+  for (int b0 = 0; b0 < B; b0 += g.Bc) {
+    const int Bc = std::min(g.Bc, B - b0);
+    CK((int)hipMemcpy2DAsync(g.ids, (size_t)g.ids_ld * 8, prompt + (long)b0 * prompt_stride, (size_t)prompt_stride * 8, (size_t)L0 * 8, Bc,
+                             hipMemcpyDeviceToDevice, st));
+    if (uniforms)
+      CK((int)hipMemcpy2DAsync(g.uni, (size_t)g.ids_ld * 4, uniforms + (long)b0 * n_new, (size_t)n_new * 4, (size_t)n_new * 4, Bc,
+                               hipMemcpyDeviceToDevice, st));
+    if (actions)
+      CK(launch_action_embed(actions + (long)b0 * act_T * c.action_dim, e->act_w, e->act_b, g.act_emb, dt, Bc * act_T, c.action_dim, H, st));
+    IVG_TRY(prefill(g.ids, g.ids_ld, Bc, L0, actions ? g.act_emb : nullptr, act_T, ctx, false, nullptr, g.logits, g.xn));
+    CK(launch_state_set(g.state, L0, 1, st));
+    SampleArgs sa;
+    sa.logits = g.logits; sa.V = V;
+    sa.uniforms = uniforms ? g.uni : nullptr; sa.n_uni = g.ids_ld;
+    sa.top_k = top_k;
+    sa.ids_out = g.ids; sa.ids_stride = g.ids_ld; sa.L0 = L0;
+    sa.forced_period = actions ? 17 : 0; sa.forced_token = V - 1;
+    sa.E = e->embed; sa.x = g.x; sa.H = H;
+    sa.act = actions ? g.act_emb : nullptr; sa.act_T = act_T; sa.ctx = ctx;
+    sa.state = g.state;
+    // step 1 eagerly (also performs every kernel's one-time attribute setup), then replay a captured step graph
+    const std::string key = std::to_string(Bc) + ":" + (uniforms ? "s" : "g") + ":" + std::to_string(top_k) + ":" +
+                            std::to_string(sa.forced_period) + ":" + std::to_string(ctx) + ":" + std::to_string(act_T) + ":" +
+                            std::to_string(L0);
+    int j = 1;
+    if (n_new >= 1) { IVG_TRY(step_body(e, st, g, Bc, sa, j < n_new)); ++j; }
+    hipGraphExec_t exec = nullptr;
+    if (e->use_graph && st != nullptr && j < n_new) {
+      auto it = e->graphs.find(key);
+      if (it != e->graphs.end()) {
+        exec = it->second;
+      } else {
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+          const int rc = step_body(e, st, g, Bc, sa, true);
+          const hipError_t ce = hipStreamEndCapture(st, &graph);
+          if (rc == 0 && ce == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+            e->graphs[key] = exec;
+          } else {
+            exec = nullptr;
+            (void)hipGetLastError();
+          }
+          if (graph) (void)hipGraphDestroy(graph);
+        } else {
+          (void)hipGetLastError();
+        }
+      }
+    }
+    for (; j < n_new; ++j) {
+      if (exec) CK((int)hipGraphLaunch(exec, st));
+      else IVG_TRY(step_body(e, st, g, Bc, sa, true));
+    }
+    if (j == n_new && n_new > 1) IVG_TRY(step_body(e, st, g, Bc, sa, false));  // decide the last token (no forward)
+    CK((int)hipMemcpy2DAsync(ids_out + (long)b0 * Ltot, (size_t)Ltot * 8, g.ids, (size_t)g.ids_ld * 8, (size_t)Ltot * 8, Bc,
+                             hipMemcpyDeviceToDevice, st));
+    if (reward_out) {
+      if (!e->rew_w) return e->fail(IVG_ERR_MISSING, "generate: reward requested but reward_linear is not loaded");
+      CK(launch_rowdot(g.xn, e->rew_w, e->rew_b, reward_out + b0, Bc, H, dt, st));
+    }
+  }
+  return 0;
+}
+
+}  // namespace ivg

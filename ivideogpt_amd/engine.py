@@ -1,0 +1,159 @@
+"""Thin Python handle on a libivg engine (one per process per GPU).  All compute happens in the HIP
+library; PyTorch only owns the device buffers (weights, inputs, outputs) and the stream."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .packing import dtype_code
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def current_stream(device):
+    """A non-default stream handle for the engine (hipGraph capture is not allowed on the legacy stream)."""
+    s = torch.cuda.current_stream(device)
+    return s
+
+
+class Engine:
+    def __init__(self, device, tensors, tok_cfg=None, llm_cfg=None, action_dim=0, reward_head=False,
+                 encode_dtype="fp32", decode_dtype="bf16", llm_dtype="bf16", max_batch=1, max_frames=16, max_seq=0):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("ivideogpt_amd runs on an MI355X only (device must be 'cuda'); there is no CPU path")
+        self.tensors = tensors  # keep the packed weights alive: the engine borrows their device memory
+        cfg = _lib.IvgConfig()
+        if tok_cfg is not None:
+            ch = list(tok_cfg["block_out_channels"])
+            cfg.n_levels = len(ch)
+            for i, c in enumerate(ch):
+                cfg.block_out_channels[i] = c
+            for k in ("layers_per_block", "latent_channels", "vq_embed_dim", "num_vq_embeddings", "num_dyn_embeddings",
+                      "norm_num_groups", "context_length", "max_att_resolution", "resolution", "patch_size"):
+                setattr(cfg, k, int(tok_cfg[k]))
+            cfg.mid_block_add_attention = int(bool(tok_cfg["mid_block_add_attention"]))
+        if llm_cfg is not None:
+            cfg.hidden_size, cfg.intermediate_size = llm_cfg["hidden_size"], llm_cfg["intermediate_size"]
+            cfg.num_layers, cfg.num_heads = llm_cfg["num_hidden_layers"], llm_cfg["num_attention_heads"]
+            cfg.vocab_size, cfg.max_position_embeddings = llm_cfg["vocab_size"], llm_cfg["max_position_embeddings"]
+            cfg.rms_norm_eps = llm_cfg["rms_norm_eps"]
+            cfg.action_dim, cfg.reward_head = int(action_dim or 0), int(bool(reward_head))
+        cfg.encode_dtype, cfg.decode_dtype, cfg.llm_dtype = dtype_code(encode_dtype), dtype_code(decode_dtype), dtype_code(llm_dtype)
+        cfg.max_batch, cfg.max_frames, cfg.max_seq = int(max_batch), int(max_frames), int(max_seq)
+        self.cfg = cfg
+        names = [n.encode() for n in tensors]
+        table = (_lib.IvgTensor * len(tensors))()
+        for i, (n, t) in enumerate(tensors.items()):
+            assert t.is_cuda and t.is_contiguous(), n
+            table[i].name = names[i]
+            table[i].data = t.data_ptr()
+            table[i].dtype = dtype_code(t.dtype)
+            table[i].ndim = min(t.dim(), 4)
+            shp = list(t.shape) if t.dim() <= 4 else [t.numel()]
+            for j, s in enumerate(shp[:4]):
+                table[i].shape[j] = s
+            if t.dim() > 4:
+                table[i].ndim = 1
+        self._names = names
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self.lib.ivg_create(C.byref(cfg), table, len(tensors), self.device.index or 0, C.byref(h))
+        _lib.check(rc, None, "ivg_create")
+        self.h = h
+        self.max_batch, self.max_frames = int(max_batch), int(max_frames)
+        self._stream = torch.cuda.Stream(device=self.device)  # dedicated non-default stream (graph capture needs one)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ivg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- stream plumbing: run on our stream, ordered after the caller's current stream and before its future work
+    class _On:
+        def __init__(self, eng):
+            self.eng = eng
+
+        def __enter__(self):
+            cur = torch.cuda.current_stream(self.eng.device)
+            self.eng._stream.wait_stream(cur)
+            self.cur = cur
+            return C.c_void_p(self.eng._stream.cuda_stream)
+
+        def __exit__(self, *exc):
+            self.cur.wait_stream(self.eng._stream)
+            return False
+
+    def stream(self):
+        return Engine._On(self)
+
+    def check(self, rc, what):
+        _lib.check(rc, self.h, what)
+
+    # ---- entry points
+    def set_context_length(self, k):
+        self.check(self.lib.ivg_set_context_length(self.h, int(k)), "set_context_length")
+
+    def tokenize(self, pixels, ids, labels):
+        B, T = pixels.shape[:2]
+        with self.stream() as s:
+            self.check(self.lib.ivg_tokenize(self.h, _ptr(pixels), dtype_code(pixels.dtype), B, T, _ptr(ids), _ptr(labels), s), "tokenize")
+            for t in (pixels, ids, labels):
+                if t is not None:
+                    t.record_stream(self._stream)
+
+    def encode_context(self, pixels, ids):
+        B, T = pixels.shape[:2]
+        with self.stream() as s:
+            self.check(self.lib.ivg_encode_context(self.h, _ptr(pixels), dtype_code(pixels.dtype), B, T, _ptr(ids), ids.stride(0), s),
+                       "encode_context")
+            pixels.record_stream(self._stream); ids.record_stream(self._stream)
+
+    def detokenize(self, ids, F, out, cache=None, cache_mode=0):
+        with self.stream() as s:
+            self.check(self.lib.ivg_detokenize(self.h, _ptr(ids), ids.shape[0], int(F), _ptr(out), cache, int(cache_mode), s), "detokenize")
+            ids.record_stream(self._stream); out.record_stream(self._stream)
+
+    def cache_create(self, B):
+        h = C.c_void_p()
+        self.check(self.lib.ivg_cache_create(self.h, int(B), C.byref(h)), "cache_create")
+        return h
+
+    def cache_destroy(self, h):
+        self.lib.ivg_cache_destroy(self.h, h)
+
+    def generate(self, prompt, n_new, out, actions=None, ctx=1, uniforms=None, top_k=100, reward=None):
+        B, L0 = prompt.shape
+        act_T = actions.shape[1] if actions is not None else 0
+        with self.stream() as s:
+            self.check(self.lib.ivg_generate(self.h, _ptr(prompt), prompt.stride(0), B, L0, int(n_new), _ptr(actions), act_T, int(ctx),
+                                             _ptr(uniforms), int(top_k), _ptr(out), _ptr(reward), s), "generate")
+            for t in (prompt, out, actions, uniforms, reward):
+                if t is not None:
+                    t.record_stream(self._stream)
+
+    def logits(self, ids, out, actions=None, ctx=1):
+        B, L = ids.shape
+        act_T = actions.shape[1] if actions is not None else 0
+        with self.stream() as s:
+            self.check(self.lib.ivg_logits(self.h, _ptr(ids), B, L, _ptr(actions), act_T, int(ctx), _ptr(out), s), "logits")
+            for t in (ids, out, actions):
+                if t is not None:
+                    t.record_stream(self._stream)
+
+    def profile_enable(self, kclass, on=True):
+        self.check(self.lib.ivg_profile_enable(self.h, kclass, int(on)), "profile_enable")
+
+    def profile_read(self, kclass):
+        st = _lib.IvgProfileStats()
+        self.check(self.lib.ivg_profile_read(self.h, kclass, C.byref(st)), "profile_read")
+        return dict(launches=st.launches, total_ms=st.total_ms, total_flops=st.total_flops, total_bytes=st.total_bytes)

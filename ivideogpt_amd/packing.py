@@ -1,0 +1,92 @@
+"""Checkpoint tensors -> the device layouts libivg consumes (host-side tensor plumbing, PyTorch-ROCm).
+
+Layouts (see csrc/igemm.hip): activations are NHWC, so a conv weight [Cout, Cin, kh, kw] becomes
+[Cout, kh*kw*Cin] (K contiguous, ordered (kh, kw, c)); linears stay [N, K]; q/k/v of the Llama layers are
+fused into one [3H, H] matrix; gate/up are interleaved [16 gate | 16 up] per 32 rows so the GEMM epilogue can
+apply SiLU(gate)*up in registers.  Norm affine parameters, biases, position embeddings and the codebooks stay fp32.
+"""
+import torch
+
+from . import _lib
+
+_TORCH_DT = {_lib.IVG_F32: torch.float32, _lib.IVG_BF16: torch.bfloat16}
+
+
+def torch_dtype(code):
+    return _TORCH_DT[code]
+
+
+def dtype_code(dt):
+    if dt in (torch.float32, "fp32", "float32", "f32", _lib.IVG_F32):
+        return _lib.IVG_F32
+    if dt in (torch.bfloat16, "bf16", "bfloat16", _lib.IVG_BF16):
+        return _lib.IVG_BF16
+    raise ValueError(f"unsupported dtype {dt!r} (float32 / bfloat16)")
+
+
+def _conv(w, dt):
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dt).contiguous()
+
+
+def pack_tokenizer(sd, cfg, device, enc_code, dec_code):
+    """DF state dict of CompressiveVQModel -> {name: device tensor} for ivg_create."""
+    enc_dt, dec_dt = torch_dtype(enc_code), torch_dtype(dec_code)
+    out = {}
+    for k, v in sd.items():
+        v = v.detach().to(device=device, dtype=torch.float32)
+        top = k.split(".")[0]
+        dt = enc_dt if top in ("encoder", "cond_encoder", "quant_conv", "quant_linear") else dec_dt
+        if k.endswith(("pos_emb", "embedding.weight", ".bias", "in_proj_bias")) or v.dim() == 1:
+            out[k] = v.contiguous()
+        elif k in ("encoder.conv_in.weight", "cond_encoder.conv_in.weight"):
+            out[k] = v.contiguous()                       # raw [C0, 3, 3, 3] fp32: direct first-layer kernel
+        elif v.dim() == 4:
+            out[k] = _conv(v, dt)
+        elif v.dim() == 2:
+            out[k] = v.to(dt).contiguous()                # Linear / MHA in_proj / out_proj; quant_linear is already (ph, pw, c)
+        else:
+            raise ValueError(f"unexpected tensor {k} {tuple(v.shape)}")
+    return out
+
+
+def pack_llama(sd, cfg, device, code, prefix=""):
+    """HF Llama (optionally HeadModelWithAction, prefix 'llm.') state dict -> engine tensors."""
+    dt = torch_dtype(code)
+    H, I, nl = cfg["hidden_size"], cfg["intermediate_size"], cfg["num_hidden_layers"]
+    heads = cfg["num_attention_heads"]
+    hd = H // heads
+
+    def g(name):
+        return sd[prefix + name].detach().to(device=device, dtype=torch.float32)
+
+    def vec(t):  # HF keeps norm weights in the model dtype: round through it so the products match
+        return t.to(dt).float().contiguous()
+
+    out = {}
+    for l in range(nl):
+        b = f"model.layers.{l}."
+        out[f"llm.layers.{l}.wqkv"] = torch.cat([g(b + "self_attn.q_proj.weight"), g(b + "self_attn.k_proj.weight"),
+                                                 g(b + "self_attn.v_proj.weight")], 0).to(dt).contiguous()
+        out[f"llm.layers.{l}.wo"] = g(b + "self_attn.o_proj.weight").to(dt).contiguous()
+        gate, up = g(b + "mlp.gate_proj.weight"), g(b + "mlp.up_proj.weight")
+        assert I % 16 == 0
+        out[f"llm.layers.{l}.wgu"] = torch.stack([gate.view(I // 16, 16, H), up.view(I // 16, 16, H)], 1) \
+            .reshape(2 * I, H).to(dt).contiguous()
+        out[f"llm.layers.{l}.wdown"] = g(b + "mlp.down_proj.weight").to(dt).contiguous()
+        out[f"llm.layers.{l}.ln1"] = vec(g(b + "input_layernorm.weight"))
+        out[f"llm.layers.{l}.ln2"] = vec(g(b + "post_attention_layernorm.weight"))
+    out["llm.embed"] = g("model.embed_tokens.weight").to(dt).contiguous()
+    out["llm.lm_head"] = g("lm_head.weight").to(dt).contiguous()
+    out["llm.norm"] = vec(g("model.norm.weight"))
+    # RoPE tables exactly as HF builds them (fp32 inv_freq, fp32 outer product, cos/sin, cast to the model dtype)
+    inv_freq = 1.0 / (cfg.get("rope_theta", 10000.0) ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    freqs = torch.arange(cfg["max_position_embeddings"], dtype=torch.float32)[:, None] * inv_freq[None, :]
+    out["llm.rope_cos"] = vec(freqs.cos().to(device))
+    out["llm.rope_sin"] = vec(freqs.sin().to(device))
+    if prefix and "action_linear.weight" in sd:
+        out["llm.action_linear.weight"] = sd["action_linear.weight"].detach().to(device=device, dtype=torch.float32).contiguous()
+        out["llm.action_linear.bias"] = sd["action_linear.bias"].detach().to(device=device, dtype=torch.float32).contiguous()
+    if "reward_linear.weight" in sd:
+        out["llm.reward_linear.weight"] = sd["reward_linear.weight"].detach().to(device=device, dtype=torch.float32).reshape(-1).contiguous()
+        out["llm.reward_linear.bias"] = sd["reward_linear.bias"].detach().to(device=device, dtype=torch.float32).contiguous()
+    return out
