@@ -1,0 +1,293 @@
+"""Op-level parity: every hand-written kernel, called through the C ABI (include/ivg.h), against a plain
+fp32/fp64 PyTorch-CPU statement of the same op.  Runs on the MI355X only (-m gpu)."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+TOL = {"fp32": 2e-5, "bf16": 2e-2}   # relative to the output scale (bf16: inputs rounded once + bf16 output)
+
+
+def lib():
+    from ivideogpt_amd import _lib
+    return _lib, _lib.load()
+
+
+def tdt(name):
+    return torch.float32 if name == "fp32" else torch.bfloat16
+
+
+def code(name):
+    return 0 if name == "fp32" else 1
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+def igemm(dt, X, W, Y, R=None, bias=None, **kw):
+    L, l = lib()
+    a = L.IvgIgemmArgs()
+    a.X, a.W, a.Y, a.R, a.bias = X.data_ptr(), W.data_ptr(), Y.data_ptr(), (R.data_ptr() if R is not None else None), \
+        (bias.data_ptr() if bias is not None else None)
+    defaults = dict(Nimg=1, Hin=1, Win=1, Cin=0, ldx=0, Hout=1, Wout=1, KH=1, KW=1, stride=1, pad=0, ups=0, N=0, ldw=0,
+                    c_img=0, c_pix=0, c_ch=1, c_grp=1, c_grp_stride=0, flags=0, alpha=1.0, nb0=1, nb1=1, nb2=1)
+    defaults.update(kw)
+    for k, v in defaults.items():
+        if k in ("sa", "sw", "sy"):
+            continue
+        setattr(a, k, v)
+    for name in ("sa", "sw", "sy"):
+        for i, v in enumerate(kw.get(name, (0, 0, 0))):
+            getattr(a, name)[i] = v
+    rc = l.ivg_op_igemm(C.byref(a), code(dt), stream())
+    assert rc == 0, f"ivg_op_igemm rc={rc}"
+    torch.cuda.synchronize()
+
+
+def q(t, dt):
+    """round through the kernel's storage type (so the CPU reference sees the same inputs)"""
+    return t.to(tdt(dt)).float()
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(300, 200, 256), (128, 128, 64), (1000, 48, 192), (77, 16386, 128)])
+def test_gemm_bias_residual(dt, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    X, W_, R, b = q(torch.randn(M, K, generator=g), dt), q(torch.randn(N, K, generator=g), dt), q(torch.randn(M, N, generator=g), dt), torch.randn(N, generator=g)
+    ref = X.double() @ W_.double().T + b.double() + R.double()
+    Xd, Wd, Rd, bd = X.to(DEV, tdt(dt)), W_.to(DEV, tdt(dt)), R.to(DEV, tdt(dt)), b.to(DEV)
+    Y = torch.full((M, N), float("nan"), device=DEV, dtype=tdt(dt))
+    igemm(dt, Xd, Wd, Y, Rd, bd, Win=M, Wout=M, Cin=K, ldx=K, N=N, ldw=K, c_pix=N, flags=1 | 4)
+    assert rel_err(Y.float(), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["s1", "s2", "ups", "k1", "patch4"])
+def test_conv_modes(dt, mode):
+    g = torch.Generator().manual_seed(7)
+    Nb, H, Cin, Cout = 3, 16, 64, 128
+    x = q(torch.randn(Nb, Cin, H, H, generator=g), dt)
+    k = {"s1": 3, "s2": 3, "ups": 3, "k1": 1, "patch4": 4}[mode]
+    w = q(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5, dt)
+    b = torch.randn(Cout, generator=g)
+    xd = x.double()
+    if mode == "s1":
+        ref, Ho, stride, pad, ups = F.conv2d(xd, w.double(), b.double(), padding=1), H, 1, 1, 0
+    elif mode == "s2":
+        ref, Ho, stride, pad, ups = F.conv2d(F.pad(xd, (0, 1, 0, 1)), w.double(), b.double(), stride=2), H // 2, 2, 0, 0
+    elif mode == "ups":
+        ref, Ho, stride, pad, ups = F.conv2d(F.interpolate(xd, scale_factor=2.0, mode="nearest"), w.double(), b.double(), padding=1), 2 * H, 1, 1, 1
+    elif mode == "k1":
+        ref, Ho, stride, pad, ups = F.conv2d(xd, w.double(), b.double()), H, 1, 0, 0
+    else:
+        ref, Ho, stride, pad, ups = F.conv2d(xd, w.double(), b.double(), stride=4), H // 4, 4, 0, 0
+    X = x.permute(0, 2, 3, 1).contiguous().to(DEV, tdt(dt))
+    Wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(DEV, tdt(dt))
+    Y = torch.full((Nb, Ho, Ho, Cout), float("nan"), device=DEV, dtype=tdt(dt))
+    igemm(dt, X, Wp, Y, None, b.to(DEV), Nimg=Nb, Hin=H, Win=H, Cin=Cin, ldx=Cin, Hout=Ho, Wout=Ho, KH=k, KW=k, stride=stride,
+          pad=pad, ups=ups, N=Cout, ldw=k * k * Cin, c_img=Ho * Ho * Cout, c_pix=Cout, flags=1)
+    assert rel_err(Y.float().permute(0, 3, 1, 2), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_conv_out_planar_video(dt):
+    """Cout = 3 written straight into a planar (B, T, 3, H, W) fp32 clip at frame offsets (decoder tail)."""
+    g = torch.Generator().manual_seed(9)
+    B, per, T, t0, H, Cin = 2, 3, 5, 2, 16, 64
+    x = q(torch.randn(B * per, Cin, H, H, generator=g), dt)
+    w = q(torch.randn(3, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5, dt)
+    b = torch.randn(3, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1).reshape(B, per, 3, H, H)
+    X = x.permute(0, 2, 3, 1).contiguous().to(DEV, tdt(dt))
+    Wp = w.permute(0, 2, 3, 1).reshape(3, -1).contiguous().to(DEV, tdt(dt))
+    clip = torch.full((B, T, 3, H, H), -7.0, device=DEV)
+    Yv = clip.view(-1)[t0 * 3 * H * H:]
+    igemm(dt, X, Wp, Yv, None, b.to(DEV), Nimg=B * per, Hin=H, Win=H, Cin=Cin, ldx=Cin, Hout=H, Wout=H, KH=3, KW=3, stride=1, pad=1,
+          N=3, ldw=9 * Cin, c_img=3 * H * H, c_pix=1, c_ch=H * H, c_grp=per, c_grp_stride=T * 3 * H * H, flags=1 | 32)
+    assert rel_err(clip[:, t0:t0 + per], ref) < TOL[dt]
+    assert (clip[:, :t0] == -7.0).all()
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_batched_attention_gemms(dt):
+    """strided batch (b, f, head) with a shared (stride 0) operand, alpha, fp32 scores, K tail (hd = 48), bias along M."""
+    g = torch.Generator().manual_seed(11)
+    B, Fr, nh, hd, P_, kv = 2, 3, 4, 48, 64, 128
+    Cc = nh * hd
+    Q = q(torch.randn(B * Fr, P_, Cc, generator=g), dt)
+    Kp = q(torch.randn(B, kv, Cc, generator=g), dt)
+    ref = torch.einsum("bfphd,bkhd->bfhpk", Q.view(B, Fr, P_, nh, hd).double(), Kp.view(B, kv, nh, hd).double()) * 0.25
+    S = torch.full((B, Fr, nh, P_, kv), float("nan"), device=DEV)
+    igemm(dt, Q.to(DEV, tdt(dt)), Kp.to(DEV, tdt(dt)), S, Win=P_, Wout=P_, Cin=hd, ldx=Cc, N=kv, ldw=Cc, c_pix=kv, flags=32, alpha=0.25,
+          nb0=B, nb1=Fr, nb2=nh, sa=(Fr * P_ * Cc, P_ * Cc, hd), sw=(kv * Cc, 0, hd), sy=(Fr * nh * P_ * kv, nh * P_ * kv, P_ * kv))
+    assert rel_err(S, ref) < TOL[dt]
+    # V^T[b][c][tok] = Wv[c][:] . x[b][tok][:] + bv[c]   (shared X operand, bias along M)
+    Wv, x, bv = q(torch.randn(Cc, Cc, generator=g) / Cc ** 0.5, dt), q(torch.randn(B, kv, Cc, generator=g), dt), torch.randn(Cc, generator=g)
+    refv = torch.einsum("ck,btk->bct", Wv.double(), x.double()) + bv.double()[None, :, None]
+    VT = torch.full((B, Cc, kv), float("nan"), device=DEV, dtype=tdt(dt))
+    igemm(dt, Wv.to(DEV, tdt(dt)), x.to(DEV, tdt(dt)), VT, None, bv.to(DEV), Win=Cc, Wout=Cc, Cin=Cc, ldx=Cc, N=kv, ldw=Cc, c_pix=kv, flags=2,
+          nb0=B, sa=(0, 0, 0), sw=(kv * Cc, 0, 0), sy=(Cc * kv, 0, 0))
+    assert rel_err(VT.float(), refv) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_glu_epilogue(dt):
+    g = torch.Generator().manual_seed(13)
+    M, H, I = 200, 128, 256
+    x, gate, up = q(torch.randn(M, H, generator=g), dt), q(torch.randn(I, H, generator=g) / H ** 0.5, dt), q(torch.randn(I, H, generator=g) / H ** 0.5, dt)
+    ref = F.silu(x.double() @ gate.double().T) * (x.double() @ up.double().T)
+    wgu = torch.stack([gate.view(I // 16, 16, H), up.view(I // 16, 16, H)], 1).reshape(2 * I, H).contiguous()
+    Y = torch.full((M, I), float("nan"), device=DEV, dtype=tdt(dt))
+    igemm(dt, x.to(DEV, tdt(dt)), wgu.to(DEV, tdt(dt)), Y, Win=M, Wout=M, Cin=H, ldx=H, N=2 * I, ldw=H, c_pix=I, flags=16)
+    assert rel_err(Y.float(), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("M", [3, 64, 100])
+def test_skinny_gemm(dt, M):
+    L, l = lib()
+    g = torch.Generator().manual_seed(17 + M)
+    N, K, I = 200, 512, 128
+    x, w = q(torch.randn(M, K, generator=g), dt), q(torch.randn(N, K, generator=g) / K ** 0.5, dt)
+    ref = x.double() @ w.double().T
+    xd, wd = x.to(DEV, tdt(dt)), w.to(DEV, tdt(dt))
+    Y = torch.full((M, N), float("nan"), device=DEV, dtype=tdt(dt))
+    assert l.ivg_op_skinny(P(xd), P(wd), P(Y), M, N, K, K, K, N, 1, 0, code(dt), stream()) == 0
+    torch.cuda.synchronize()
+    assert rel_err(Y.float(), ref) < TOL[dt]
+    Yf = torch.full((M, N), float("nan"), device=DEV)
+    assert l.ivg_op_skinny(P(xd), P(wd), P(Yf), M, N, K, K, K, N, 1, 32, code(dt), stream()) == 0
+    torch.cuda.synchronize()
+    assert rel_err(Yf, ref) < 2e-5  # fp32 output: only accumulation-order error
+    parts = torch.full((2, M, N), float("nan"), device=DEV)
+    assert l.ivg_op_skinny(P(xd), P(wd), P(parts), M, N, K, K, K, N, 2, 32, code(dt), stream()) == 0
+    torch.cuda.synchronize()
+    assert rel_err(parts.sum(0), ref) < 2e-5
+    gate, up = q(torch.randn(I, K, generator=g) / K ** 0.5, dt), q(torch.randn(I, K, generator=g) / K ** 0.5, dt)
+    wgu = torch.stack([gate.view(I // 16, 16, K), up.view(I // 16, 16, K)], 1).reshape(2 * I, K).contiguous().to(DEV, tdt(dt))
+    refg = F.silu(x.double() @ gate.double().T) * (x.double() @ up.double().T)
+    Yg = torch.full((M, I), float("nan"), device=DEV, dtype=tdt(dt))
+    assert l.ivg_op_skinny(P(xd), P(wgu), P(Yg), M, 2 * I, K, K, K, I, 1, 16, code(dt), stream()) == 0
+    torch.cuda.synchronize()
+    assert rel_err(Yg.float(), refg) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("C_,P_,silu,pos", [(64, 256, 1, 0), (128, 4096, 1, 0), (192, 512, 0, 1), (768, 300, 1, 0), (512, 1500, 0, 1)])
+def test_groupnorm(dt, C_, P_, silu, pos):
+    L, l = lib()
+    g = torch.Generator().manual_seed(C_ + P_)
+    N = 3
+    x = q(torch.randn(N, P_, C_, generator=g) * 2 + 0.5, dt)
+    gamma, beta = torch.randn(C_, generator=g), torch.randn(C_, generator=g)
+    pe = torch.randn(P_, C_, generator=g) if pos else None
+    ref = F.group_norm(x.double().permute(0, 2, 1), 32, gamma.double(), beta.double(), 1e-6).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    if pos:
+        ref = ref + pe.double()
+    X = x.to(DEV, tdt(dt))
+    Y = torch.full_like(X, float("nan"))
+    ws = torch.empty(N * 64 * 32 * 2, dtype=torch.float64, device=DEV)
+    rc = l.ivg_op_groupnorm(P(X), P(Y), P(ws), P(gamma.to(DEV)), P(beta.to(DEV)), P(pe.to(DEV)) if pos else None, N, P_, C_, 32,
+                            1e-6, silu, code(dt), stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert rel_err(Y.float(), ref) < (1e-5 if dt == "fp32" else 1e-2)
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("Lq,Lk,causal", [(256, 512, 0), (514, 514, 1), (64, 2048, 0), (33, 33, 1)])
+def test_softmax(dt, Lq, Lk, causal):
+    L, l = lib()
+    g = torch.Generator().manual_seed(Lq + Lk)
+    rows_b = 3
+    ld = (Lk + 63) // 64 * 64
+    S = torch.randn(rows_b * Lq, ld, generator=g) * 3
+    ref = S[:, :Lk].double().view(rows_b, Lq, Lk)
+    if causal:
+        mask = torch.ones(Lq, Lk, dtype=torch.bool).tril(Lk - Lq)
+        ref = ref.masked_fill(~mask, float("-inf"))
+    ref = torch.softmax(ref, -1).view(-1, Lk)
+    Sd = S.to(DEV)
+    Pm = torch.full((rows_b * Lq, ld), float("nan"), device=DEV, dtype=tdt(dt))
+    assert l.ivg_op_softmax(P(Sd), P(Pm), rows_b * Lq, Lq, Lk, ld, ld, causal, code(dt), stream()) == 0
+    torch.cuda.synchronize()
+    assert (Pm[:, Lk:] == 0).all()
+    assert (Pm[:, :Lk].float().cpu().double() - ref).abs().max().item() < (1e-6 if dt == "fp32" else 4e-3)
+
+
+def test_vq_argmin_matches_cdist_argmin():
+    """K10 in isolation on the same fp32 z: indices bit-exact vs argmin(torch.cdist) (lowest index on ties)."""
+    L, l = lib()
+    g = torch.Generator().manual_seed(3)
+    for R, n_e, scale in [(1000, 8192, 0.5), (70, 512, 0.4), (4096, 8192, 1.0)]:
+        z = torch.randn(R, 64, generator=g) * 0.75
+        E = torch.randn(n_e, 64, generator=g) * scale
+        ref = torch.argmin(torch.cdist(z, E), dim=1)
+        out = torch.full((R,), -1, dtype=torch.int64, device=DEV)
+        ee = torch.empty(n_e, device=DEV)
+        assert l.ivg_op_vq_argmin(P(z.to(DEV)), P(E.to(DEV)), P(ee), P(out), R, n_e, stream()) == 0
+        torch.cuda.synchronize()
+        bad = (out.cpu() != ref).nonzero().flatten()
+        if len(bad):  # audit: every mismatch must be an fp32 near-tie in the fp64 distances
+            d = torch.cdist(z[bad].double(), E.double())
+            gap = (d.gather(1, out.cpu()[bad, None]) - d.gather(1, ref[bad, None])).abs().squeeze(1)
+            assert (gap < 1e-5).all(), f"{len(bad)} mismatches, max fp64 gap {gap.max():.3e}"
+        assert len(bad) == 0, f"{len(bad)} near-tie mismatches out of {R} (all within fp32 round-off)"
+    # duplicated codes: the lowest index must win
+    E = torch.randn(512, 64, generator=g)
+    E[300] = E[17]
+    z = E[300:301].clone() + 1e-3
+    out = torch.full((1,), -1, dtype=torch.int64, device=DEV)
+    ee = torch.empty(512, device=DEV)
+    assert l.ivg_op_vq_argmin(P(z.to(DEV)), P(E.to(DEV)), P(ee), P(out), 1, 512, stream()) == 0
+    torch.cuda.synchronize()
+    assert out.item() == 17
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_add_rmsnorm(dt):
+    L, l = lib()
+    g = torch.Generator().manual_seed(5)
+    M, H, S_ = 37, 768, 3
+    x, w = q(torch.randn(M, H, generator=g), dt), torch.randn(H, generator=g)
+    part = torch.randn(S_, M, H, generator=g)
+    xs = q(((x + part[0]) + part[1]) + part[2], dt)   # fixed summation order s = 0, 1, 2
+    xf = xs.double()
+    nrm = q((xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).float(), dt)
+    ref = w.double() * nrm.double()
+    X = x.to(DEV, tdt(dt))
+    out = torch.full((M, H), float("nan"), device=DEV, dtype=tdt(dt))
+    assert l.ivg_op_add_rmsnorm(P(X), P(part.to(DEV)), S_, P(w.to(DEV)), P(out), M, H, 1e-6, code(dt), stream()) == 0
+    torch.cuda.synchronize()
+    assert rel_err(X.float(), xs) < (1e-6 if dt == "fp32" else 1e-2)
+    assert rel_err(out.float(), ref) < (1e-5 if dt == "fp32" else 1.5e-2)
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_conv_in_from_video(dt):
+    L, l = lib()
+    g = torch.Generator().manual_seed(21)
+    B, T, t0, per, H, C0 = 2, 5, 2, 3, 32, 64
+    vid = torch.rand(B, T, 3, H, H, generator=g)
+    w, b = torch.randn(C0, 3, 3, 3, generator=g) / 27 ** 0.5, torch.randn(C0, generator=g)
+    ref = F.conv2d(vid[:, t0:t0 + per].reshape(-1, 3, H, H).double(), w.double(), b.double(), padding=1)
+    Y = torch.full((B * per, H, H, C0), float("nan"), device=DEV, dtype=tdt(dt))
+    assert l.ivg_op_conv_in(P(vid.to(DEV)), 0, P(w.to(DEV)), P(b.to(DEV)), P(Y), code(dt), B * per, per, T, t0, H, H, C0, stream()) == 0
+    torch.cuda.synchronize()
+    assert rel_err(Y.float().permute(0, 3, 1, 2), ref) < (1e-5 if dt == "fp32" else 1e-2)
