@@ -191,6 +191,29 @@ void Run::prof_end(DType dt) {
 
 #define API_CK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { e->err = std::string(#x) + ": " + hipGetErrorString(_e); return IVG_ERR_HIP; } } while (0)
 
+// Every entry point first walks its own allocation plan (host arithmetic only) and grows the arena if this call
+// needs more than any earlier one; then runs for real.  f(Run&) must be the same call in both passes.
+template <typename F>
+static int plan_then_run(ivg_engine* e, hipStream_t st, F&& f) {
+  e->ws.planning = true; e->ws.off = 0; e->ws.high = 0; e->ws.overflow = false;
+  Run p{e, nullptr, true};
+  int rc = f(p);
+  const size_t need = e->ws.high + (1 << 20);
+  e->ws.planning = false; e->ws.off = 0;
+  if (rc) return rc;
+  if (need > e->ws.cap) {
+    API_CK(hipDeviceSynchronize());
+    if (e->ws.base) API_CK(hipFree(e->ws.base));
+    e->ws.base = nullptr; e->ws.cap = 0;
+    API_CK(hipMalloc((void**)&e->ws.base, need));
+    e->ws.cap = need;
+  }
+  Run r{e, st, false};
+  rc = f(r);
+  if (rc == 0 && e->ws.overflow) return e->fail(IVG_ERR_CAPACITY, "internal: workspace plan was smaller than the run");
+  return rc;
+}
+
 static int plan_and_allocate(ivg_engine* e) {
   const ivg_config& c = e->cfg;
   e->ws.planning = true; e->ws.off = 0; e->ws.high = 0;
@@ -208,7 +231,7 @@ static int plan_and_allocate(ivg_engine* e) {
     e->ctx = saved;
   }
   if (c.num_layers > 0) {
-    const int Lpre = std::min(e->Lmax, 257 * std::max(1, c.context_length));
+    const int Lpre = std::min(e->Lmax - 1, 514);  // typical prompt (2 context frames); larger calls grow the arena on demand
     int rc = r.generate(nullptr, 0, B, Lpre, 1, nullptr, 0, 1, nullptr, 0, nullptr, nullptr); if (rc) return rc;
   }
   e->ws.cap = e->ws.high + (1 << 20);
@@ -304,27 +327,23 @@ int ivg_tokenize(ivg_engine* e, const void* pixels, int pixel_dtype, int B, int 
   if (!e) return IVG_ERR_INVALID;
   IVG_TRY(check_tok(e, B, T, "tokenize"));
   if (T < e->ctx + 1) return e->fail(IVG_ERR_INVALID, "tokenize: needs at least one future frame (T >= context_length + 1)");
-  Run r{e, (hipStream_t)stream, false};
-  e->ws.off = 0;
-  return r.tokenize(pixels, (DType)pixel_dtype, B, T, ids_out, 257L * e->ctx - 1 + 17L * (T - e->ctx), labels_out, false);
+  return plan_then_run(e, (hipStream_t)stream, [&](Run& r) {
+    return r.tokenize(pixels, (DType)pixel_dtype, B, T, ids_out, 257L * e->ctx - 1 + 17L * (T - e->ctx), labels_out, false); });
 }
 
 int ivg_encode_context(ivg_engine* e, const void* pixels, int pixel_dtype, int B, int T, int64_t* ids_out, int64_t ids_stride, ivg_stream stream) {
   if (!e) return IVG_ERR_INVALID;
   IVG_TRY(check_tok(e, B, std::min(T, e->cfg.max_frames), "encode_context"));
   if (T < e->ctx || ids_stride < 257L * e->ctx) return e->fail(IVG_ERR_INVALID, "encode_context: T < context_length or ids_stride < 257*ctx");
-  Run r{e, (hipStream_t)stream, false};
-  e->ws.off = 0;
-  return r.tokenize(pixels, (DType)pixel_dtype, B, T, ids_out, ids_stride, nullptr, true);
+  return plan_then_run(e, (hipStream_t)stream, [&](Run& r) {
+    return r.tokenize(pixels, (DType)pixel_dtype, B, T, ids_out, ids_stride, nullptr, true); });
 }
 
 int ivg_detokenize(ivg_engine* e, const int64_t* ids, int B, int F, float* pixels_out, ivg_cache* cache, int cache_mode, ivg_stream stream) {
   if (!e) return IVG_ERR_INVALID;
   IVG_TRY(check_tok(e, B, e->ctx + F, "detokenize"));
   if (F < 0) return e->fail(IVG_ERR_INVALID, "detokenize: token count does not match 257*ctx - 1 + 17*F");
-  Run r{e, (hipStream_t)stream, false};
-  e->ws.off = 0;
-  return r.detokenize(ids, B, F, pixels_out, cache, cache ? cache_mode : 0);
+  return plan_then_run(e, (hipStream_t)stream, [&](Run& r) { return r.detokenize(ids, B, F, pixels_out, cache, cache ? cache_mode : 0); });
 }
 
 int ivg_cache_create(ivg_engine* e, int B, ivg_cache** out) {
@@ -360,36 +379,27 @@ int ivg_generate(ivg_engine* e, const int64_t* prompt, int64_t prompt_stride, in
     return e->fail(IVG_ERR_CAPACITY, "generate: sequence of " + std::to_string(L0 + n_new) + " tokens exceeds the KV cache (" + std::to_string(e->Lmax) + ")");
   if (actions && (e->cfg.action_dim <= 0 || !e->act_w)) return e->fail(IVG_ERR_INVALID, "generate: actions given but the model is action-free");
   if (actions && (act_T > e->cfg.max_frames || ((n_new + 1) / 17) + ctx - 1 > act_T)) return e->fail(IVG_ERR_INVALID, "generate: action tensor too short / longer than max_frames");
-  Run r{e, (hipStream_t)stream, false};
-  e->ws.off = 0;
-  return r.generate(prompt, prompt_stride, B, L0, n_new, actions, act_T, ctx, uniforms, top_k, ids_out, reward_out);
+  return plan_then_run(e, (hipStream_t)stream, [&](Run& r) {
+    return r.generate(prompt, prompt_stride, B, L0, n_new, actions, act_T, ctx, uniforms, top_k, ids_out, reward_out); });
 }
 
 int ivg_logits(ivg_engine* e, const int64_t* ids, int B, int L, const float* actions, int act_T, int ctx, float* logits_out, ivg_stream stream) {
   if (!e) return IVG_ERR_INVALID;
   if (e->cfg.num_layers <= 0) return e->fail(IVG_ERR_INVALID, "logits: engine was created without a transformer");
   if (B <= 0 || B > std::min(e->cfg.max_batch, 128) || L > e->Lmax) return e->fail(IVG_ERR_CAPACITY, "logits: batch or length exceeds capacity");
-  Run r{e, (hipStream_t)stream, false};
-  e->ws.off = 0;
-  // capacity check of the workspace for this (B, L): plan first
-  {
-    Run p{e, nullptr, true};
-    const size_t save_high = e->ws.high;
-    e->ws.planning = true; e->ws.high = 0; e->ws.off = 0;
-    p.prefill(nullptr, 0, B, L, nullptr, 0, ctx, true, (float*)1, nullptr, nullptr);
-    const size_t need = e->ws.high;
-    e->ws.planning = false; e->ws.high = save_high; e->ws.off = 0;
-    if (need > e->ws.cap) return e->fail(IVG_ERR_CAPACITY, "logits: workspace too small for this (B, L)");
-  }
-  const void* act_emb = nullptr;
-  if (actions) {
-    if (e->cfg.action_dim <= 0 || !e->act_w) return e->fail(IVG_ERR_INVALID, "logits: actions given but the model is action-free");
-    char* buf = (char*)e->ws.alloc((size_t)B * act_T * e->cfg.hidden_size * dtype_size(e->llm_dt));
-    int rc = launch_action_embed(actions, e->act_w, e->act_b, buf, e->llm_dt, B * act_T, e->cfg.action_dim, e->cfg.hidden_size, (hipStream_t)stream);
-    if (rc) return e->fail(IVG_ERR_HIP, "action_embed launch failed");
-    act_emb = buf;
-  }
-  return r.prefill(ids, L, B, L, act_emb, act_T, ctx, true, logits_out, nullptr, nullptr);
+  if (actions && (e->cfg.action_dim <= 0 || !e->act_w)) return e->fail(IVG_ERR_INVALID, "logits: actions given but the model is action-free");
+  return plan_then_run(e, (hipStream_t)stream, [&](Run& r) {
+    const void* act_emb = nullptr;
+    if (actions) {
+      char* buf = (char*)e->ws.alloc((size_t)B * act_T * e->cfg.hidden_size * dtype_size(e->llm_dt));
+      if (!r.planning) {
+        int rc = launch_action_embed(actions, e->act_w, e->act_b, buf, e->llm_dt, B * act_T, e->cfg.action_dim, e->cfg.hidden_size, r.st);
+        if (rc) return e->fail(IVG_ERR_HIP, "action_embed launch failed");
+      }
+      act_emb = buf;
+    }
+    return r.prefill(ids, L, B, L, act_emb, act_T, ctx, true, logits_out, nullptr, nullptr);
+  });
 }
 
 int ivg_profile_enable(ivg_engine* e, int k, int enable) {

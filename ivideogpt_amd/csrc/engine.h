@@ -13,11 +13,13 @@ struct Arena {
   char* base = nullptr;
   size_t cap = 0, off = 0, high = 0;
   bool planning = true;  // planning pass: no memory, only the high-water mark
+  bool overflow = false;
   void* alloc(size_t bytes) {
     off = (off + 255) & ~(size_t)255;
     void* p = planning ? (void*)(uintptr_t)(0x1000 + off) : (void*)(base + off);
     off += bytes;
     if (off > high) high = off;
+    if (!planning && off > cap) { overflow = true; return base; }  // never hand out memory past the arena (callers plan first)
     return p;
   }
   size_t mark() const { return off; }

@@ -262,6 +262,7 @@ int launch_igemm(const IgemmArgs& a, DType dtype, hipStream_t stream) {
   d.single_tap = (a.KH * a.KW == 1) ? 1 : 0;
   d.c_img = a.c_img; d.c_pix = a.c_pix; d.c_ch = a.c_ch; d.c_grp = a.c_grp > 0 ? a.c_grp : 1;
   d.c_grp_stride = a.c_grp_stride; d.flags = a.flags; d.alpha = a.alpha;
+  if (a.c_grp <= 1 && a.c_grp_stride == 0) d.c_grp_stride = a.c_img;  // no frame grouping given: image n starts at n * c_img
   d.nb1 = a.nb1; d.nb2 = a.nb2;
   for (int i = 0; i < 3; ++i) { d.sa[i] = a.sa[i]; d.sw[i] = a.sw[i]; d.sy[i] = a.sy[i]; }
   const int nbatch = a.nb0 * a.nb1 * a.nb2;

@@ -203,8 +203,8 @@ def test_groupnorm(dt, C_, P_, silu, pos):
     X = x.to(DEV, tdt(dt))
     Y = torch.full_like(X, float("nan"))
     ws = torch.empty(N * 64 * 32 * 2, dtype=torch.float64, device=DEV)
-    rc = l.ivg_op_groupnorm(P(X), P(Y), P(ws), P(gamma.to(DEV)), P(beta.to(DEV)), P(pe.to(DEV)) if pos else None, N, P_, C_, 32,
-                            1e-6, silu, code(dt), stream())
+    gd, bd, pd = gamma.to(DEV), beta.to(DEV), (pe.to(DEV) if pos else None)   # keep the device tensors alive across the call
+    rc = l.ivg_op_groupnorm(P(X), P(Y), P(ws), P(gd), P(bd), P(pd), N, P_, C_, 32, 1e-6, silu, code(dt), stream())
     assert rc == 0
     torch.cuda.synchronize()
     assert rel_err(Y.float(), ref) < (1e-5 if dt == "fp32" else 1e-2)
@@ -241,7 +241,8 @@ def test_vq_argmin_matches_cdist_argmin():
         ref = torch.argmin(torch.cdist(z, E), dim=1)
         out = torch.full((R,), -1, dtype=torch.int64, device=DEV)
         ee = torch.empty(n_e, device=DEV)
-        assert l.ivg_op_vq_argmin(P(z.to(DEV)), P(E.to(DEV)), P(ee), P(out), R, n_e, stream()) == 0
+        zd, Ed = z.to(DEV), E.to(DEV)
+        assert l.ivg_op_vq_argmin(P(zd), P(Ed), P(ee), P(out), R, n_e, stream()) == 0
         torch.cuda.synchronize()
         bad = (out.cpu() != ref).nonzero().flatten()
         if len(bad):  # audit: every mismatch must be an fp32 near-tie in the fp64 distances
@@ -255,7 +256,8 @@ def test_vq_argmin_matches_cdist_argmin():
     z = E[300:301].clone() + 1e-3
     out = torch.full((1,), -1, dtype=torch.int64, device=DEV)
     ee = torch.empty(512, device=DEV)
-    assert l.ivg_op_vq_argmin(P(z.to(DEV)), P(E.to(DEV)), P(ee), P(out), 1, 512, stream()) == 0
+    zd, Ed = z.to(DEV), E.to(DEV)
+    assert l.ivg_op_vq_argmin(P(zd), P(Ed), P(ee), P(out), 1, 512, stream()) == 0
     torch.cuda.synchronize()
     assert out.item() == 17
 
@@ -273,7 +275,8 @@ def test_add_rmsnorm(dt):
     ref = w.double() * nrm.double()
     X = x.to(DEV, tdt(dt))
     out = torch.full((M, H), float("nan"), device=DEV, dtype=tdt(dt))
-    assert l.ivg_op_add_rmsnorm(P(X), P(part.to(DEV)), S_, P(w.to(DEV)), P(out), M, H, 1e-6, code(dt), stream()) == 0
+    pd, wd = part.to(DEV), w.to(DEV)
+    assert l.ivg_op_add_rmsnorm(P(X), P(pd), S_, P(wd), P(out), M, H, 1e-6, code(dt), stream()) == 0
     torch.cuda.synchronize()
     assert rel_err(X.float(), xs) < (1e-6 if dt == "fp32" else 1e-2)
     assert rel_err(out.float(), ref) < (1e-5 if dt == "fp32" else 1.5e-2)
@@ -288,6 +291,7 @@ def test_conv_in_from_video(dt):
     w, b = torch.randn(C0, 3, 3, 3, generator=g) / 27 ** 0.5, torch.randn(C0, generator=g)
     ref = F.conv2d(vid[:, t0:t0 + per].reshape(-1, 3, H, H).double(), w.double(), b.double(), padding=1)
     Y = torch.full((B * per, H, H, C0), float("nan"), device=DEV, dtype=tdt(dt))
-    assert l.ivg_op_conv_in(P(vid.to(DEV)), 0, P(w.to(DEV)), P(b.to(DEV)), P(Y), code(dt), B * per, per, T, t0, H, H, C0, stream()) == 0
+    vd, wd, bd = vid.to(DEV), w.to(DEV), b.to(DEV)
+    assert l.ivg_op_conv_in(P(vd), 0, P(wd), P(bd), P(Y), code(dt), B * per, per, T, t0, H, H, C0, stream()) == 0
     torch.cuda.synchronize()
     assert rel_err(Y.float().permute(0, 3, 1, 2), ref) < (1e-5 if dt == "fp32" else 1e-2)
