@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+"""bench.py -- predicted frames / s of the iVideoGPT prediction hot path on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one pass of the hot path over one batch of synthetic clips already resident in HBM:
+    encode the context frames -> autoregressive rollout (17*F - 1 tokens) -> decode all T frames -> clamp(0, 1)
+(BASELINE.json configs[1]: ivideogpt-oxe-64-act-free shapes, synthetic 64x64 bf16 pixels, 64 trajectories per GPU,
+2 context + 14 predicted frames; seeded random weights of the real architecture -- no checkpoints exist offline).
+Multi-GPU: independent trajectories shard by batch rows (weak scaling: 64 per GPU), no data-path collective; the
+per-sample metric rows are all-gathered over RCCL once per step (the reference's accelerator.gather, train_gpt.py:476-479).
+
+Prints ONE JSON line on rank 0 (see the task contract): value = predicted frames / s over all GPUs, plus
+  "roofline"     : the dominant kernel (bf16 implicit-GEMM conv / GEMM), algorithmic FLOPs / HIP-event durations
+  "cpu_baseline" : the oracle's restatement of the reference algorithm timed on this box's host cores (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from ivideogpt_amd import CompressiveVQModel, LlamaForCausalLM, weights as W  # noqa: E402
+from ivideogpt_amd import _lib, parallel  # noqa: E402
+from ivideogpt_amd.pipeline import frame_metrics, predict_frames  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def build_models(device, res, medium, enc, dec, llm):
+    tcfg = W.tokenizer_config(**(W.CTX_VAE64 if res == 64 else dict(W.CTX_VAE256, resolution=256, max_att_resolution=32)))
+    lcfg = W.LLAMA_MEDIUM if medium else W.LLAMA_SMALL
+    tsd = W.random_tokenizer_state_dict(tcfg, seed=0, codebook_std=0.4)
+    lsd = W.random_llama_state_dict(lcfg, seed=0)
+    tok = CompressiveVQModel(tcfg, tsd, encode_dtype=enc, decode_dtype=dec).to(device)
+    model = LlamaForCausalLM(lcfg, lsd, dtype=llm).to(device)
+    return tcfg, lcfg, tsd, lsd, tok, model
+
+
+def cpu_baseline(tcfg, lcfg, tsd, lsd, ctx, T, sample_b, res):
+    """Reference algorithm on the host cores (oracle = CPU port of the reference's op sequence), bounded sample."""
+    from oracle.llama import LlamaRef
+    from oracle.pipeline import predict_reference_algorithm
+    from oracle.vq_tokenizer import CompressiveVQRef
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    tok = CompressiveVQRef(**tcfg).eval()
+    tok.load_state_dict(tsd, strict=True)
+    llm = LlamaRef(lsd, lcfg["num_hidden_layers"], lcfg["num_attention_heads"], lcfg["rms_norm_eps"], lcfg["rope_theta"],
+                   lcfg["max_position_embeddings"])
+    g = torch.Generator().manual_seed(123)
+    px = torch.rand(sample_b, T, 3, res, res, generator=g)
+    F = T - ctx
+    u = torch.rand(sample_b, 17 * F - 1, generator=g)
+    t0 = time.perf_counter()
+    frames, _ = predict_reference_algorithm(tok, llm, px, ctx, uniforms=u, top_k=100)
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(frames).all()
+    return {"value": sample_b * F / dt, "unit": "predicted frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{sample_b} trajectories x ({ctx} context + {F} predicted) frames {res}x{res}, fp32, full tokenize + top-k "
+                      f"sampling rollout + detokenize, one pass ({dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="trajectories per GPU")
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--res", type=int, default=64, choices=[64, 256])
+    ap.add_argument("--medium", action="store_true", help="436 M transformer (config_medium)")
+    ap.add_argument("--encode-dtype", default="fp32")
+    ap.add_argument("--decode-dtype", default="bf16")
+    ap.add_argument("--llm-dtype", default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2)
+    ap.add_argument("--greedy", action="store_true")
+    a = ap.parse_args()
+
+    rank, world, local = parallel.init_from_env("nccl")
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run for N > 1)"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    tcfg, lcfg, tsd, lsd, tok, model = build_models(dev, a.res, a.medium, a.encode_dtype, a.decode_dtype, a.llm_dtype)
+    ctx, B, T = tcfg["context_length"], a.batch, a.frames
+    F = T - ctx
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    pixels = torch.rand(B, T, 3, a.res, a.res, device=dev, generator=g).to(torch.bfloat16)   # resident in HBM before timing
+    sample_gen = torch.Generator(device=dev).manual_seed(2000 + rank)
+
+    def step():
+        frames = predict_frames(tok, model, pixels, ctx, F, do_sample=not a.greedy, top_k=100, generator=sample_gen)
+        rows = frame_metrics(frames[:, ctx:], pixels[:, ctx:])
+        return frames, parallel.gather_metric_rows_even(rows)
+
+    for _ in range(max(1, a.warmup)):   # also builds the engines / captures the decode-step graph
+        frames, rows = step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(frames).all() and rows.shape[0] == world * B
+
+    prof_engines = [tok._engine, model._engine]
+    kclass = _lib.IVG_K_IGEMM_BF16 if a.decode_dtype == "bf16" else _lib.IVG_K_IGEMM_F32
+    for e in prof_engines:
+        e.profile_read(kclass)
+        e.profile_enable(kclass, True)
+
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        frames, rows = step()
+    torch.cuda.synchronize()
+    parallel.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = parallel.max_over_ranks(elapsed, dev)
+
+    stats = [e.profile_read(kclass) for e in prof_engines]
+    for e in prof_engines:
+        e.profile_enable(kclass, False)
+    launches = sum(s["launches"] for s in stats)
+    k_ms = sum(s["total_ms"] for s in stats)
+    k_flops = sum(s["total_flops"] for s in stats)
+
+    # one extra, untimed pass for the per-stage split (events on the engine streams' parent stream)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    ev[0].record()
+    prompt = tok.encode_context(pixels, ctx)
+    ev[1].record()
+    toks = model.generate(prompt, do_sample=not a.greedy, top_k=100, max_new_tokens=17 * F - 1, generator=sample_gen)
+    ev[2].record()
+    tok.detokenize(toks, ctx).clamp_(0, 1)
+    ev[3].record()
+    torch.cuda.synchronize()
+    stage = {"encode_ms": ev[0].elapsed_time(ev[1]), "rollout_ms": ev[1].elapsed_time(ev[2]), "decode_ms": ev[2].elapsed_time(ev[3])}
+
+    if rank == 0:
+        units = world * B * F * a.steps
+        achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        out = {
+            "metric": "predicted frames/sec (encode+GPT rollout+decode), 64x64x16f" if a.res == 64 else
+                      "predicted frames/sec (encode+GPT rollout+decode), 256x256x16f",
+            "value": units / elapsed,
+            "unit": "predicted frames/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"ivideogpt-oxe-{a.res}-act-free{'-medium' if a.medium else ''}: synthetic {a.res}x{a.res} bf16 clips, "
+                                   f"{B} trajectories per GPU, {ctx} context + {F} predicted frames, top-k 100 sampling, seeded random weights",
+                       "global_batch": world * B, "frames": T, "resolution": a.res,
+                       "arith": {"encode": a.encode_dtype, "rollout": a.llm_dtype, "decode": a.decode_dtype},
+                       "parallelism": f"batch-shard x{world} (no data-path collective; 1 RCCL all-gather of [B,4] metric rows per step)"},
+            "roofline": {"bound": "mfma", "kernel": "ivg::igemm_kernel<bf16,128,128,64,64> (implicit-GEMM conv / GEMM)",
+                         "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
+                         "launches_per_step": launches / max(1, a.steps), "avg_launch_ms": k_ms / max(1, launches),
+                         "kernel_ms_per_step": k_ms / max(1, a.steps), "traffic": None},
+            "stage_ms": stage,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(tcfg, lcfg, tsd, lsd, ctx, T, a.cpu_sample, a.res)
+            out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    parallel.barrier()
+
+
+if __name__ == "__main__":
+    main()

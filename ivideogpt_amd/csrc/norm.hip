@@ -144,31 +144,47 @@ int launch_groupnorm(const void* X, void* Y, void* part_ws, const float* gamma, 
 }
 
 // ------------------------------------------------------------------------------------------------ RMSNorm
-// One wave per row.  x (T, updated in place when partials are given), out = rmsnorm(x) * w.
+// One workgroup per row (H <= 2048), every thread owns up to 8 strided elements so all loads of a pass are
+// independent (the decode step is latency-bound: M = batch rows only).  x (T) is updated in place when split-K
+// partials are given (fixed order s = 0..S-1), out = rmsnorm(x) * w.
 template <typename T>
 __global__ __launch_bounds__(256) void add_rmsnorm_kernel(T* __restrict__ x, long xs, const float* __restrict__ part, int splits,
                                                           const float* __restrict__ w, T* __restrict__ out, int M, int H,
                                                           float eps) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= M) return;
+  __shared__ float red[4];
+  const int row = blockIdx.x, tid = threadIdx.x;
   T* xr = x + (long)row * xs;
-  float ss = 0.f;
-  for (int c = lane; c < H; c += 64) {
-    float f = to_f32(xr[c]);
-    if (part) {
-      for (int s = 0; s < splits; ++s) f += part[((long)s * M + row) * H + c];
-      const T r = from_f32<T>(f);
-      xr[c] = r;
-      f = to_f32(r);
+  float f[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { const int c = tid + 256 * i; f[i] = c < H ? to_f32(xr[c]) : 0.f; }
+  if (part) {
+    for (int s = 0; s < splits; ++s) {
+      const float* pr = part + ((long)s * M + row) * H;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const int c = tid + 256 * i; if (c < H) f[i] += pr[c]; }
     }
-    ss = fmaf(f, f, ss);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = tid + 256 * i;
+      if (c < H) { const T r = from_f32<T>(f[i]); xr[c] = r; f[i] = to_f32(r); }
+    }
   }
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ss = fmaf(f[i], f[i], ss);
   ss = wave_sum(ss);
+  if ((tid & 63) == 0) red[tid >> 6] = ss;
+  __syncthreads();
+  ss = (red[0] + red[1]) + (red[2] + red[3]);
   const float inv = rsqrtf(ss / (float)H + eps);
   if (out) {
-    for (int c = lane; c < H; c += 64) {  // re-read own writes (same thread): no hazard
-      const float nrm = to_f32(from_f32<T>(to_f32(xr[c]) * inv));  // HF casts back to the input dtype before * weight
-      out[(long)row * H + c] = from_f32<T>(w[c] * nrm);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = tid + 256 * i;
+      if (c < H) {
+        const float nrm = to_f32(from_f32<T>(f[i] * inv));  // HF casts back to the input dtype before * weight
+        out[(long)row * H + c] = from_f32<T>(w[c] * nrm);
+      }
     }
   }
 }
@@ -176,7 +192,8 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(T* __restrict__ x, lon
 int launch_add_rmsnorm(void* x, long x_stride, const float* part, int splits, const float* w, void* out, int M, int H, float eps,
                        DType dt, hipStream_t st) {
   if (H > 2048) return (int)hipErrorInvalidValue;
-  dim3 g(cdiv(M, 4));
+  if (M <= 0) return 0;
+  dim3 g(M);
   if (dt == BF16)
     hipLaunchKernelGGL(add_rmsnorm_kernel<bf16_t>, g, dim3(256), 0, st, (bf16_t*)x, x_stride, part, splits, w, (bf16_t*)out, M, H, eps);
   else

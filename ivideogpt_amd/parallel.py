@@ -1,0 +1,75 @@
+"""Multi-GPU plumbing for the prediction path: independent trajectories shard by contiguous batch rows,
+weights are replicated, and the ONLY collective is one all-gather of the per-sample metric rows per batch
+(mirrors ``accelerator.gather`` of mse/psnr/ssim/lpips at /root/reference/train_gpt.py:476-479).
+One process per GPU; ``torch.distributed`` backend "nccl" is RCCL on ROCm (xGMI), "gloo" in the CPU tests."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """-> (rank, world_size, local_rank).  Initialises the default process group when WORLD_SIZE > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_rows(n_rows, rank, world):
+    """Contiguous row range [lo, hi) of rank `rank` (sizes differ by at most one)."""
+    base, rem = divmod(n_rows, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_metric_rows(local_rows, total_rows=None):
+    """All-gather per-sample metric rows [B_local, n_metrics] -> [B_total, n_metrics] in rank order on every rank.
+    Ranks may hold different row counts (uneven shard): rows are padded to the max and trimmed after the gather."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local_rows
+    world = dist.get_world_size()
+    n = torch.tensor([local_rows.shape[0]], device=local_rows.device, dtype=torch.int64)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    mx = max(counts)
+    pad = local_rows
+    if local_rows.shape[0] < mx:
+        pad = torch.cat([local_rows, local_rows.new_zeros(mx - local_rows.shape[0], *local_rows.shape[1:])], 0)
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad.contiguous())
+    rows = torch.cat([o[:c] for o, c in zip(out, counts)], 0)
+    if total_rows is not None:
+        assert rows.shape[0] == total_rows
+    return rows
+
+
+def gather_metric_rows_even(local_rows):
+    """Fast path when every rank holds the same number of rows: one ncclAllGather of [B_local, n_metrics]."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local_rows
+    out = local_rows.new_empty(dist.get_world_size() * local_rows.shape[0], *local_rows.shape[1:])
+    dist.all_gather_into_tensor(out, local_rows.contiguous())
+    return out
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value, device):
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
