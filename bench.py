@@ -45,28 +45,56 @@ def build_models(device, res, medium, enc, dec, llm):
     return tcfg, lcfg, tsd, lsd, tok, model
 
 
-def cpu_baseline(tcfg, lcfg, tsd, lsd, ctx, T, sample_b, res):
-    """Reference algorithm on the host cores (oracle = CPU port of the reference's op sequence), bounded sample."""
+def _cpu_threads():
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return avail
+
+
+def cpu_baseline_worker(res, medium, ctx, T, sample_b, threads):
+    """Runs in a subprocess: reference algorithm on the host cores (oracle = CPU port of the reference's op sequence)."""
     from oracle.llama import LlamaRef
     from oracle.pipeline import predict_reference_algorithm
     from oracle.vq_tokenizer import CompressiveVQRef
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    torch.set_num_threads(threads)
+    tcfg = W.tokenizer_config(**(W.CTX_VAE64 if res == 64 else dict(W.CTX_VAE256, resolution=256, max_att_resolution=32)))
+    lcfg = W.LLAMA_MEDIUM if medium else W.LLAMA_SMALL
     tok = CompressiveVQRef(**tcfg).eval()
-    tok.load_state_dict(tsd, strict=True)
+    tok.load_state_dict(W.random_tokenizer_state_dict(tcfg, seed=0, codebook_std=0.4), strict=True)
+    lsd = W.random_llama_state_dict(lcfg, seed=0)
     llm = LlamaRef(lsd, lcfg["num_hidden_layers"], lcfg["num_attention_heads"], lcfg["rms_norm_eps"], lcfg["rope_theta"],
                    lcfg["max_position_embeddings"])
     g = torch.Generator().manual_seed(123)
-    px = torch.rand(sample_b, T, 3, res, res, generator=g)
     F = T - ctx
+    px = torch.rand(sample_b, T, 3, res, res, generator=g)
     u = torch.rand(sample_b, 17 * F - 1, generator=g)
     t0 = time.perf_counter()
     frames, _ = predict_reference_algorithm(tok, llm, px, ctx, uniforms=u, top_k=100)
     dt = time.perf_counter() - t0
     assert torch.isfinite(frames).all()
-    return {"value": sample_b * F / dt, "unit": "predicted frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{sample_b} trajectories x ({ctx} context + {F} predicted) frames {res}x{res}, fp32, full tokenize + top-k "
-                      f"sampling rollout + detokenize, one pass ({dt:.1f} s)"}
+    print(json.dumps({"value": sample_b * F / dt, "unit": "predicted frames/s", "cores": threads, "kind": "port",
+                      "sample": f"{sample_b} trajectories x ({ctx} context + {F} predicted) frames {res}x{res}, fp32, whole-clip tokenize + "
+                                f"top-k 100 sampling rollout + detokenize, one pass of {dt:.1f} s on {threads} threads"}), flush=True)
+
+
+def cpu_baseline(res, medium, ctx, T, sample_b, threads, budget_s=150):
+    """Bounded: the worker runs in a subprocess under a wall-clock limit so the bench line always prints."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--res", str(res), "--frames", str(T),
+           "--cpu-sample", str(sample_b), "--cpu-threads", str(threads)] + (["--medium"] if medium else [])
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    try:
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=budget_s)
+        for line in reversed(out.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"value": None, "unit": "predicted frames/s", "cores": threads, "kind": "port",
+                "sample": "worker failed: " + (out.stderr.strip().splitlines() or ["?"])[-1][:200]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "predicted frames/s", "cores": threads, "kind": "port",
+                "sample": f"{sample_b} trajectories did not finish within the {budget_s} s budget"}
 
 
 def main():
@@ -83,8 +111,14 @@ def main():
     ap.add_argument("--llm-dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the CPU baseline (0: min(32, available cores))")
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--greedy", action="store_true")
     a = ap.parse_args()
+
+    if a.cpu_baseline_worker:
+        ctx = (W.CTX_VAE64 if a.res == 64 else W.CTX_VAE256)["context_length"]
+        return cpu_baseline_worker(a.res, a.medium, ctx, a.frames, a.cpu_sample, a.cpu_threads)
 
     rank, world, local = parallel.init_from_env("nccl")
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run for N > 1)"
@@ -168,8 +202,10 @@ def main():
             "stage_ms": stage,
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(tcfg, lcfg, tsd, lsd, ctx, T, a.cpu_sample, a.res)
-            out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            threads = a.cpu_threads or min(32, _cpu_threads())
+            out["cpu_baseline"] = cpu_baseline(a.res, a.medium, ctx, T, a.cpu_sample, threads)
+            if out["cpu_baseline"]["value"]:
+                out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     parallel.barrier()
 

@@ -84,51 +84,101 @@ int launch_rope_kv(void* qkv, void* kc, void* vc, void* vt, int ldvt, const floa
 }
 
 // ------------------------------------------------------------------------------------------------ decode attention
-// One workgroup per (b, head).  HBM-bound stream of the K and V rows of the cache (coalesced: LPK lanes
-// share one row, 16 bytes each).  Two passes over LDS-held scores -> deterministic reduction order.
-template <typename T>
-__global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ qkv, const T* __restrict__ kc,
-                                                          const T* __restrict__ vc, T* __restrict__ out, int heads, int hd,
-                                                          int Lmax, const StepState* __restrict__ state) {
+// One workgroup per (b, head): RoPE of the new q/k, KV-cache append and single-token attention in one launch.
+// HBM-bound stream of the K and V rows of the cache (coalesced: LPK lanes share one row, 16 bytes each, four
+// independent row loads in flight per lane).  Two passes over LDS-held scores -> deterministic reduction order.
+template <typename T> __device__ __forceinline__ float dot_chunk(const float* qf, Chunk16 raw) {
   constexpr int VEC = Traits<T>::VEC;
+  float d = 0.f;
+  if constexpr (sizeof(T) == 2) {
+    const bf16x8 kk = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) d = fmaf(qf[j], (float)kk[j], d);
+  } else {
+    const f32x4 kk = __builtin_bit_cast(f32x4, raw);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) d = fmaf(qf[j], kk[j], d);
+  }
+  return d;
+}
+template <typename T> __device__ __forceinline__ void axpy_chunk(float* of, float pw, Chunk16 raw) {
+  constexpr int VEC = Traits<T>::VEC;
+  if constexpr (sizeof(T) == 2) {
+    const bf16x8 vv = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) of[j] = fmaf(pw, (float)vv[j], of[j]);
+  } else {
+    const f32x4 vv = __builtin_bit_cast(f32x4, raw);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) of[j] = fmaf(pw, vv[j], of[j]);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
+                                                          T* __restrict__ out, const float* __restrict__ cosT,
+                                                          const float* __restrict__ sinT, int heads, int hd, int Lmax,
+                                                          const StepState* __restrict__ state) {
+  constexpr int VEC = Traits<T>::VEC;
+  constexpr int UNR = 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lpk = hd / VEC;          // lanes per key row (8 for bf16 hd=64, 16 for fp32)
   const int gpb = 256 / lpk;         // key groups per workgroup
-  float* sc = (float*)smem;          // [Lmax] scores
+  float* sq = (float*)smem;          // [hd] roped q   | [hd] roped new k | [hd] new v  (values already rounded to T)
+  float* sk = sq + hd;
+  float* sv = sk + hd;
+  float* sc = sv + hd;               // [Lmax] scores
   float* red = sc + Lmax;            // [gpb][hd] partial outputs
   __shared__ float sred[8];
   const int b = blockIdx.x / heads, h = blockIdx.x % heads;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int sub = tid % lpk, grp = tid / lpk;
-  const int n_keys = state->pos + 1;  // keys 0..pos (the current token was appended by rope_kv)
-  const int H = heads * hd;
+  const int pos = state->pos;        // position of the token being fed = number of cached keys
+  const int n_keys = pos + 1;
+  const int H = heads * hd, half = hd / 2;
   const float scale = rsqrtf((float)hd);
-  float qf[VEC];
-  {
-    const T* q = qkv + (long)b * 3 * H + h * hd + sub * VEC;
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) qf[j] = to_f32(q[j]);
+  T* kb = kc + ((long)b * heads + h) * Lmax * hd;
+  T* vb = vc + ((long)b * heads + h) * Lmax * hd;
+  if (tid < half) {  // RoPE (HF rotate_half) of q and the new k; append k, v to the cache
+    const T* row = qkv + (long)b * 3 * H + h * hd;
+    const float c = cosT[(long)pos * half + tid], s = sinT[(long)pos * half + tid];
+    const float q1 = to_f32(row[tid]), q2 = to_f32(row[tid + half]);
+    const float k1 = to_f32(row[H + tid]), k2 = to_f32(row[H + tid + half]);
+    const T qa = from_f32<T>(q1 * c - q2 * s), qb = from_f32<T>(q2 * c + q1 * s);
+    const T ka = from_f32<T>(k1 * c - k2 * s), kb2 = from_f32<T>(k2 * c + k1 * s);
+    const T va = row[2 * H + tid], vb2 = row[2 * H + tid + half];
+    sq[tid] = to_f32(qa); sq[tid + half] = to_f32(qb);
+    sk[tid] = to_f32(ka); sk[tid + half] = to_f32(kb2);
+    sv[tid] = to_f32(va); sv[tid + half] = to_f32(vb2);
+    kb[(long)pos * hd + tid] = ka; kb[(long)pos * hd + tid + half] = kb2;
+    vb[(long)pos * hd + tid] = va; vb[(long)pos * hd + tid + half] = vb2;
   }
-  const T* kb = kc + ((long)b * heads + h) * Lmax * hd;
-  const T* vb = vc + ((long)b * heads + h) * Lmax * hd;
-  // pass A: scores
-  for (int t0 = 0; t0 < n_keys; t0 += gpb) {
-    const int t = t0 + grp;
-    float d = 0.f;
-    if (t < n_keys) {
-      const Chunk16 raw = *(const Chunk16*)(kb + (long)t * hd + sub * VEC);
-      if constexpr (sizeof(T) == 2) {
-        const bf16x8 kk = __builtin_bit_cast(bf16x8, raw);
+  __syncthreads();
+  float qf[VEC];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) d = fmaf(qf[j], (float)kk[j], d);
-      } else {
-        const f32x4 kk = __builtin_bit_cast(f32x4, raw);
+  for (int j = 0; j < VEC; ++j) qf[j] = sq[sub * VEC + j];
+  // pass A: scores of the cached keys (the new key comes from LDS)
+  for (int t0 = 0; t0 < pos; t0 += gpb * UNR) {
+    Chunk16 raw[UNR];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) d = fmaf(qf[j], kk[j], d);
-      }
+    for (int u = 0; u < UNR; ++u) {
+      const int t = t0 + u * gpb + grp;
+      raw[u] = t < pos ? *(const Chunk16*)(kb + (long)t * hd + sub * VEC) : Chunk16{0u, 0u, 0u, 0u};
     }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int t = t0 + u * gpb + grp;
+      float d = dot_chunk<T>(qf, raw[u]);
+      for (int o = 1; o < lpk; o <<= 1) d += __shfl_xor(d, o, 64);
+      if (t < pos && sub == 0) sc[t] = d * scale;
+    }
+  }
+  if (grp == 0) {
+    float d = 0.f;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) d = fmaf(qf[j], sk[sub * VEC + j], d);
     for (int o = 1; o < lpk; o <<= 1) d += __shfl_xor(d, o, 64);
-    if (t < n_keys && sub == 0) sc[t] = d * scale;
+    if (sub == 0) sc[pos] = d * scale;
   }
   __syncthreads();
   // pass B: softmax statistics
@@ -144,22 +194,27 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   if (lane == 0) sred[4 + wv] = sum;
   __syncthreads();
   sum = (sred[4] + sred[5]) + (sred[6] + sred[7]);
-  // pass C: weighted V sum; group `grp` takes keys grp, grp+gpb, ...
+  // pass C: weighted V sum; group `grp` takes keys grp, grp+gpb, ... (fixed order), the new token's v from LDS
   float of[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) of[j] = 0.f;
-  for (int t = grp; t < n_keys; t += gpb) {
-    const float pw = sc[t];
-    const Chunk16 raw = *(const Chunk16*)(vb + (long)t * hd + sub * VEC);
-    if constexpr (sizeof(T) == 2) {
-      const bf16x8 vv = __builtin_bit_cast(bf16x8, raw);
+  for (int t0 = 0; t0 < pos; t0 += gpb * UNR) {
+    Chunk16 raw[UNR];
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) of[j] = fmaf(pw, (float)vv[j], of[j]);
-    } else {
-      const f32x4 vv = __builtin_bit_cast(f32x4, raw);
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) of[j] = fmaf(pw, vv[j], of[j]);
+    for (int u = 0; u < UNR; ++u) {
+      const int t = t0 + u * gpb + grp;
+      raw[u] = t < pos ? *(const Chunk16*)(vb + (long)t * hd + sub * VEC) : Chunk16{0u, 0u, 0u, 0u};
     }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int t = t0 + u * gpb + grp;
+      if (t < pos) axpy_chunk<T>(of, sc[t], raw[u]);
+    }
+  }
+  if (grp == 0) {
+    const float pw = sc[pos];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) of[j] = fmaf(pw, sv[sub * VEC + j], of[j]);
   }
 #pragma unroll
   for (int j = 0; j < VEC; ++j) red[grp * hd + sub * VEC + j] = of[j];
@@ -171,19 +226,19 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   }
 }
 
-int launch_decode_attn(const void* qkv, const void* kc, const void* vc, void* out, int B, int heads, int hd, int Lmax,
-                       const StepState* state, DType dt, hipStream_t st) {
+int launch_decode_attn(const void* qkv, void* kc, void* vc, void* out, const float* cosT, const float* sinT, int B, int heads, int hd,
+                       int Lmax, const StepState* state, DType dt, hipStream_t st) {
   const int vec = dt == BF16 ? 8 : 4;
-  if (hd % vec != 0 || hd > 256 || 256 % (hd / vec) != 0) return (int)hipErrorInvalidValue;
+  if (hd % vec != 0 || hd > 256 || 256 % (hd / vec) != 0 || (hd & 1)) return (int)hipErrorInvalidValue;
   const int gpb = 256 / (hd / vec);
-  const size_t smem = (size_t)(Lmax + gpb * hd) * sizeof(float);
+  const size_t smem = (size_t)(3 * hd + Lmax + gpb * hd) * sizeof(float);
   dim3 g(B * heads);
   if (dt == BF16)
-    hipLaunchKernelGGL(decode_attn_kernel<bf16_t>, g, dim3(256), smem, st, (const bf16_t*)qkv, (const bf16_t*)kc, (const bf16_t*)vc,
-                       (bf16_t*)out, heads, hd, Lmax, state);
+    hipLaunchKernelGGL(decode_attn_kernel<bf16_t>, g, dim3(256), smem, st, (const bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc, (bf16_t*)out,
+                       cosT, sinT, heads, hd, Lmax, state);
   else
-    hipLaunchKernelGGL(decode_attn_kernel<float>, g, dim3(256), smem, st, (const float*)qkv, (const float*)kc, (const float*)vc,
-                       (float*)out, heads, hd, Lmax, state);
+    hipLaunchKernelGGL(decode_attn_kernel<float>, g, dim3(256), smem, st, (const float*)qkv, (float*)kc, (float*)vc, (float*)out, cosT,
+                       sinT, heads, hd, Lmax, state);
   return (int)hipGetLastError();
 }
 
@@ -197,16 +252,16 @@ __device__ __forceinline__ unsigned f2key(float f) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotone: larger float -> larger key
 }
 
+constexpr int SAMPLE_KPT = 72;  // logits per thread (contiguous segment): vocab <= 256 * 72 = 18432
+
 template <typename T>
 __global__ __launch_bounds__(256) void sample_embed_kernel(SampleArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* lg = (float*)smem;  // [V]
-  __shared__ int hist[256];
-  __shared__ unsigned s_prefix;
-  __shared__ int s_k;
-  __shared__ float s_f[8];
-  __shared__ int s_i[8];
-  __shared__ double s_d[256];
+  float* lg = (float*)smem;  // [V] staging: coalesced global read, then each thread takes a contiguous segment
+  __shared__ float s_f[4];
+  __shared__ int s_i[4];
+  __shared__ int s_cnt[2][4];
+  __shared__ double s_w[4];
   __shared__ long s_tok;
   __shared__ double s_target;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -218,16 +273,22 @@ __global__ __launch_bounds__(256) void sample_embed_kernel(SampleArgs a) {
     tok = a.forced_token;
   } else {
     const float* src = a.logits + (long)b * V;
+    for (int i = tid; i < V; i += 256) lg[i] = src[i];
+    if (tid == 0) s_tok = -1;
+    __syncthreads();
+    const int seg = (V + 255) / 256;
+    const int i0 = tid * seg;
+    float v[SAMPLE_KPT];
     float mx = -INFINITY;
     int mi = 0x7fffffff;
-    for (int i = tid; i < V; i += 256) {
-      const float v = src[i];
-      lg[i] = v;
-      if (v > mx) { mx = v; mi = i; }  // ascending i per thread: first max kept
-    }
-    // (max, lowest index) reduction
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int q = 0; q < SAMPLE_KPT; ++q) {
+      const int i = i0 + q;
+      v[q] = (q < seg && i < V) ? lg[i] : -INFINITY;
+      if (v[q] > mx) { mx = v[q]; mi = i; }  // ascending index: the first maximum is kept
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {  // (max, lowest index) reduction
       const float ov = __shfl_xor(mx, o, 64);
       const int oi = __shfl_xor(mi, o, 64);
       if (ov > mx || (ov == mx && oi < mi)) { mx = ov; mi = oi; }
@@ -240,92 +301,88 @@ __global__ __launch_bounds__(256) void sample_embed_kernel(SampleArgs a) {
     if (a.uniforms == nullptr) {
       tok = mi;
     } else {
-      // ---- k-th largest key by 4-pass radix select (8 bits per pass, from the top)
-      if (tid == 0) { s_prefix = 0u; s_k = a.top_k < V ? a.top_k : V; }
-      for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        hist[tid] = 0;
+      // ---- key of the k-th largest logit: bitwise binary search (largest T with #{key >= T} >= k)
+      unsigned key[SAMPLE_KPT];
+#pragma unroll
+      for (int q = 0; q < SAMPLE_KPT; ++q) key[q] = f2key(v[q]);
+      const int k = a.top_k < V ? a.top_k : V;
+      unsigned prefix = 0u;
+      for (int bit = 31; bit >= 0; --bit) {
+        const unsigned cand = prefix | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int q = 0; q < SAMPLE_KPT; ++q) cnt += (key[q] >= cand) ? 1 : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+        if (lane == 0) s_cnt[bit & 1][wv] = cnt;
         __syncthreads();
-        const unsigned prefix = s_prefix;
-        const unsigned mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
-        for (int i = tid; i < V; i += 256) {
-          const unsigned key = f2key(lg[i]);
-          if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
-        }
-        __syncthreads();
-        if (tid == 0) {
-          int k = s_k, d = 255;
-          for (; d > 0; --d) { if (hist[d] >= k) break; k -= hist[d]; }
-          s_prefix = prefix | ((unsigned)d << shift);
-          s_k = k;
-        }
-        __syncthreads();
+        const int total = s_cnt[bit & 1][0] + s_cnt[bit & 1][1] + s_cnt[bit & 1][2] + s_cnt[bit & 1][3];
+        if (total >= k) prefix = cand;
       }
-      const unsigned thr = s_prefix;  // key of the k-th largest logit; everything >= thr is kept (ties included)
-      // ---- inverse CDF in ascending id order, fp64 accumulation (matches the oracle's double cumsum)
-      const int seg = (V + 255) / 256;
-      const int i0 = tid * seg, i1 = min(V, i0 + seg);
+      const unsigned thr = prefix;  // everything >= thr is kept (ties at the threshold included, as HF's masked_fill)
+      // ---- inverse CDF in ascending id order, fp64 (oracle: double cumsum of exp(logit - max) over the kept ids)
       double part = 0.0;
-      for (int i = i0; i < i1; ++i)
-        if (f2key(lg[i]) >= thr) part += exp((double)(lg[i] - mx));
-      s_d[tid] = part;
-      __syncthreads();
-      if (tid == 0) {  // serial exclusive scan over 256 partials (fixed order)
-        double run = 0.0;
-        for (int t = 0; t < 256; ++t) { const double p = s_d[t]; s_d[t] = run; run += p; }
-        s_d[0] = 0.0;
-        // total kept mass and target
-        const double target = (double)a.uniforms[(long)b * a.n_uni + (j - 1)] * run;
-        s_tok = -1;
-        s_target = target;
+#pragma unroll
+      for (int q = 0; q < SAMPLE_KPT; ++q)
+        if (key[q] >= thr && v[q] > -INFINITY) part += exp((double)(v[q] - mx));
+      double incl = part;  // inclusive scan over threads (thread order == id order)
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const double up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
       }
+      if (lane == 63) s_w[wv] = incl;
+      __syncthreads();
+      double base = 0.0, total = 0.0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { if (w < wv) base += s_w[w]; total += s_w[w]; }
+      incl += base;
+      double excl = __shfl_up(incl, 1, 64);
+      if (lane == 0) excl = base;
+      if (tid == 0) s_target = (double)a.uniforms[(long)b * a.n_uni + (j - 1)] * total;
       __syncthreads();
       const double target = s_target;
-      // my segment contains the crossing iff excl <= target < excl + part  (cdf > target first happens inside)
-      const double excl = s_d[tid];
-      if (part > 0.0 && excl <= target && target < excl + part) {
+      // intervals [excl, incl) tile [0, total) exactly (incl of thread t IS excl of thread t+1)
+      if (part > 0.0 && excl <= target && target < incl) {
         double run = excl;
-        long found = -1;
-        for (int i = i0; i < i1; ++i) {
-          if (f2key(lg[i]) >= thr) {
-            run += exp((double)(lg[i] - mx));
-            if (run > target) { found = i; break; }
+        long found = -1, last = -1;
+#pragma unroll
+        for (int q = 0; q < SAMPLE_KPT; ++q) {
+          if (key[q] >= thr && v[q] > -INFINITY) {
+            run += exp((double)(v[q] - mx));
+            last = i0 + q;
+            if (found < 0 && run > target) found = i0 + q;
           }
         }
-        if (found < 0) {  // rounding at the segment edge: take the segment's last kept token
-          for (int i = i1 - 1; i >= i0; --i) if (f2key(lg[i]) >= thr) { found = i; break; }
-        }
-        s_tok = found;
+        s_tok = found >= 0 ? found : last;  // rounding at the segment edge: the segment's last kept token
       }
       __syncthreads();
       tok = s_tok;
-      if (tok < 0) tok = mi;  // unreachable for u in [0,1): defensive
+      if (tok < 0) tok = mi;  // unreachable for u in [0, 1): defensive
     }
   }
   if (tid == 0) a.ids_out[(long)b * a.ids_stride + a.L0 + (j - 1)] = (int64_t)tok;
   // ---- next input embedding
-  constexpr int VEC = Traits<T>::VEC;
   const T* src = (const T*)a.E + tok * a.H;
   T* dst = (T*)a.x + (long)b * a.H;
   const T* act = nullptr;
   if (forced && a.act) act = (const T*)a.act + ((long)b * a.act_T + (j / a.forced_period + a.ctx - 1)) * a.H;
   for (int c = tid; c < a.H; c += 256) {
-    float v = to_f32(src[c]);
-    if (act) v = to_f32(from_f32<T>(v + to_f32(act[c])));
-    dst[c] = from_f32<T>(v);
+    float val = to_f32(src[c]);
+    if (act) val += to_f32(act[c]);
+    dst[c] = from_f32<T>(val);
   }
-  (void)VEC;
 }
 
 int launch_sample_embed(const SampleArgs& a, int B, DType dt, hipStream_t st) {
   const size_t smem = (size_t)a.V * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)sample_embed_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    hipFuncSetAttribute((const void*)sample_embed_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void*)sample_embed_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void*)sample_embed_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     attr_set = true;
   }
-  if (smem > 96 * 1024) return (int)hipErrorInvalidValue;
+  if (a.V > 256 * SAMPLE_KPT || smem > 96 * 1024) return (int)hipErrorInvalidValue;
   if (dt == BF16) hipLaunchKernelGGL(sample_embed_kernel<bf16_t>, dim3(B), dim3(256), smem, st, a);
   else hipLaunchKernelGGL(sample_embed_kernel<float>, dim3(B), dim3(256), smem, st, a);
   return (int)hipGetLastError();

@@ -54,9 +54,10 @@ int launch_embed(const int64_t* ids, long id_stride, const void* E, void* x, DTy
 // (pos0 from *state when state != null).  vt (optional): transposed V scratch [B][heads][hd][ldvt] for the prefill P.V GEMM.
 int launch_rope_kv(void* qkv, void* kc, void* vc, void* vt, int ldvt, const float* cosT, const float* sinT, int B, int L,
                    int heads, int hd, int Lmax, const StepState* state, int pos0, DType dt, hipStream_t st);
-// single-token attention against the cache: out[b][h*hd..] = softmax(q.K^T / sqrt(hd)) V over positions [0, *pos]
-int launch_decode_attn(const void* qkv, const void* kc, const void* vc, void* out, int B, int heads, int hd, int Lmax,
-                       const StepState* state, DType dt, hipStream_t st);
+// single-token step: RoPE of q / new k at position *pos, append k, v to the cache, then
+// out[b][h*hd..] = softmax(q.K^T / sqrt(hd)) V over positions [0, *pos]
+int launch_decode_attn(const void* qkv, void* kc, void* vc, void* out, const float* cosT, const float* sinT, int B, int heads, int hd,
+                       int Lmax, const StepState* state, DType dt, hipStream_t st);
 // token decision + embedding of the decided token (+ action embedding on forced sdf slots) + state advance
 struct SampleArgs {
   const float* logits; int V;            // [B][V] fp32 (row stride V)

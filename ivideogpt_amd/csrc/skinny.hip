@@ -55,25 +55,35 @@ __global__ __launch_bounds__(256) void skinny_kernel(const SkinnyDev p) {
     xoff[b] = (long)(xok[b] ? m : 0) * p.ldx + lg * VEC;
   }
 
-  for (int k = kbeg; k < kend; k += KSTEP) {
-    Chunk16 wv[FN], xv[MF];
+  // bursts of S K-steps: every load of a burst is issued before the first MFMA (the step is latency-bound, so
+  // memory-level parallelism matters more than anything else here)
+  constexpr int S = MF >= 8 ? 2 : 4;
+  for (int k = kbeg; k < kend; k += KSTEP * S) {
+    Chunk16 wv[S][FN], xv[S][MF];
 #pragma unroll
-    for (int a = 0; a < FN; ++a) wv[a] = wok[a] ? *(const Chunk16*)(W + woff[a] + k) : Chunk16{0u, 0u, 0u, 0u};
+    for (int t = 0; t < S; ++t) {
+      const int kk = k + t * KSTEP;
+      const bool in = kk < kend;
 #pragma unroll
-    for (int b = 0; b < MF; ++b) xv[b] = xok[b] ? *(const Chunk16*)(X + xoff[b] + k) : Chunk16{0u, 0u, 0u, 0u};
+      for (int a = 0; a < FN; ++a) wv[t][a] = (in && wok[a]) ? *(const Chunk16*)(W + woff[a] + kk) : Chunk16{0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int a = 0; a < FN; ++a)
+      for (int b = 0; b < MF; ++b) xv[t][b] = (in && xok[b]) ? *(const Chunk16*)(X + xoff[b] + kk) : Chunk16{0u, 0u, 0u, 0u};
+    }
 #pragma unroll
-      for (int b = 0; b < MF; ++b) {
-        if constexpr (sizeof(T) == 2) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[a]),
-                                                              __builtin_bit_cast(bf16x8, xv[b]), acc[a][b], 0, 0, 0);
-        } else {
-          const f32x4 wf = __builtin_bit_cast(f32x4, wv[a]), xf = __builtin_bit_cast(f32x4, xv[b]);
+    for (int t = 0; t < S; ++t)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[t], xf[t], acc[a][b], 0, 0, 0);
+      for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int b = 0; b < MF; ++b) {
+          if constexpr (sizeof(T) == 2) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[t][a]),
+                                                                __builtin_bit_cast(bf16x8, xv[t][b]), acc[a][b], 0, 0, 0);
+          } else {
+            const f32x4 wf = __builtin_bit_cast(f32x4, wv[t][a]), xf = __builtin_bit_cast(f32x4, xv[t][b]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u], xf[u], acc[a][b], 0, 0, 0);
+          }
         }
-      }
   }
 
   // ---- combine the 4 waves' K slices (fixed order w = 0..3)

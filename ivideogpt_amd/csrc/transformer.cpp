@@ -170,9 +170,8 @@ static int step_body(ivg_engine* e, hipStream_t st, const GenBuf& g, int B, cons
     SkinnyArgs s;
     s.X = g.xn; s.W = w.wqkv; s.Y = g.qkv; s.M = B; s.N = 3 * H; s.K = H; s.ldx = H; s.ldw = H; s.ldy = 3 * H;
     CK(launch_skinny(s, dt, st));
-    CK(launch_rope_kv(g.qkv, kc_ptr(e, l, 0), kc_ptr(e, l, 1), nullptr, 0, e->rope_cos, e->rope_sin, B, 1, e->heads, e->hd, e->Lmax,
-                      g.state, 0, dt, st));
-    CK(launch_decode_attn(g.qkv, kc_ptr(e, l, 0), kc_ptr(e, l, 1), g.attn, B, e->heads, e->hd, e->Lmax, g.state, dt, st));
+    CK(launch_decode_attn(g.qkv, kc_ptr(e, l, 0), kc_ptr(e, l, 1), g.attn, e->rope_cos, e->rope_sin, B, e->heads, e->hd, e->Lmax,
+                          g.state, dt, st));
     SkinnyArgs o;
     o.X = g.attn; o.W = w.wo; o.Y = g.part_o; o.M = B; o.N = H; o.K = H; o.ldx = H; o.ldw = H; o.ldy = H; o.splits = g.so;
     o.flags = IG_OUT_F32;
