@@ -147,7 +147,6 @@ int build_transformer(ivg_engine* e) {
   for (int l = 0; l < c.num_layers; ++l) {
     const std::string b = "llm.layers." + std::to_string(l) + ".";
     LayerW w;
-    w.ln1 = L.f32(b + "ln1", H); w.ln2 = L.f32(b + "ln2", H);
     w.wqkv = L.data(b + "wqkv", (int)dt, (int64_t)3 * H * H);
     w.wo = L.data(b + "wo", (int)dt, (int64_t)H * H);
     w.wgu = L.data(b + "wgu", (int)dt, (int64_t)2 * I * H);
@@ -156,7 +155,6 @@ int build_transformer(ivg_engine* e) {
   }
   e->embed = L.data("llm.embed", (int)dt, (int64_t)V * H);
   e->lm_head = L.data("llm.lm_head", (int)dt, (int64_t)V * H);
-  e->final_norm = L.f32("llm.norm", H);
   e->rope_cos = L.f32("llm.rope_cos", (int64_t)c.max_position_embeddings * (e->hd / 2));
   e->rope_sin = L.f32("llm.rope_sin", (int64_t)c.max_position_embeddings * (e->hd / 2));
   if (c.action_dim > 0) {
@@ -261,6 +259,7 @@ void ivg_destroy(ivg_engine* e) {
   if (e->kv) (void)hipFree(e->kv);
   if (e->vt) (void)hipFree(e->vt);
   if (e->gen_buf) (void)hipFree(e->gen_buf);
+  if (e->ones) (void)hipFree(e->ones);
   delete e;
 }
 
@@ -297,6 +296,12 @@ int ivg_create(const ivg_config* cfg, const ivg_tensor* weights, int n_weights, 
     e->gen_bytes = gen_buffer_bytes(e);
     if (hipMalloc((void**)&e->kv, kvb) != hipSuccess || hipMalloc((void**)&e->vt, vtb) != hipSuccess || hipMalloc((void**)&e->gen_buf, e->gen_bytes) != hipSuccess) {
       e->err = "hipMalloc of the KV cache failed"; return bail(IVG_ERR_HIP);
+    }
+    {
+      std::vector<float> one((size_t)cfg->hidden_size, 1.0f);
+      if (hipMalloc((void**)&e->ones, one.size() * 4) != hipSuccess || hipMemcpy(e->ones, one.data(), one.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        e->err = "hipMalloc failed"; return bail(IVG_ERR_HIP);
+      }
     }
     (void)hipMemset(e->vt, 0, vtb);
     (void)hipMemset(e->gen_buf, 0, e->gen_bytes);

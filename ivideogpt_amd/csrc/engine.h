@@ -44,7 +44,7 @@ struct TrunkW {  // encoder or decoder
   ConvW conv_out;
   std::vector<XAttW> xatt;
 };
-struct LayerW { const float* ln1; const float* ln2; const void* wqkv; const void* wo; const void* wgu; const void* wdown; };
+struct LayerW { const void* wqkv; const void* wo; const void* wgu; const void* wdown; };  // RMSNorm weights are folded into wqkv / wgu
 
 struct Feature { void* p = nullptr; int side = 0, C = 0; };
 
@@ -75,7 +75,8 @@ struct ivg_engine {
   float* ee_c = nullptr; float* ee_d = nullptr;
   // transformer
   std::vector<ivg::LayerW> layers;
-  const void* embed = nullptr; const void* lm_head = nullptr; const float* final_norm = nullptr;
+  const void* embed = nullptr; const void* lm_head = nullptr;  // final norm weight folded into lm_head
+  float* ones = nullptr;     // [hidden] of 1.0f: the prefill's stand-alone RMSNorm has no weight left to apply
   const float* rope_cos = nullptr; const float* rope_sin = nullptr;
   const float* act_w = nullptr; const float* act_b = nullptr; const float* rew_w = nullptr; const float* rew_b = nullptr;
   int heads = 0, hd = 0, Lmax = 0;

@@ -11,6 +11,7 @@ enum IgemmFlags : int {
   IG_SILU = 8,       // silu(.) after bias/residual
   IG_GLU = 16,       // weight rows packed [16 gate | 16 up] per 32: out[m][j] = silu(gate) * up, N_out = N/2
   IG_OUT_F32 = 32,   // output is fp32 regardless of T (attention scores, logits, final pixels)
+  SK_NORM = 64,      // skinny GEMM only: scale row m by rsqrt(mean_k X[m][k]^2 + eps) (RMSNorm with the weight folded into W)
 };
 
 // Y[z](m, n) = epi( alpha * sum_k A[z](m, k) * W[z][n][k] )
@@ -51,7 +52,9 @@ struct SkinnyArgs {
   void* Y = nullptr;       // T, or fp32 when IG_OUT_F32 / splits > 1
   int M = 0, N = 0, K = 0, ldx = 0, ldw = 0, ldy = 0;
   int splits = 1;
-  int flags = 0;           // IG_GLU | IG_OUT_F32
+  int flags = 0;           // IG_GLU | IG_OUT_F32 | IG_RESIDUAL (Y += ..., in place) | SK_NORM
+  float eps = 1e-6f;       // SK_NORM
+  int* bump = nullptr;     // optional pair of device ints incremented once at the end (StepState advance)
 };
 int launch_skinny(const SkinnyArgs& a, DType dtype, hipStream_t stream);
 int skinny_pick_splits(int N, int K, DType dtype);

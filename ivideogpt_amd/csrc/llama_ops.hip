@@ -433,20 +433,22 @@ int launch_add_rows(void* x, long x_stride, const void* add, long add_stride, in
   return (int)hipGetLastError();
 }
 
+// r[b] = rsqrt(mean(h^2) + eps) * dot(h[b], w) + bias: reward head on the final-normed hidden state (norm weight folded into w)
 template <typename T>
 __global__ __launch_bounds__(64) void rowdot_kernel(const T* __restrict__ h, const float* __restrict__ w,
-                                                    const float* __restrict__ bias, float* __restrict__ out, int H) {
+                                                    const float* __restrict__ bias, float* __restrict__ out, int H, float eps) {
   const int b = blockIdx.x;
-  float s = 0.f;
-  for (int c = threadIdx.x; c < H; c += 64) s = fmaf(to_f32(h[(long)b * H + c]), w[c], s);
+  float s = 0.f, ss = 0.f;
+  for (int c = threadIdx.x; c < H; c += 64) { const float v = to_f32(h[(long)b * H + c]); s = fmaf(v, w[c], s); ss = fmaf(v, v, ss); }
   s = wave_sum(s);
-  if (threadIdx.x == 0) out[b] = s + bias[0];
+  ss = wave_sum(ss);
+  if (threadIdx.x == 0) out[b] = s * rsqrtf(ss / (float)H + eps) + bias[0];
 }
 
-int launch_rowdot(const void* h, const float* w, const float* bias, float* out, int B, int H, DType dt, hipStream_t st) {
+int launch_rowdot(const void* h, const float* w, const float* bias, float* out, int B, int H, float eps, DType dt, hipStream_t st) {
   if (B <= 0) return 0;
-  if (dt == BF16) hipLaunchKernelGGL(rowdot_kernel<bf16_t>, dim3(B), dim3(64), 0, st, (const bf16_t*)h, w, bias, out, H);
-  else hipLaunchKernelGGL(rowdot_kernel<float>, dim3(B), dim3(64), 0, st, (const float*)h, w, bias, out, H);
+  if (dt == BF16) hipLaunchKernelGGL(rowdot_kernel<bf16_t>, dim3(B), dim3(64), 0, st, (const bf16_t*)h, w, bias, out, H, eps);
+  else hipLaunchKernelGGL(rowdot_kernel<float>, dim3(B), dim3(64), 0, st, (const float*)h, w, bias, out, H, eps);
   return (int)hipGetLastError();
 }
 

@@ -76,7 +76,7 @@ int launch_state_set(StepState* state, int pos, int j, hipStream_t st);
 int launch_action_embed(const float* act, const float* W, const float* bias, void* out, DType dt, int BT, int A, int H,
                         hipStream_t st);
 int launch_add_rows(void* x, long x_stride, const void* add, long add_stride, int B, int H, DType dt, hipStream_t st);
-// r[b] = dot(h[b], w) + bias   (reward head)
-int launch_rowdot(const void* h, const float* w, const float* bias, float* out, int B, int H, DType dt, hipStream_t st);
+// r[b] = rsqrt(mean(h[b]^2) + eps) * dot(h[b], w) + bias   (reward head on the RMS-normed hidden state)
+int launch_rowdot(const void* h, const float* w, const float* bias, float* out, int B, int H, float eps, DType dt, hipStream_t st);
 
 }  // namespace ivg

@@ -21,8 +21,8 @@ static size_t esz(DType d) { return d == BF16 ? 2 : 4; }
 static size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct GenBuf {  // persistent decode-step buffers (fixed addresses so the captured step graph can be replayed)
-  StepState* state; char* x; char* xn; char* qkv; char* attn; char* act; float* part_o; float* part_d; float* logits;
-  int64_t* ids; float* uni; char* act_emb; int so, sd, Bc, ids_ld;
+  StepState* state; char* x; char* qkv; char* attn; char* act; float* logits;
+  int64_t* ids; float* uni; char* act_emb; int Bc, ids_ld;
 };
 
 static int gen_chunk(const ivg_engine* e) { return std::min(e->cfg.max_batch, 128); }
@@ -32,19 +32,14 @@ static void gen_layout(const ivg_engine* e, GenBuf& g, char* base, size_t* total
   const DType dt = e->llm_dt;
   const int Bc = gen_chunk(e), H = c.hidden_size, I = c.intermediate_size, V = c.vocab_size;
   g.Bc = Bc;
-  g.so = skinny_pick_splits(H, H, dt);
-  g.sd = skinny_pick_splits(H, I, dt);
   g.ids_ld = e->Lmax;
   size_t off = 0;
   auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off = rup(off + bytes, 256); return p; };
   g.state = (StepState*)take(sizeof(StepState));
   g.x = take((size_t)Bc * H * esz(dt));
-  g.xn = take((size_t)Bc * H * esz(dt));
   g.qkv = take((size_t)Bc * 3 * H * esz(dt));
   g.attn = take((size_t)Bc * H * esz(dt));
   g.act = take((size_t)Bc * I * esz(dt));
-  g.part_o = (float*)take((size_t)g.so * Bc * H * 4);
-  g.part_d = (float*)take((size_t)g.sd * Bc * H * 4);
   g.logits = (float*)take((size_t)Bc * V * 4);
   g.ids = (int64_t*)take((size_t)Bc * g.ids_ld * 8);
   g.uni = (float*)take((size_t)Bc * g.ids_ld * 4);
@@ -94,7 +89,7 @@ int Run::prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const voi
   }
   for (int l = 0; l < c.num_layers; ++l) {
     const LayerW& w = e->layers[l];
-    if (!planning) CK(launch_add_rmsnorm(x, H, nullptr, 0, w.ln1, xn, (int)M, H, c.rms_norm_eps, dt, st));
+    if (!planning) CK(launch_add_rmsnorm(x, H, nullptr, 0, e->ones, xn, (int)M, H, c.rms_norm_eps, dt, st));
     ConvW wq; wq.w = w.wqkv; wq.cin = H; wq.cout = 3 * H;
     IVG_TRY(linear(dt, xn, M, wq, qkv, nullptr, 0, 0));
     if (!planning)
@@ -124,7 +119,7 @@ int Run::prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const voi
     }
     ConvW wo; wo.w = w.wo; wo.cin = H; wo.cout = H;
     IVG_TRY(linear(dt, attn, M, wo, x, x, 0, 0));  // in-place residual
-    if (!planning) CK(launch_add_rmsnorm(x, H, nullptr, 0, w.ln2, xn, (int)M, H, c.rms_norm_eps, dt, st));
+    if (!planning) CK(launch_add_rmsnorm(x, H, nullptr, 0, e->ones, xn, (int)M, H, c.rms_norm_eps, dt, st));
     {  // act = silu(gate) * up   (weights packed [16 gate | 16 up] per 32 rows)
       IgemmArgs g;
       g.X = xn; g.W = w.wgu; g.Y = act;
@@ -136,17 +131,17 @@ int Run::prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const voi
     IVG_TRY(linear(dt, act, M, wd, x, x, 0, 0));
   }
   if (logits_all) {
-    if (!planning) CK(launch_add_rmsnorm(x, H, nullptr, 0, e->final_norm, xn, (int)M, H, c.rms_norm_eps, dt, st));
+    if (!planning) CK(launch_add_rmsnorm(x, H, nullptr, 0, e->ones, xn, (int)M, H, c.rms_norm_eps, dt, st));
     ConvW wl; wl.w = e->lm_head; wl.cin = H; wl.cout = V;
     IVG_TRY(linear(dt, xn, M, wl, logits_all, nullptr, 0, 1));
   }
   if (logits_last && !planning) {
-    // final norm of the last position of every sequence -> hidden_last [B][H]; logits by the skinny GEMM
-    CK(launch_add_rmsnorm(x + (size_t)(L - 1) * H * esz(dt), (long)L * H, nullptr, 0, e->final_norm, hidden_last, B, H,
-                          c.rms_norm_eps, dt, st));
+    // last position of every sequence -> residual rows hidden_last [B][H]; final RMSNorm is fused into the lm_head GEMM
+    CK((int)hipMemcpy2DAsync(hidden_last, (size_t)H * esz(dt), x + (size_t)(L - 1) * H * esz(dt), (size_t)L * H * esz(dt),
+                             (size_t)H * esz(dt), B, hipMemcpyDeviceToDevice, st));
     SkinnyArgs s;
     s.X = hidden_last; s.W = e->lm_head; s.Y = logits_last; s.M = B; s.N = V; s.K = H; s.ldx = H; s.ldw = H; s.ldy = V;
-    s.flags = IG_OUT_F32;
+    s.flags = IG_OUT_F32 | SK_NORM; s.eps = c.rms_norm_eps;
     CK(launch_skinny(s, dt, st));
   }
   e->ws.reset(m);
@@ -162,36 +157,32 @@ static int step_body(ivg_engine* e, hipStream_t st, const GenBuf& g, int B, cons
   const int H = c.hidden_size, I = c.intermediate_size, V = c.vocab_size;
   CK(launch_sample_embed(sa, B, dt, st));
   if (!forward) return 0;
-  const float* pending = nullptr;
-  int pend_s = 0;
+  // 5 launches per layer: RMSNorms are fused into the consuming GEMMs (weights pre-multiplied by the norm weight,
+  // row scale computed from the activations the GEMM streams anyway), residual adds into the producing GEMMs.
   for (int l = 0; l < c.num_layers; ++l) {
     const LayerW& w = e->layers[l];
-    CK(launch_add_rmsnorm(g.x, H, pending, pend_s, w.ln1, g.xn, B, H, c.rms_norm_eps, dt, st));
     SkinnyArgs s;
-    s.X = g.xn; s.W = w.wqkv; s.Y = g.qkv; s.M = B; s.N = 3 * H; s.K = H; s.ldx = H; s.ldw = H; s.ldy = 3 * H;
+    s.X = g.x; s.W = w.wqkv; s.Y = g.qkv; s.M = B; s.N = 3 * H; s.K = H; s.ldx = H; s.ldw = H; s.ldy = 3 * H;
+    s.flags = SK_NORM; s.eps = c.rms_norm_eps;
     CK(launch_skinny(s, dt, st));
     CK(launch_decode_attn(g.qkv, kc_ptr(e, l, 0), kc_ptr(e, l, 1), g.attn, e->rope_cos, e->rope_sin, B, e->heads, e->hd, e->Lmax,
                           g.state, dt, st));
     SkinnyArgs o;
-    o.X = g.attn; o.W = w.wo; o.Y = g.part_o; o.M = B; o.N = H; o.K = H; o.ldx = H; o.ldw = H; o.ldy = H; o.splits = g.so;
-    o.flags = IG_OUT_F32;
+    o.X = g.attn; o.W = w.wo; o.Y = g.x; o.M = B; o.N = H; o.K = H; o.ldx = H; o.ldw = H; o.ldy = H; o.flags = IG_RESIDUAL;
     CK(launch_skinny(o, dt, st));
-    CK(launch_add_rmsnorm(g.x, H, g.part_o, g.so, w.ln2, g.xn, B, H, c.rms_norm_eps, dt, st));
     SkinnyArgs u;
-    u.X = g.xn; u.W = w.wgu; u.Y = g.act; u.M = B; u.N = 2 * I; u.K = H; u.ldx = H; u.ldw = H; u.ldy = I; u.flags = IG_GLU;
+    u.X = g.x; u.W = w.wgu; u.Y = g.act; u.M = B; u.N = 2 * I; u.K = H; u.ldx = H; u.ldw = H; u.ldy = I;
+    u.flags = IG_GLU | SK_NORM; u.eps = c.rms_norm_eps;
     CK(launch_skinny(u, dt, st));
     SkinnyArgs d;
-    d.X = g.act; d.W = w.wdown; d.Y = g.part_d; d.M = B; d.N = H; d.K = I; d.ldx = I; d.ldw = I; d.ldy = H; d.splits = g.sd;
-    d.flags = IG_OUT_F32;
+    d.X = g.act; d.W = w.wdown; d.Y = g.x; d.M = B; d.N = H; d.K = I; d.ldx = I; d.ldw = I; d.ldy = H; d.flags = IG_RESIDUAL;
     CK(launch_skinny(d, dt, st));
-    pending = g.part_d; pend_s = g.sd;
   }
-  CK(launch_add_rmsnorm(g.x, H, pending, pend_s, e->final_norm, g.xn, B, H, c.rms_norm_eps, dt, st));
   SkinnyArgs lm;
-  lm.X = g.xn; lm.W = e->lm_head; lm.Y = g.logits; lm.M = B; lm.N = V; lm.K = H; lm.ldx = H; lm.ldw = H; lm.ldy = V;
-  lm.flags = IG_OUT_F32;
+  lm.X = g.x; lm.W = e->lm_head; lm.Y = g.logits; lm.M = B; lm.N = V; lm.K = H; lm.ldx = H; lm.ldw = H; lm.ldy = V;
+  lm.flags = IG_OUT_F32 | SK_NORM; lm.eps = c.rms_norm_eps;
+  lm.bump = (int*)g.state;  // pos += 1, j += 1 once the last reader of the state (the last layer's attention) is done
   CK(launch_skinny(lm, dt, st));
-  CK(launch_step_advance(g.state, st));
   return 0;
 }
 
@@ -216,7 +207,7 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
                                hipMemcpyDeviceToDevice, st));
     if (actions)
       CK(launch_action_embed(actions + (long)b0 * act_T * c.action_dim, e->act_w, e->act_b, g.act_emb, dt, Bc * act_T, c.action_dim, H, st));
-    IVG_TRY(prefill(g.ids, g.ids_ld, Bc, L0, actions ? g.act_emb : nullptr, act_T, ctx, false, nullptr, g.logits, g.xn));
+    IVG_TRY(prefill(g.ids, g.ids_ld, Bc, L0, actions ? g.act_emb : nullptr, act_T, ctx, false, nullptr, g.logits, g.x));
     CK(launch_state_set(g.state, L0, 1, st));
     SampleArgs sa;
     sa.logits = g.logits; sa.V = V;
@@ -264,7 +255,7 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
                              hipMemcpyDeviceToDevice, st));
     if (reward_out) {
       if (!e->rew_w) return e->fail(IVG_ERR_MISSING, "generate: reward requested but reward_linear is not loaded");
-      CK(launch_rowdot(g.xn, e->rew_w, e->rew_b, reward_out + b0, Bc, H, dt, st));
+      CK(launch_rowdot(g.x, e->rew_w, e->rew_b, reward_out + b0, Bc, H, c.rms_norm_eps, dt, st));
     }
   }
   return 0;

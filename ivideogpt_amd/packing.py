@@ -65,19 +65,20 @@ def pack_llama(sd, cfg, device, code, prefix=""):
     out = {}
     for l in range(nl):
         b = f"model.layers.{l}."
-        out[f"llm.layers.{l}.wqkv"] = torch.cat([g(b + "self_attn.q_proj.weight"), g(b + "self_attn.k_proj.weight"),
-                                                 g(b + "self_attn.v_proj.weight")], 0).to(dt).contiguous()
+        ln1, ln2 = g(b + "input_layernorm.weight"), g(b + "post_attention_layernorm.weight")
+        # RMSNorm weights are folded into the consuming projection (W' = W diag(w)): the engine fuses the norm's row
+        # scale into the GEMM, so no separate normalisation pass exists in the decode step
+        out[f"llm.layers.{l}.wqkv"] = (torch.cat([g(b + "self_attn.q_proj.weight"), g(b + "self_attn.k_proj.weight"),
+                                                  g(b + "self_attn.v_proj.weight")], 0) * ln1[None, :]).to(dt).contiguous()
         out[f"llm.layers.{l}.wo"] = g(b + "self_attn.o_proj.weight").to(dt).contiguous()
         gate, up = g(b + "mlp.gate_proj.weight"), g(b + "mlp.up_proj.weight")
         assert I % 16 == 0
-        out[f"llm.layers.{l}.wgu"] = torch.stack([gate.view(I // 16, 16, H), up.view(I // 16, 16, H)], 1) \
-            .reshape(2 * I, H).to(dt).contiguous()
+        out[f"llm.layers.{l}.wgu"] = (torch.stack([gate.view(I // 16, 16, H), up.view(I // 16, 16, H)], 1)
+                                      .reshape(2 * I, H) * ln2[None, :]).to(dt).contiguous()
         out[f"llm.layers.{l}.wdown"] = g(b + "mlp.down_proj.weight").to(dt).contiguous()
-        out[f"llm.layers.{l}.ln1"] = vec(g(b + "input_layernorm.weight"))
-        out[f"llm.layers.{l}.ln2"] = vec(g(b + "post_attention_layernorm.weight"))
     out["llm.embed"] = g("model.embed_tokens.weight").to(dt).contiguous()
-    out["llm.lm_head"] = g("lm_head.weight").to(dt).contiguous()
-    out["llm.norm"] = vec(g("model.norm.weight"))
+    fnorm = g("model.norm.weight")
+    out["llm.lm_head"] = (g("lm_head.weight") * fnorm[None, :]).to(dt).contiguous()
     # RoPE tables exactly as HF builds them (fp32 inv_freq, fp32 outer product, cos/sin, cast to the model dtype)
     inv_freq = 1.0 / (cfg.get("rope_theta", 10000.0) ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
     freqs = torch.arange(cfg["max_position_embeddings"], dtype=torch.float32)[:, None] * inv_freq[None, :]
@@ -87,6 +88,7 @@ def pack_llama(sd, cfg, device, code, prefix=""):
         out["llm.action_linear.weight"] = sd["action_linear.weight"].detach().to(device=device, dtype=torch.float32).contiguous()
         out["llm.action_linear.bias"] = sd["action_linear.bias"].detach().to(device=device, dtype=torch.float32).contiguous()
     if "reward_linear.weight" in sd:
-        out["llm.reward_linear.weight"] = sd["reward_linear.weight"].detach().to(device=device, dtype=torch.float32).reshape(-1).contiguous()
+        out["llm.reward_linear.weight"] = (sd["reward_linear.weight"].detach().to(device=device, dtype=torch.float32).reshape(-1)
+                                           * fnorm).contiguous()   # reward head reads the final-normed hidden state
         out["llm.reward_linear.bias"] = sd["reward_linear.bias"].detach().to(device=device, dtype=torch.float32).contiguous()
     return out

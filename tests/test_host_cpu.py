@@ -79,9 +79,11 @@ def test_packing_layouts_cpu():
     lt = pack_llama(lsd, lcfg, "cpu", 1, prefix="llm.")
     wgu = lt["llm.layers.0.wgu"]
     assert wgu.shape == (256, 64)
-    assert torch.equal(wgu[0:16], lsd["llm.model.layers.0.mlp.gate_proj.weight"][0:16].to(torch.bfloat16))
-    assert torch.equal(wgu[16:32], lsd["llm.model.layers.0.mlp.up_proj.weight"][0:16].to(torch.bfloat16))
-    assert torch.equal(wgu[32:48], lsd["llm.model.layers.0.mlp.gate_proj.weight"][16:32].to(torch.bfloat16))
+    ln2 = lsd["llm.model.layers.0.post_attention_layernorm.weight"][None, :]   # RMSNorm weight folded into the projection
+    assert torch.equal(wgu[0:16], (lsd["llm.model.layers.0.mlp.gate_proj.weight"][0:16] * ln2).to(torch.bfloat16))
+    assert torch.equal(wgu[16:32], (lsd["llm.model.layers.0.mlp.up_proj.weight"][0:16] * ln2).to(torch.bfloat16))
+    assert torch.equal(wgu[32:48], (lsd["llm.model.layers.0.mlp.gate_proj.weight"][16:32] * ln2).to(torch.bfloat16))
+    assert torch.equal(lt["llm.lm_head"], (lsd["llm.lm_head.weight"] * lsd["llm.model.norm.weight"][None, :]).to(torch.bfloat16))
     assert lt["llm.action_linear.weight"].shape == (64, 3) and lt["llm.rope_cos"].shape == (1024, 32)
 
 
