@@ -131,7 +131,7 @@ int ivg_logits(ivg_engine* e, const int64_t* ids, int B, int L, const float* act
                ivg_stream stream);
 
 /* ---- measurement hooks (bench.py): time one kernel class with HIP events on the launching stream */
-enum ivg_kernel_class { IVG_K_IGEMM_BF16 = 0, IVG_K_IGEMM_F32 = 1, IVG_K_COUNT = 2 };
+enum ivg_kernel_class { IVG_K_IGEMM_BF16 = 0, IVG_K_IGEMM_F32 = 1, IVG_K_CONV3X3_BF16 = 2, IVG_K_CONV3X3_F32 = 3, IVG_K_COUNT = 4 };
 typedef struct {
   int64_t launches;
   double total_ms;      /* sum of per-launch durations (hipEventElapsedTime) */

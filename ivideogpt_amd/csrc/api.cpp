@@ -169,8 +169,8 @@ int build_transformer(ivg_engine* e) {
 }
 
 // ---- measurement hooks
-void Run::prof_begin(DType dt, double flops, double bytes) {
-  ProfClass& pc = e->prof[dt == BF16 ? IVG_K_IGEMM_BF16 : IVG_K_IGEMM_F32];
+void Run::prof_begin(DType dt, double flops, double bytes, int base) {
+  ProfClass& pc = e->prof[base + (dt == BF16 ? 0 : 1)];
   if (!pc.enabled) return;
   ProfSlot s;
   if (!pc.pool.empty()) { s = pc.pool.back(); pc.pool.pop_back(); }
@@ -179,10 +179,16 @@ void Run::prof_begin(DType dt, double flops, double bytes) {
   (void)hipEventRecord(s.a, st);
   pc.used.push_back(s);
 }
-void Run::prof_end(DType dt) {
-  ProfClass& pc = e->prof[dt == BF16 ? IVG_K_IGEMM_BF16 : IVG_K_IGEMM_F32];
+void Run::prof_end(DType dt, int base) {
+  ProfClass& pc = e->prof[base + (dt == BF16 ? 0 : 1)];
   if (!pc.enabled || pc.used.empty()) return;
   (void)hipEventRecord(pc.used.back().b, st);
+}
+void Run::prof_cancel(DType dt, int base) {
+  ProfClass& pc = e->prof[base + (dt == BF16 ? 0 : 1)];
+  if (!pc.enabled || pc.used.empty()) return;
+  pc.pool.push_back(pc.used.back());
+  pc.used.pop_back();
 }
 
 }  // namespace ivg
@@ -436,6 +442,11 @@ int ivg_op_igemm(const ivg_igemm_args* a, int dtype, ivg_stream stream) {
   g.c_img = a->c_img; g.c_pix = a->c_pix; g.c_ch = a->c_ch; g.c_grp = a->c_grp; g.c_grp_stride = a->c_grp_stride;
   g.flags = a->flags; g.alpha = a->alpha; g.nb0 = a->nb0; g.nb1 = a->nb1; g.nb2 = a->nb2;
   for (int i = 0; i < 3; ++i) { g.sa[i] = a->sa[i]; g.sw[i] = a->sw[i]; g.sy[i] = a->sy[i]; }
+  if (g.KH == 3 && g.KW == 3 && g.stride == 1) {  // same dispatch as the engine: LDS-halo kernel first
+    const int rc = launch_conv3x3(g, (DType)dtype, (hipStream_t)stream);
+    if (rc == 0) return IVG_OK;
+    if (rc > 0) return IVG_ERR_HIP;
+  }
   return launch_igemm(g, (DType)dtype, (hipStream_t)stream) ? IVG_ERR_HIP : IVG_OK;
 }
 

@@ -1,0 +1,282 @@
+// 3x3 / stride-1 / pad-1 convolution (optionally over a nearest-x2 upsampled input) for gfx950 -- the FLOP majority
+// of the tokenizer (DF ResnetBlock2D.conv1/conv2, Upsample2D.conv, conv_in of the decoders).
+//
+// Why a second conv kernel: the generic implicit GEMM (igemm.hip) re-gathers the A tile from global memory for every
+// tap, and measured on MI355X it runs at exactly the per-CU ingest limit (~10 B/clk/CU from HBM, ~17 from L2/MALL:
+// 395 TF at Cout = 128, 690 TF at Cout = 512; LDS-DMA staging changes nothing).  Here a workgroup
+//   * owns a TH x TW = 256-pixel spatial tile of one image and BN output channels,
+//   * stages the (TH+2) x (TW+2) input HALO tile of one 64-channel (bf16; 32 fp32) chunk in LDS ONCE and runs all
+//     nine taps out of it (A traffic / 9, no im2col), double-buffered across channel chunks, the next chunk's halo
+//     arriving in pieces under the current chunk's taps,
+//   * streams the [BN][128 B] weight tile of each (tap, chunk) through a second double buffer,
+//   * both by LDS-DMA (global_load_lds, 16 B/lane; out-of-image pixels source a zero page), 128-byte LDS rows with
+//     the same XOR swizzle as igemm.hip (swizzle on the SOURCE chunk, conflict-free ds_read_b128),
+//   * 8 waves (2 per SIMD), each a 64 x 64 (or 64 x 32) sub-tile of MFMA fragments, swapped operands so a lane owns
+//     4 consecutive output channels;  the XCD-aware block order keeps the N tiles of one spatial tile on one L2.
+// Bytes per (tap, chunk) step: 16 KiB of weights + 1/9 of a ~50 KiB halo for 4.2 MFLOP -> ~195 FLOP/B (igemm: 64).
+#include <cstdlib>
+
+#include "igemm.h"
+
+namespace ivg {
+
+struct Conv3Dev {
+  const void* X; const void* W; void* Y; const void* R; const float* bias;
+  int H, Wd, Cin, Ho, Wo;            // input H x W (before upsampling), output Ho x Wo
+  int TH, TW, tw_shift;              // output tile, TW = 1 << tw_shift, TH * TW = 256
+  int HTH, HTW;                      // halo tile (input pixels)
+  int tiles_x, tiles_per_img, n_sp;  // spatial tiles
+  int N, ldw, tiles_n;
+  long c_img, c_pix, c_ch, c_grp_stride;
+  int c_grp, flags;
+  int hb_bytes;                      // one halo buffer
+};
+
+// source of every out-of-image 16-byte chunk (zero-initialised device global; one per translation unit, no RDC needed)
+__device__ __attribute__((aligned(16))) unsigned char g_zero_chunk3[16];
+
+__device__ __forceinline__ void glds16b(const void* gsrc, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <typename T, int BN, bool UPS>
+__global__ __launch_bounds__(512) void conv3x3_kernel(const Conv3Dev p) {
+  constexpr int VEC = Traits<T>::VEC;
+  constexpr int CK = 8 * VEC;              // channels per chunk: one 128-byte LDS row per halo pixel
+  constexpr int WN = BN / 2;               // 8 waves = 4 (M) x 2 (N)
+  constexpr int FM = 4, FN = WN / 16;
+  constexpr int W_BYTES = BN * 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* hbuf0 = smem;
+  unsigned char* wbuf0 = smem + 2 * p.hb_bytes;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int wm = wave & 3, wn = wave >> 2;
+
+  // ---- XCD-aware block order (blocks b, b+8, ... share an XCD/L2): give each XCD a contiguous run of work items
+  // with the N tile fastest, so the N tiles of one spatial tile hit the same L2 (bijective for any grid size)
+  const int nwg = gridDim.x;
+  int v;
+  {
+    const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int tile_n = v % p.tiles_n;
+  const int sp = v / p.tiles_n;
+  const int img = sp / p.tiles_per_img;
+  const int t_in = sp - img * p.tiles_per_img;
+  const int ty = t_in / p.tiles_x, tx = t_in - ty * p.tiles_x;
+  const int y0 = ty * p.TH, x0 = tx * p.TW;            // output tile origin
+  const int iy0 = UPS ? ((y0 - 1) >> 1) : (y0 - 1);    // halo origin in input pixels
+  const int ix0 = UPS ? ((x0 - 1) >> 1) : (x0 - 1);
+  const T* X = (const T*)p.X + (long)img * p.H * p.Wd * p.Cin;
+  const T* Wt = (const T*)p.W;
+  const int n_base = tile_n * BN;
+  const int halo_rows = p.HTH * p.HTW;
+  const int halo_iters = (halo_rows * 8 + 511) / 512;
+
+  // one 8-KiB piece of a halo tile: 512 lanes x 16 B, lane-linear in LDS
+  auto issue_halo_piece = [&](int chunk, int it, unsigned char* hb) {
+    const int q = it * 512 + tid;
+    const int row = q >> 3, slot = q & 7;
+    const int c = slot ^ ((row >> 1) & 7);
+    const int hy = row / p.HTW, hx = row - hy * p.HTW;
+    const int iy = iy0 + hy, ix = ix0 + hx;
+    const bool ok = (row < halo_rows) & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.Wd);
+    const void* src = ok ? (const void*)(X + ((long)(iy * p.Wd + ix) * p.Cin + chunk * CK + c * VEC)) : (const void*)g_zero_chunk3;
+    glds16b(src, hb + (it * 512 + wave * 64) * 16);
+  };
+  auto issue_w = [&](int step, unsigned char* wb) {
+    const int chunk = step / 9, tap = step - chunk * 9;
+#pragma unroll
+    for (int it = 0; it < BN * 8 / 512; ++it) {
+      const int q = it * 512 + tid;
+      const int n = q >> 3, slot = q & 7;
+      const int c = slot ^ ((n >> 1) & 7);
+      const bool ok = (n_base + n) < p.N;
+      const void* src = ok ? (const void*)(Wt + ((long)(n_base + n) * p.ldw + tap * p.Cin + chunk * CK + c * VEC)) : (const void*)g_zero_chunk3;
+      glds16b(src, wb + (it * 512 + wave * 64) * 16);
+    }
+  };
+
+  // ---- per-lane pixel bookkeeping: fragment fm covers pixels wm*64 + fm*16 + lr of the tile
+  int py[FM], px[FM];
+#pragma unroll
+  for (int b = 0; b < FM; ++b) {
+    const int pl = wm * 64 + b * 16 + lr;
+    py[b] = pl >> p.tw_shift;
+    px[b] = pl & (p.TW - 1);
+  }
+
+  f32x4 acc[FN][FM];
+#pragma unroll
+  for (int a = 0; a < FN; ++a)
+#pragma unroll
+    for (int b = 0; b < FM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nchunks = p.Cin / CK;
+  const int steps = nchunks * 9;
+  for (int it = 0; it < halo_iters; ++it) issue_halo_piece(0, it, hbuf0);
+  issue_w(0, wbuf0);
+  __syncthreads();
+  for (int s = 0; s < steps; ++s) {
+    const int chunk = s / 9, tap = s - chunk * 9;
+    if (s + 1 < steps) issue_w(s + 1, wbuf0 + ((s + 1) & 1) * W_BYTES);
+    if (chunk + 1 < nchunks && tap < halo_iters) issue_halo_piece(chunk + 1, tap, hbuf0 + ((chunk + 1) & 1) * p.hb_bytes);
+    if (chunk + 1 < nchunks && tap == 8)
+      for (int it = 9; it < halo_iters; ++it) issue_halo_piece(chunk + 1, it, hbuf0 + ((chunk + 1) & 1) * p.hb_bytes);
+    const unsigned char* hb = hbuf0 + (chunk & 1) * p.hb_bytes;
+    const unsigned char* wb = wbuf0 + (s & 1) * W_BYTES;
+    const int kh = tap / 3, kw = tap - kh * 3;
+    int hr[FM];
+#pragma unroll
+    for (int b = 0; b < FM; ++b) {
+      if constexpr (UPS) hr[b] = (((y0 + py[b] + kh - 1) >> 1) - iy0) * p.HTW + (((x0 + px[b] + kw - 1) >> 1) - ix0);
+      else hr[b] = (py[b] + kh) * p.HTW + (px[b] + kw);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int c = kk * 4 + lg;
+      Chunk16 xa[FM], wv[FN];
+#pragma unroll
+      for (int b = 0; b < FM; ++b) xa[b] = *(const Chunk16*)(hb + swz(hr[b], c));
+#pragma unroll
+      for (int a = 0; a < FN; ++a) wv[a] = *(const Chunk16*)(wb + swz(wn * WN + a * 16 + lr, c));
+#pragma unroll
+      for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int b = 0; b < FM; ++b) {
+          if constexpr (sizeof(T) == 2) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[a]), __builtin_bit_cast(bf16x8, xa[b]),
+                                                                acc[a][b], 0, 0, 0);
+          } else {
+            const f32x4 wf = __builtin_bit_cast(f32x4, wv[a]), xf = __builtin_bit_cast(f32x4, xa[b]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u], xf[u], acc[a][b], 0, 0, 0);
+          }
+        }
+    }
+    __syncthreads();  // also drains this step's DMA (the compiler puts vmcnt(0) in front of the barrier)
+  }
+
+  // ---- epilogue (same contract as igemm.hip): lane holds 4 consecutive n of pixel (py, px)
+  const int flags = p.flags;
+#pragma unroll
+  for (int b = 0; b < FM; ++b) {
+    const int pix = (y0 + py[b]) * p.Wo + (x0 + px[b]);
+    const long obase = (long)(img / p.c_grp) * p.c_grp_stride + (long)(img % p.c_grp) * p.c_img + (long)pix * p.c_pix;
+#pragma unroll
+    for (int a = 0; a < FN; ++a) {
+      const int n0 = n_base + wn * WN + a * 16 + lg * 4;
+      if (n0 >= p.N) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r];
+      if (flags & IG_BIAS_N) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (n0 + r < p.N) v[r] += p.bias[n0 + r];
+      }
+      const bool vec_ok = (p.c_ch == 1) && (n0 + 3 < p.N) && ((p.c_pix & 3) == 0);
+      const long o = obase + (long)n0 * p.c_ch;
+      if (flags & IG_RESIDUAL) {
+        const T* R = (const T*)p.R;
+        if (vec_ok && ((o & 3) == 0)) {
+          if constexpr (sizeof(T) == 2) {
+            const bf16x4 rv = *(const bf16x4*)(R + o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+          } else {
+            const f32x4 rv = *(const f32x4*)(R + o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += rv[r];
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (n0 + r < p.N) v[r] += to_f32(R[o + (long)r * p.c_ch]);
+        }
+      }
+      if (flags & IG_SILU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+      }
+      if (flags & IG_OUT_F32) {
+        float* Y = (float*)p.Y;
+        if (vec_ok && ((o & 3) == 0)) *(f32x4*)(Y + o) = f32x4{v[0], v[1], v[2], v[3]};
+        else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (n0 + r < p.N) Y[o + (long)r * p.c_ch] = v[r];
+        }
+      } else {
+        T* Y = (T*)p.Y;
+        if (vec_ok && ((o & 3) == 0)) {
+          if constexpr (sizeof(T) == 2) *(bf16x4*)(Y + o) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+          else *(f32x4*)(Y + o) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (n0 + r < p.N) Y[o + (long)r * p.c_ch] = from_f32<T>(v[r]);
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int BN, bool UPS>
+static int launch_c3(const Conv3Dev& d, int nimg, hipStream_t stream) {
+  const int smem = 2 * d.hb_bytes + 2 * BN * 128;
+  static int attr_set = 0;
+  auto kfn = conv3x3_kernel<T, BN, UPS>;
+  if (attr_set < smem) {
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = 160 * 1024;
+  }
+  const long blocks = (long)nimg * d.tiles_per_img * d.tiles_n;
+  hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(512), smem, stream, d);
+  return (int)hipGetLastError();
+}
+
+bool conv3x3_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("IVG_CONV3X3"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
+
+// Returns -1 when the shape is not covered (caller falls back to the generic implicit GEMM).
+int launch_conv3x3(const IgemmArgs& a, DType dtype, hipStream_t stream) {
+  if (!conv3x3_enabled()) return -1;
+  if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1) return -1;
+  if (a.nb0 * a.nb1 * a.nb2 != 1 || a.alpha != 1.0f || (a.flags & (IG_GLU | IG_BIAS_M))) return -1;
+  const int ck = dtype == BF16 ? 64 : 32;
+  if (a.Cin % ck != 0 || a.ldx != a.Cin) return -1;
+  const int Ho = a.Hout, Wo = a.Wout;
+  if (a.ups ? (Ho != 2 * a.Hin || Wo != 2 * a.Win) : (Ho != a.Hin || Wo != a.Win)) return -1;
+  int TW = Wo >= 64 ? 64 : Wo;
+  if (TW != 16 && TW != 32 && TW != 64) return -1;
+  const int TH = 256 / TW;
+  if (Wo % TW != 0 || Ho % TH != 0) return -1;
+  Conv3Dev d;
+  d.X = a.X; d.W = a.W; d.Y = a.Y; d.R = a.R; d.bias = a.bias;
+  d.H = a.Hin; d.Wd = a.Win; d.Cin = a.Cin; d.Ho = Ho; d.Wo = Wo;
+  d.TH = TH; d.TW = TW; d.tw_shift = TW == 64 ? 6 : (TW == 32 ? 5 : 4);
+  if (a.ups) { d.HTH = TH / 2 + 2; d.HTW = TW / 2 + 2; }
+  else { d.HTH = TH + 2; d.HTW = TW + 2; }
+  d.tiles_x = Wo / TW; d.tiles_per_img = d.tiles_x * (Ho / TH); d.n_sp = a.Nimg * d.tiles_per_img;
+  d.N = a.N; d.ldw = a.ldw;
+  const int bn = a.N > 64 ? 128 : 64;
+  d.tiles_n = cdiv(a.N, bn);
+  d.c_img = a.c_img; d.c_pix = a.c_pix; d.c_ch = a.c_ch; d.c_grp = a.c_grp > 0 ? a.c_grp : 1; d.c_grp_stride = a.c_grp_stride;
+  if (a.c_grp <= 1 && a.c_grp_stride == 0) d.c_grp_stride = a.c_img;
+  d.flags = a.flags;
+  d.hb_bytes = cdiv(d.HTH * d.HTW * 8, 512) * 8192;
+  if (2 * d.hb_bytes + 2 * bn * 128 > 160 * 1024) return -1;
+  if (((uintptr_t)a.X & 15) || ((uintptr_t)a.W & 15)) return -1;
+#define IVG_C3(T, BNv) (a.ups ? launch_c3<T, BNv, true>(d, a.Nimg, stream) : launch_c3<T, BNv, false>(d, a.Nimg, stream))
+  if (dtype == BF16) return bn == 128 ? IVG_C3(bf16_t, 128) : IVG_C3(bf16_t, 64);
+  return bn == 128 ? IVG_C3(float, 128) : IVG_C3(float, 64);
+#undef IVG_C3
+}
+
+}  // namespace ivg

@@ -41,8 +41,9 @@ struct Run {
                const float* uniforms, int top_k, int64_t* ids_out, float* reward_out);
 
   // ---- measurement
-  void prof_begin(DType dt, double flops, double bytes);
-  void prof_end(DType dt);
+  void prof_begin(DType dt, double flops, double bytes, int base = 0);   // base 0: igemm classes, 2: conv3x3 classes
+  void prof_end(DType dt, int base = 0);
+  void prof_cancel(DType dt, int base = 0);
 };
 
 size_t dtype_size(DType d);

@@ -42,6 +42,8 @@ struct IgemmArgs {
 
 // dtype = element type of X / W / R (and of Y unless IG_OUT_F32).  Returns hipError_t as int.
 int launch_igemm(const IgemmArgs& a, DType dtype, hipStream_t stream);
+// LDS-halo 3x3 stride-1 kernel (conv3x3.hip); returns -1 when the shape is not covered (use launch_igemm then)
+int launch_conv3x3(const IgemmArgs& a, DType dtype, hipStream_t stream);
 
 // Skinny GEMM for the autoregressive decode steps (M <= 128 rows, weights streamed once):
 //   Y[m][n] = epi( sum_k X[m][k] * W[n][k] ),  X row stride ldx, W row stride ldw.

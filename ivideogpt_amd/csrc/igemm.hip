@@ -15,6 +15,8 @@
 //     CONSECUTIVE output channels of one pixel, so the NHWC epilogue stores/loads 8-16 bytes per lane;
 //   * bf16: v_mfma_f32_16x16x32_bf16 (fp32 accumulate).  fp32: v_mfma_f32_16x16x4_f32, an exact
 //     fp32 fma chain -- used by the tokenize path where VQ indices must match the fp32 reference.
+#include <cstdlib>
+
 #include "igemm.h"
 
 namespace ivg {
@@ -32,7 +34,16 @@ struct IgemmDev {
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-template <typename T, int BM, int BN, int WM, int WN>
+// source of every out-of-image / out-of-range 16-byte chunk of the LDS-DMA path (zero-initialised device global)
+__device__ __attribute__((aligned(16))) unsigned char g_zero_chunk[16];
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_wave_base) {
+  // global -> LDS DMA, 16 B per lane; LDS destination = wave-uniform base + lane * 16 (cdna_hip_programming.md 5)
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <typename T, int BM, int BN, int WM, int WN, bool GLDS>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDev p) {
   constexpr int VEC = Traits<T>::VEC;
   constexpr int BK = 8 * VEC;  // one 128-byte row
@@ -109,6 +120,37 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDev p) {
   };
 
   const int wave = tid >> 6, lane = tid & 63;
+  // LDS-DMA staging: lane (r = lane>>3, slot = lane&7) of instruction i lands at row 8*wave + 32*i + r, slot `slot`
+  // (lane-linear destination); the XOR swizzle is applied on the SOURCE chunk index, reads are unchanged.
+  auto issue_tile = [&](int kt, int buf) {
+    const int k0 = kt * BK;
+    const int tap = p.single_tap ? 0 : k0 / p.Cin;
+    const int c0 = k0 - tap * p.Cin;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    unsigned char* sA = smem + buf * STAGE;
+    unsigned char* sB = sA + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int row = row0 + 32 * i;
+      const int c = chunk ^ ((row >> 1) & 7);
+      int ih = a_h[i] + kh, iw = a_w[i] + kw;
+      const bool ok = (ih >= 0) & (ih < h_lim) & (iw >= 0) & (iw < w_lim) & ((k0 + c * VEC) < p.K);
+      if (p.ups) { ih >>= 1; iw >>= 1; }
+      const void* src = ok ? (const void*)(X + ((long)(a_base[i] + ih * p.Win + iw) * p.ldx + c0 + c * VEC)) : (const void*)g_zero_chunk;
+      glds16(src, sA + (8 * wave + 32 * i) * 128);
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      if (8 * wave + 32 * i < BN) {
+        const int r = row0 + 32 * i;
+        const int c = chunk ^ ((r >> 1) & 7);
+        const int n = tile_n * BN + r;
+        const bool ok = (n < p.N) & ((k0 + c * VEC) < p.K);
+        const void* src = ok ? (const void*)(Wt + ((long)n * p.ldw + k0 + c * VEC)) : (const void*)g_zero_chunk;
+        glds16(src, sB + (8 * wave + 32 * i) * 128);
+      }
+    }
+  };
   const int wm = wave % WAVES_M, wn = wave / WAVES_M;
   const int lr = lane & 15, lg = lane >> 4;
 
@@ -119,12 +161,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDev p) {
     for (int b = 0; b < FM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (p.K + BK - 1) / BK;
-  load_tile(0);
-  store_tile(0);
+  if constexpr (GLDS) {
+    issue_tile(0, 0);
+  } else {
+    load_tile(0);
+    store_tile(0);
+  }
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);
+    if (kt + 1 < nk) {
+      if constexpr (GLDS) issue_tile(kt + 1, buf ^ 1);
+      else load_tile(kt + 1);
+    }
     const unsigned char* sA = smem + buf * STAGE;
     const unsigned char* sB = sA + A_BYTES;
 #pragma unroll
@@ -149,8 +198,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDev p) {
           }
         }
     }
-    if (kt + 1 < nk) store_tile(buf ^ 1);
-    __syncthreads();
+    if constexpr (!GLDS) {
+      if (kt + 1 < nk) store_tile(buf ^ 1);
+    }
+    __syncthreads();  // GLDS: the compiler drains the DMA (vmcnt(0)) in front of the barrier
   }
 
   // ---- epilogue: lane holds, per fragment, 4 consecutive n (= lg*4 + r) of pixel m (= lr)
@@ -228,11 +279,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDev p) {
   }
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
-static int launch_cfg(const IgemmDev& d, int nbatch, hipStream_t stream) {
+static bool use_glds() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("IVG_IGEMM_GLDS"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
+
+template <typename T, int BM, int BN, int WM, int WN, bool GLDS>
+static int launch_cfg2(const IgemmDev& d, int nbatch, hipStream_t stream) {
   constexpr int smem = 2 * (BM + BN) * 128;
   static bool attr_set = false;
-  auto kfn = igemm_kernel<T, BM, BN, WM, WN>;
+  auto kfn = igemm_kernel<T, BM, BN, WM, WN, GLDS>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
@@ -242,6 +299,11 @@ static int launch_cfg(const IgemmDev& d, int nbatch, hipStream_t stream) {
   dim3 grid((unsigned)tiles, (unsigned)nbatch, 1);
   hipLaunchKernelGGL(kfn, grid, dim3(256), smem, stream, d);
   return (int)hipGetLastError();
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+static int launch_cfg(const IgemmDev& d, int nbatch, hipStream_t stream) {
+  return use_glds() ? launch_cfg2<T, BM, BN, WM, WN, true>(d, nbatch, stream) : launch_cfg2<T, BM, BN, WM, WN, false>(d, nbatch, stream);
 }
 
 template <typename T>

@@ -40,8 +40,16 @@ int Run::conv(DType dt, const void* X, int N, int H, int W, const ConvW& c, void
   a.c_img = (long)Ho * Wo * c.cout; a.c_pix = c.cout; a.c_ch = 1;
   a.flags = flags | (c.b ? IG_BIAS_N : 0) | (Rres ? IG_RESIDUAL : 0) | (out_f32 ? IG_OUT_F32 : 0);
   if (planning) return 0;
-  prof_begin(dt, 2.0 * N * Ho * Wo * (double)c.cout * k * k * c.cin,
-             (double)esz(dt) * ((double)N * H * W * c.cin + (double)c.cout * k * k * c.cin) + (double)(out_f32 ? 4 : esz(dt)) * N * Ho * Wo * c.cout);
+  const double flops = 2.0 * N * Ho * Wo * (double)c.cout * k * k * c.cin;
+  const double bytes = (double)esz(dt) * ((double)N * H * W * c.cin + (double)c.cout * k * k * c.cin) + (double)(out_f32 ? 4 : esz(dt)) * N * Ho * Wo * c.cout;
+  if (k == 3 && stride == 1) {  // FLOP majority: LDS-halo kernel; shapes it does not cover fall through to the implicit GEMM
+    prof_begin(dt, flops, bytes, 2);
+    const int rc = launch_conv3x3(a, dt, st);
+    if (rc == 0) { prof_end(dt, 2); return 0; }
+    prof_cancel(dt, 2);
+    if (rc > 0) CK(rc);
+  }
+  prof_begin(dt, flops, bytes);
   CK(launch_igemm(a, dt, st));
   prof_end(dt);
   return 0;

@@ -104,6 +104,34 @@ def test_conv_modes(dt, mode):
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("H,Cin,Cout,ups,res", [(64, 128, 128, 0, 1), (32, 256, 512, 0, 0), (16, 512, 512, 1, 0), (32, 128, 64, 1, 1),
+                                                 (128, 64, 128, 0, 0), (16, 64, 192, 0, 1)])
+def test_conv3x3_halo_kernel(dt, H, Cin, Cout, ups, res):
+    """the LDS-halo 3x3 kernel (conv3x3.hip): every tile shape (16x16 / 8x32 / 4x64), multi-chunk Cin, several N tiles,
+    nearest-x2 upsampling folded into the halo gather, bias + in-place residual"""
+    g = torch.Generator().manual_seed(H + Cin + Cout)
+    Nb = 3
+    x = q(torch.randn(Nb, Cin, H, H, generator=g), dt)
+    w = q(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5, dt)
+    b = torch.randn(Cout, generator=g)
+    Ho = 2 * H if ups else H
+    xin = F.interpolate(x.double(), scale_factor=2.0, mode="nearest") if ups else x.double()
+    ref = F.conv2d(xin, w.double(), b.double(), padding=1)
+    r = q(torch.randn(Nb, Cout, Ho, Ho, generator=g), dt) if res else None
+    if res:
+        ref = ref + r.double()
+    X = x.permute(0, 2, 3, 1).contiguous().to(DEV, tdt(dt))
+    Wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(DEV, tdt(dt))
+    Y = torch.full((Nb, Ho, Ho, Cout), float("nan"), device=DEV, dtype=tdt(dt))
+    if res:
+        Y.copy_(r.permute(0, 2, 3, 1))   # in-place residual: R == Y
+    bd = b.to(DEV)
+    igemm(dt, X, Wp, Y, Y if res else None, bd, Nimg=Nb, Hin=H, Win=H, Cin=Cin, ldx=Cin, Hout=Ho, Wout=Ho, KH=3, KW=3, stride=1, pad=1,
+          ups=ups, N=Cout, ldw=9 * Cin, c_img=Ho * Ho * Cout, c_pix=Cout, flags=1 | (4 if res else 0))
+    assert rel_err(Y.float().permute(0, 3, 1, 2), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
 def test_conv_out_planar_video(dt):
     """Cout = 3 written straight into a planar (B, T, 3, H, W) fp32 clip at frame offsets (decoder tail)."""
     g = torch.Generator().manual_seed(9)
