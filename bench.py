@@ -35,13 +35,23 @@ PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MI
 PEAK_HBM_GBS = 8000.0
 
 
-def build_models(device, res, medium, enc, dec, llm):
+def build_models(device, res, medium, enc, dec, llm, action_dim=0, ctx=None, frames=16):
     tcfg = W.tokenizer_config(**(W.CTX_VAE64 if res == 64 else dict(W.CTX_VAE256, resolution=256, max_att_resolution=32)))
     lcfg = W.LLAMA_MEDIUM if medium else W.LLAMA_SMALL
     tsd = W.random_tokenizer_state_dict(tcfg, seed=0, codebook_std=0.4)
-    lsd = W.random_llama_state_dict(lcfg, seed=0)
     tok = CompressiveVQModel(tcfg, tsd, encode_dtype=enc, decode_dtype=dec).to(device)
-    model = LlamaForCausalLM(lcfg, lsd, dtype=llm).to(device)
+    if ctx is not None and ctx != tcfg["context_length"]:
+        tok.set_context_length(ctx)      # e.g. the BAIR checkpoints run with 1 context frame
+    c = tok.context_length
+    if action_dim:
+        from ivideogpt_amd import HeadModelWithAction
+        lsd = W.random_llama_state_dict(lcfg, seed=0, action_dim=action_dim)
+        model = HeadModelWithAction(LlamaForCausalLM(lcfg, None, dtype=llm), action_dim, 257 * c - 1, 16, c, frames)
+        model.load_state_dict(lsd, strict=True)
+        model.to(device)
+    else:
+        lsd = W.random_llama_state_dict(lcfg, seed=0)
+        model = LlamaForCausalLM(lcfg, lsd, dtype=llm).to(device)
     return tcfg, lcfg, tsd, lsd, tok, model
 
 
@@ -114,6 +124,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the CPU baseline (0: min(32, available cores))")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--greedy", action="store_true")
+    ap.add_argument("--action-dim", type=int, default=0, help=">0: action-conditioned HeadModelWithAction (BASELINE config 3: 4)")
+    ap.add_argument("--ctx", type=int, default=0, help="context frames (0: the tokenizer's pretrained context_length)")
     a = ap.parse_args()
 
     if a.cpu_baseline_worker:
@@ -126,15 +138,17 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    tcfg, lcfg, tsd, lsd, tok, model = build_models(dev, a.res, a.medium, a.encode_dtype, a.decode_dtype, a.llm_dtype)
-    ctx, B, T = tcfg["context_length"], a.batch, a.frames
+    tcfg, lcfg, tsd, lsd, tok, model = build_models(dev, a.res, a.medium, a.encode_dtype, a.decode_dtype, a.llm_dtype, a.action_dim,
+                                                    a.ctx or None, a.frames)
+    ctx, B, T = tok.context_length, a.batch, a.frames
     F = T - ctx
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     pixels = torch.rand(B, T, 3, a.res, a.res, device=dev, generator=g).to(torch.bfloat16)   # resident in HBM before timing
     sample_gen = torch.Generator(device=dev).manual_seed(2000 + rank)
+    actions = torch.randn(B, T, a.action_dim, device=dev, generator=g) if a.action_dim else None
 
     def step():
-        frames = predict_frames(tok, model, pixels, ctx, F, do_sample=not a.greedy, top_k=100, generator=sample_gen)
+        frames = predict_frames(tok, model, pixels, ctx, F, actions=actions, do_sample=not a.greedy, top_k=100, generator=sample_gen)
         rows = frame_metrics(frames[:, ctx:], pixels[:, ctx:])
         return frames, parallel.gather_metric_rows_even(rows)
 
@@ -143,7 +157,8 @@ def main():
     torch.cuda.synchronize()
     assert torch.isfinite(frames).all() and rows.shape[0] == world * B
 
-    prof_engines = [tok._engine, model._engine]
+    llm_engine = (model.llm if a.action_dim else model)._engine
+    prof_engines = [tok._engine, llm_engine]
     kclass = _lib.IVG_K_IGEMM_BF16 if a.decode_dtype == "bf16" else _lib.IVG_K_IGEMM_F32
     for e in prof_engines:
         e.profile_read(kclass)
@@ -171,7 +186,8 @@ def main():
     ev[0].record()
     prompt = tok.encode_context(pixels, ctx)
     ev[1].record()
-    toks = model.generate(prompt, do_sample=not a.greedy, top_k=100, max_new_tokens=17 * F - 1, generator=sample_gen)
+    kw = {"action": actions} if a.action_dim else {}
+    toks = model.generate(prompt, do_sample=not a.greedy, top_k=100, max_new_tokens=17 * F - 1, generator=sample_gen, **kw)
     ev[2].record()
     tok.detokenize(toks, ctx).clamp_(0, 1)
     ev[3].record()
@@ -190,7 +206,7 @@ def main():
             "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"ivideogpt-oxe-{a.res}-act-free{'-medium' if a.medium else ''}: synthetic {a.res}x{a.res} bf16 clips, "
+            "config": {"workload": f"ivideogpt-{'bair' if a.action_dim else 'oxe'}-{a.res}-{'act-cond' if a.action_dim else 'act-free'}{'-medium' if a.medium else ''}: synthetic {a.res}x{a.res} bf16 clips, "
                                    f"{B} trajectories per GPU, {ctx} context + {F} predicted frames, top-k 100 sampling, seeded random weights",
                        "global_batch": world * B, "frames": T, "resolution": a.res,
                        "arith": {"encode": a.encode_dtype, "rollout": a.llm_dtype, "decode": a.decode_dtype},

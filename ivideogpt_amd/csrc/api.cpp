@@ -255,6 +255,8 @@ void ivg_destroy(ivg_engine* e) {
   (void)hipSetDevice(e->device);
   (void)hipDeviceSynchronize();
   for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
+  if (e->fork_ev) (void)hipEventDestroy(e->fork_ev);
+  for (int i = 0; i < 7; ++i) { if (e->join_ev[i]) (void)hipEventDestroy(e->join_ev[i]); if (e->side[i]) (void)hipStreamDestroy(e->side[i]); }
   for (int k = 0; k < IVG_K_COUNT; ++k) {
     for (auto& s : e->prof[k].used) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto& s : e->prof[k].pool) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
@@ -311,6 +313,15 @@ int ivg_create(const ivg_config* cfg, const ivg_tensor* weights, int n_weights, 
     }
     (void)hipMemset(e->vt, 0, vtb);
     (void)hipMemset(e->gen_buf, 0, e->gen_bytes);
+    {
+      const char* ch = getenv("IVG_CHAINS");
+      if (ch) e->chains = std::max(1, std::min(8, atoi(ch)));
+      bool ok = hipEventCreateWithFlags(&e->fork_ev, hipEventDisableTiming) == hipSuccess;
+      for (int i = 0; i < 7 && ok; ++i)
+        ok = hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&e->join_ev[i], hipEventDisableTiming) == hipSuccess;
+      if (!ok) { e->err = "could not create the side streams of the decode step"; return bail(IVG_ERR_HIP); }
+    }
   }
   int rc = plan_and_allocate(e);
   if (rc) return bail(rc);

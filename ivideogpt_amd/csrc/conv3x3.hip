@@ -41,7 +41,8 @@ __device__ __forceinline__ void glds16b(const void* gsrc, unsigned char* lds_wav
 }
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-template <typename T, int BN, bool UPS>
+// ABL (development ablations, 0 in production): 1 no MFMA, 2 no LDS reads + no MFMA, 4 no halo DMA, 8 no weight DMA
+template <typename T, int BN, bool UPS, int ABL = 0>
 __global__ __launch_bounds__(512) void conv3x3_kernel(const Conv3Dev p) {
   constexpr int VEC = Traits<T>::VEC;
   constexpr int CK = 8 * VEC;              // channels per chunk: one 128-byte LDS row per halo pixel
@@ -124,10 +125,14 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const Conv3Dev p) {
   __syncthreads();
   for (int s = 0; s < steps; ++s) {
     const int chunk = s / 9, tap = s - chunk * 9;
-    if (s + 1 < steps) issue_w(s + 1, wbuf0 + ((s + 1) & 1) * W_BYTES);
-    if (chunk + 1 < nchunks && tap < halo_iters) issue_halo_piece(chunk + 1, tap, hbuf0 + ((chunk + 1) & 1) * p.hb_bytes);
-    if (chunk + 1 < nchunks && tap == 8)
-      for (int it = 9; it < halo_iters; ++it) issue_halo_piece(chunk + 1, it, hbuf0 + ((chunk + 1) & 1) * p.hb_bytes);
+    if constexpr (!(ABL & 8)) {
+      if (s + 1 < steps) issue_w(s + 1, wbuf0 + ((s + 1) & 1) * W_BYTES);
+    }
+    if constexpr (!(ABL & 4)) {
+      if (chunk + 1 < nchunks && tap < halo_iters) issue_halo_piece(chunk + 1, tap, hbuf0 + ((chunk + 1) & 1) * p.hb_bytes);
+      if (chunk + 1 < nchunks && tap == 8)
+        for (int it = 9; it < halo_iters; ++it) issue_halo_piece(chunk + 1, it, hbuf0 + ((chunk + 1) & 1) * p.hb_bytes);
+    }
     const unsigned char* hb = hbuf0 + (chunk & 1) * p.hb_bytes;
     const unsigned char* wb = wbuf0 + (s & 1) * W_BYTES;
     const int kh = tap / 3, kw = tap - kh * 3;
@@ -139,12 +144,20 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const Conv3Dev p) {
     }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
+      if constexpr (ABL & 2) break;
       const int c = kk * 4 + lg;
       Chunk16 xa[FM], wv[FN];
 #pragma unroll
       for (int b = 0; b < FM; ++b) xa[b] = *(const Chunk16*)(hb + swz(hr[b], c));
 #pragma unroll
       for (int a = 0; a < FN; ++a) wv[a] = *(const Chunk16*)(wb + swz(wn * WN + a * 16 + lr, c));
+      if constexpr (ABL & 1) {
+#pragma unroll
+        for (int b = 0; b < FM; ++b) asm volatile("" :: "v"(xa[b]));
+#pragma unroll
+        for (int a = 0; a < FN; ++a) asm volatile("" :: "v"(wv[a]));
+        continue;
+      }
 #pragma unroll
       for (int a = 0; a < FN; ++a)
 #pragma unroll
@@ -223,11 +236,11 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const Conv3Dev p) {
   }
 }
 
-template <typename T, int BN, bool UPS>
+template <typename T, int BN, bool UPS, int ABL = 0>
 static int launch_c3(const Conv3Dev& d, int nimg, hipStream_t stream) {
   const int smem = 2 * d.hb_bytes + 2 * BN * 128;
   static int attr_set = 0;
-  auto kfn = conv3x3_kernel<T, BN, UPS>;
+  auto kfn = conv3x3_kernel<T, BN, UPS, ABL>;
   if (attr_set < smem) {
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
@@ -273,6 +286,21 @@ int launch_conv3x3(const IgemmArgs& a, DType dtype, hipStream_t stream) {
   d.hb_bytes = cdiv(d.HTH * d.HTW * 8, 512) * 8192;
   if (2 * d.hb_bytes + 2 * bn * 128 > 160 * 1024) return -1;
   if (((uintptr_t)a.X & 15) || ((uintptr_t)a.W & 15)) return -1;
+  {  // development ablations of the bf16 / BN = 128 / no-upsample instance (IVG_C3_ABLATE=<mask>)
+    static int abl = -1;
+    if (abl < 0) { const char* e = getenv("IVG_C3_ABLATE"); abl = e ? atoi(e) : 0; }
+    if (abl && dtype == BF16 && bn == 128 && !a.ups) {
+      switch (abl) {
+        case 1: return launch_c3<bf16_t, 128, false, 1>(d, a.Nimg, stream);
+        case 2: return launch_c3<bf16_t, 128, false, 2>(d, a.Nimg, stream);
+        case 4: return launch_c3<bf16_t, 128, false, 4>(d, a.Nimg, stream);
+        case 8: return launch_c3<bf16_t, 128, false, 8>(d, a.Nimg, stream);
+        case 12: return launch_c3<bf16_t, 128, false, 12>(d, a.Nimg, stream);
+        case 14: return launch_c3<bf16_t, 128, false, 14>(d, a.Nimg, stream);
+        default: break;
+      }
+    }
+  }
 #define IVG_C3(T, BNv) (a.ups ? launch_c3<T, BNv, true>(d, a.Nimg, stream) : launch_c3<T, BNv, false>(d, a.Nimg, stream))
   if (dtype == BF16) return bn == 128 ? IVG_C3(bf16_t, 128) : IVG_C3(bf16_t, 64);
   return bn == 128 ? IVG_C3(float, 128) : IVG_C3(float, 64);

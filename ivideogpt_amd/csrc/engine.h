@@ -86,6 +86,11 @@ struct ivg_engine {
   size_t gen_bytes = 0;
   std::unordered_map<std::string, hipGraphExec_t> graphs;
   bool use_graph = true;
+  int chains = 1;            // concurrent dependency chains (measured: no gain on MI355X, graph branches serialise; IVG_CHAINS=n to try)
+                             // of a decode step of a decode step (batch rows split across side streams)
+  hipStream_t side[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t fork_ev = nullptr;
+  hipEvent_t join_ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   ivg::ProfClass prof[IVG_K_COUNT];
 
   int fail(int code, const std::string& msg) { err = msg; return code; }

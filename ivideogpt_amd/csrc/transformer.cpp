@@ -21,9 +21,12 @@ static size_t esz(DType d) { return d == BF16 ? 2 : 4; }
 static size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct GenBuf {  // persistent decode-step buffers (fixed addresses so the captured step graph can be replayed)
-  StepState* state; char* x; char* qkv; char* attn; char* act; float* logits;
+  StepState* state;  // [MAX_CHAINS], one per concurrent chain, 256 B apart
+  char* x; char* qkv; char* attn; char* act; float* logits;
   int64_t* ids; float* uni; char* act_emb; int Bc, ids_ld;
 };
+constexpr int MAX_CHAINS = 8;
+static StepState* chain_state(const GenBuf& g, int c) { return (StepState*)((char*)g.state + 256 * c); }
 
 static int gen_chunk(const ivg_engine* e) { return std::min(e->cfg.max_batch, 128); }
 
@@ -35,7 +38,7 @@ static void gen_layout(const ivg_engine* e, GenBuf& g, char* base, size_t* total
   g.ids_ld = e->Lmax;
   size_t off = 0;
   auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off = rup(off + bytes, 256); return p; };
-  g.state = (StepState*)take(sizeof(StepState));
+  g.state = (StepState*)take(256 * MAX_CHAINS);
   g.x = take((size_t)Bc * H * esz(dt));
   g.qkv = take((size_t)Bc * 3 * H * esz(dt));
   g.attn = take((size_t)Bc * H * esz(dt));
@@ -151,10 +154,26 @@ int Run::prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const voi
 // -------------------------------------------------------------------------------------------- one decode step
 // decide token j (sample / forced), embed it, run it through the layers against the KV cache, produce the
 // logits for token j+1, advance the device-side state.
-static int step_body(ivg_engine* e, hipStream_t st, const GenBuf& g, int B, const SampleArgs& sa, bool forward) {
+// One chain = rows [b0, b0 + B) of the generate batch: its own dependency chain, state counters and buffer slices.
+static int step_chain(ivg_engine* e, hipStream_t st, const GenBuf& g, int chain, int b0, int B, const SampleArgs& sa0, bool forward) {
   const ivg_config& c = e->cfg;
   const DType dt = e->llm_dt;
   const int H = c.hidden_size, I = c.intermediate_size, V = c.vocab_size;
+  const size_t es = esz(dt);
+  StepState* state = chain_state(g, chain);
+  char* x = g.x + (size_t)b0 * H * es;
+  char* qkv = g.qkv + (size_t)b0 * 3 * H * es;
+  char* attn = g.attn + (size_t)b0 * H * es;
+  char* act = g.act + (size_t)b0 * I * es;
+  float* logits = g.logits + (size_t)b0 * V;
+  const size_t kv_off = (size_t)b0 * e->heads * e->Lmax * e->hd * es;
+  SampleArgs sa = sa0;
+  sa.logits = logits;
+  if (sa.uniforms) sa.uniforms += (size_t)b0 * sa.n_uni;
+  sa.ids_out += (size_t)b0 * sa.ids_stride;
+  sa.x = x;
+  if (sa.act) sa.act = (const char*)sa.act + (size_t)b0 * sa.act_T * H * es;
+  sa.state = state;
   CK(launch_sample_embed(sa, B, dt, st));
   if (!forward) return 0;
   // 5 launches per layer: RMSNorms are fused into the consuming GEMMs (weights pre-multiplied by the norm weight,
@@ -162,27 +181,47 @@ static int step_body(ivg_engine* e, hipStream_t st, const GenBuf& g, int B, cons
   for (int l = 0; l < c.num_layers; ++l) {
     const LayerW& w = e->layers[l];
     SkinnyArgs s;
-    s.X = g.x; s.W = w.wqkv; s.Y = g.qkv; s.M = B; s.N = 3 * H; s.K = H; s.ldx = H; s.ldw = H; s.ldy = 3 * H;
+    s.X = x; s.W = w.wqkv; s.Y = qkv; s.M = B; s.N = 3 * H; s.K = H; s.ldx = H; s.ldw = H; s.ldy = 3 * H;
     s.flags = SK_NORM; s.eps = c.rms_norm_eps;
     CK(launch_skinny(s, dt, st));
-    CK(launch_decode_attn(g.qkv, kc_ptr(e, l, 0), kc_ptr(e, l, 1), g.attn, e->rope_cos, e->rope_sin, B, e->heads, e->hd, e->Lmax,
-                          g.state, dt, st));
+    CK(launch_decode_attn(qkv, kc_ptr(e, l, 0) + kv_off, kc_ptr(e, l, 1) + kv_off, attn, e->rope_cos, e->rope_sin, B, e->heads, e->hd,
+                          e->Lmax, state, dt, st));
     SkinnyArgs o;
-    o.X = g.attn; o.W = w.wo; o.Y = g.x; o.M = B; o.N = H; o.K = H; o.ldx = H; o.ldw = H; o.ldy = H; o.flags = IG_RESIDUAL;
+    o.X = attn; o.W = w.wo; o.Y = x; o.M = B; o.N = H; o.K = H; o.ldx = H; o.ldw = H; o.ldy = H; o.flags = IG_RESIDUAL;
     CK(launch_skinny(o, dt, st));
     SkinnyArgs u;
-    u.X = g.x; u.W = w.wgu; u.Y = g.act; u.M = B; u.N = 2 * I; u.K = H; u.ldx = H; u.ldw = H; u.ldy = I;
+    u.X = x; u.W = w.wgu; u.Y = act; u.M = B; u.N = 2 * I; u.K = H; u.ldx = H; u.ldw = H; u.ldy = I;
     u.flags = IG_GLU | SK_NORM; u.eps = c.rms_norm_eps;
     CK(launch_skinny(u, dt, st));
     SkinnyArgs d;
-    d.X = g.act; d.W = w.wdown; d.Y = g.x; d.M = B; d.N = H; d.K = I; d.ldx = I; d.ldw = I; d.ldy = H; d.flags = IG_RESIDUAL;
+    d.X = act; d.W = w.wdown; d.Y = x; d.M = B; d.N = H; d.K = I; d.ldx = I; d.ldw = I; d.ldy = H; d.flags = IG_RESIDUAL;
     CK(launch_skinny(d, dt, st));
   }
   SkinnyArgs lm;
-  lm.X = g.x; lm.W = e->lm_head; lm.Y = g.logits; lm.M = B; lm.N = V; lm.K = H; lm.ldx = H; lm.ldw = H; lm.ldy = V;
+  lm.X = x; lm.W = e->lm_head; lm.Y = logits; lm.M = B; lm.N = V; lm.K = H; lm.ldx = H; lm.ldw = H; lm.ldy = V;
   lm.flags = IG_OUT_F32 | SK_NORM; lm.eps = c.rms_norm_eps;
-  lm.bump = (int*)g.state;  // pos += 1, j += 1 once the last reader of the state (the last layer's attention) is done
+  lm.bump = (int*)state;  // pos += 1, j += 1 once the last reader of this chain's state (its last attention) is done
   CK(launch_skinny(lm, dt, st));
+  return 0;
+}
+
+// A decode step of the whole batch: the rows are split into `nc` chains that run CONCURRENTLY on side streams (fork /
+// join by events; under stream capture this becomes one graph with nc parallel branches).  Every kernel of a step is
+// latency- or per-CU-ingest-bound and uses a fraction of the chip, so independent chains overlap almost for free and
+// the HBM-bound attention of one chain hides the launch latencies of the others.
+static int step_body(ivg_engine* e, hipStream_t st, const GenBuf& g, int B, int nc, int cs, const SampleArgs& sa, bool forward) {
+  if (nc <= 1) return step_chain(e, st, g, 0, 0, B, sa, forward);
+  CK((int)hipEventRecord(e->fork_ev, st));
+  for (int c = 1; c < nc; ++c) CK((int)hipStreamWaitEvent(e->side[c - 1], e->fork_ev, 0));
+  for (int c = 0; c < nc; ++c) {
+    const int b0 = c * cs, bc = std::min(cs, B - b0);
+    if (bc <= 0) continue;
+    IVG_TRY(step_chain(e, c == 0 ? st : e->side[c - 1], g, c, b0, bc, sa, forward));
+  }
+  for (int c = 1; c < nc; ++c) {
+    CK((int)hipEventRecord(e->join_ev[c - 1], e->side[c - 1]));
+    CK((int)hipStreamWaitEvent(st, e->join_ev[c - 1], 0));
+  }
   return 0;
 }
 
@@ -208,7 +247,12 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
     if (actions)
       CK(launch_action_embed(actions + (long)b0 * act_T * c.action_dim, e->act_w, e->act_b, g.act_emb, dt, Bc * act_T, c.action_dim, H, st));
     IVG_TRY(prefill(g.ids, g.ids_ld, Bc, L0, actions ? g.act_emb : nullptr, act_T, ctx, false, nullptr, g.logits, g.x));
-    CK(launch_state_set(g.state, L0, 1, st));
+    // chains: rows split into up to e->chains groups of a multiple of 16 rows
+    int nc = std::max(1, std::min(e->chains, MAX_CHAINS));
+    int cs = ((Bc + nc - 1) / nc + 15) / 16 * 16;
+    nc = (Bc + cs - 1) / cs;
+    if (st == nullptr) { nc = 1; cs = Bc; }  // side streams cannot fork from the legacy default stream under capture
+    for (int c = 0; c < nc; ++c) CK(launch_state_set(chain_state(g, c), L0, 1, st));
     SampleArgs sa;
     sa.logits = g.logits; sa.V = V;
     sa.uniforms = uniforms ? g.uni : nullptr; sa.n_uni = g.ids_ld;
@@ -219,11 +263,11 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
     sa.act = actions ? g.act_emb : nullptr; sa.act_T = act_T; sa.ctx = ctx;
     sa.state = g.state;
     // step 1 eagerly (also performs every kernel's one-time attribute setup), then replay a captured step graph
-    const std::string key = std::to_string(Bc) + ":" + (uniforms ? "s" : "g") + ":" + std::to_string(top_k) + ":" +
+    const std::string key = std::to_string(Bc) + ":" + std::to_string(nc) + ":" + (uniforms ? "s" : "g") + ":" + std::to_string(top_k) + ":" +
                             std::to_string(sa.forced_period) + ":" + std::to_string(ctx) + ":" + std::to_string(act_T) + ":" +
                             std::to_string(L0);
     int j = 1;
-    if (n_new >= 1) { IVG_TRY(step_body(e, st, g, Bc, sa, j < n_new)); ++j; }
+    if (n_new >= 1) { IVG_TRY(step_body(e, st, g, Bc, nc, cs, sa, j < n_new)); ++j; }
     hipGraphExec_t exec = nullptr;
     if (e->use_graph && st != nullptr && j < n_new) {
       auto it = e->graphs.find(key);
@@ -232,7 +276,7 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
       } else {
         hipGraph_t graph = nullptr;
         if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-          const int rc = step_body(e, st, g, Bc, sa, true);
+          const int rc = step_body(e, st, g, Bc, nc, cs, sa, true);
           const hipError_t ce = hipStreamEndCapture(st, &graph);
           if (rc == 0 && ce == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
             e->graphs[key] = exec;
@@ -248,9 +292,9 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
     }
     for (; j < n_new; ++j) {
       if (exec) CK((int)hipGraphLaunch(exec, st));
-      else IVG_TRY(step_body(e, st, g, Bc, sa, true));
+      else IVG_TRY(step_body(e, st, g, Bc, nc, cs, sa, true));
     }
-    if (j == n_new && n_new > 1) IVG_TRY(step_body(e, st, g, Bc, sa, false));  // decide the last token (no forward)
+    if (j == n_new && n_new > 1) IVG_TRY(step_body(e, st, g, Bc, nc, cs, sa, false));  // decide the last token (no forward)
     CK((int)hipMemcpy2DAsync(ids_out + (long)b0 * Ltot, (size_t)Ltot * 8, g.ids, (size_t)g.ids_ld * 8, (size_t)Ltot * 8, Bc,
                              hipMemcpyDeviceToDevice, st));
     if (reward_out) {

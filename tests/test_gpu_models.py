@@ -179,6 +179,24 @@ def test_generate_graph_replay_equals_eager(monkeypatch):
     assert torch.equal(a, b)
 
 
+def test_generate_multichain_equals_single_chain_and_oracle(monkeypatch):
+    """B = 40 rows run as 3 concurrent chains (16 + 16 + 8 rows on side streams, one fork/join graph per token): same
+    tokens as the single-chain engine, and rows match the oracle (sampled with explicit uniforms)."""
+    from oracle.llama import generate_cached
+    cfg, sd, g = llama_fixture("llama_tiny_ctx1_free.npz")
+    gen = torch.Generator().manual_seed(9)
+    prompt = torch.randint(0, 8192, (40, 257), generator=gen)
+    prompt[:, -1] = cfg["vocab_size"] - 1
+    u = torch.rand(40, 36, generator=gen)
+    a = make_llm(cfg, sd).generate(prompt.to(DEV), do_sample=True, top_k=100, max_new_tokens=36, uniforms=u.to(DEV)).cpu()
+    monkeypatch.setenv("IVG_CHAINS", "1")
+    b = make_llm(cfg, sd).generate(prompt.to(DEV), do_sample=True, top_k=100, max_new_tokens=36, uniforms=u.to(DEV)).cpu()
+    assert torch.equal(a, b), f"{(a != b).sum().item()} tokens differ between 3-chain and 1-chain runs"
+    rows = [0, 15, 16, 31, 32, 39]
+    ref = generate_cached(oracle_llama(cfg, sd), prompt[rows], 36, top_k=100, uniforms=u[rows])
+    assert torch.equal(a[rows], ref)
+
+
 # ------------------------------------------------------------------------------------------------ full width
 def test_full_width_64_tokenizer_vs_oracle():
     """ctx_vae64 shapes (114 M parameters), one trajectory: HIP fp32 vs the CPU oracle run here."""
