@@ -400,7 +400,11 @@ int ivg_generate(ivg_engine* e, const int64_t* prompt, int64_t prompt_stride, in
   if (B <= 0 || n_new < 1 || L0 < 1 || L0 + n_new > e->Lmax)
     return e->fail(IVG_ERR_CAPACITY, "generate: sequence of " + std::to_string(L0 + n_new) + " tokens exceeds the KV cache (" + std::to_string(e->Lmax) + ")");
   if (actions && (e->cfg.action_dim <= 0 || !e->act_w)) return e->fail(IVG_ERR_INVALID, "generate: actions given but the model is action-free");
-  if (actions && (act_T > e->cfg.max_frames || ((n_new + 1) / 17) + ctx - 1 > act_T)) return e->fail(IVG_ERR_INVALID, "generate: action tensor too short / longer than max_frames");
+  if (actions) {
+    if (L0 < 257 * ctx || (L0 - 257 * ctx) % 17 != 0) return e->fail(IVG_ERR_INVALID, "generate: action-conditioned prompt must hold 257*ctx + 17*t tokens");
+    const int last = (L0 - 257 * ctx) / 17 + n_new / 17 + ctx - 1;  // highest action row read (prompt slots + forced sdf slots)
+    if (last >= act_T || act_T > e->cfg.max_frames) return e->fail(IVG_ERR_INVALID, "generate: action tensor too short (or longer than max_frames)");
+  }
   return plan_then_run(e, (hipStream_t)stream, [&](Run& r) {
     return r.generate(prompt, prompt_stride, B, L0, n_new, actions, act_T, ctx, uniforms, top_k, ids_out, reward_out); });
 }

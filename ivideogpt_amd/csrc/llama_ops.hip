@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void sample_embed_kernel(SampleArgs a) {
   const T* src = (const T*)a.E + tok * a.H;
   T* dst = (T*)a.x + (long)b * a.H;
   const T* act = nullptr;
-  if (forced && a.act) act = (const T*)a.act + ((long)b * a.act_T + (j / a.forced_period + a.ctx - 1)) * a.H;
+  if (forced && a.act) act = (const T*)a.act + ((long)b * a.act_T + (a.slot0 + j / a.forced_period + a.ctx - 1)) * a.H;
   for (int c = tid; c < a.H; c += 256) {
     float val = to_f32(src[c]);
     if (act) val += to_f32(act[c]);

@@ -66,7 +66,8 @@ struct SampleArgs {
   int64_t* ids_out; long ids_stride; int L0;   // ids_out[b*ids_stride + L0 + j - 1] = token j
   int forced_period; int64_t forced_token;     // j % period == 0 -> forced token (0 = never)
   const void* E; void* x; int H;               // next input embedding x[b][:] (T)
-  const void* act; int act_T; int ctx;         // act[B][act_T][H] (T) or null: added on forced slots with index j/period + ctx - 1
+  const void* act; int act_T; int ctx;         // act[B][act_T][H] (T) or null: added on forced slots, index slot0 + j/period + ctx - 1
+  int slot0;                                   // sdf slots already inside the prompt beyond the first: (L0 - 257*ctx) / 17
   StepState* state;
 };
 int launch_sample_embed(const SampleArgs& a, int B, DType dt, hipStream_t st);

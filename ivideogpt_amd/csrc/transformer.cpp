@@ -246,7 +246,7 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
                                hipMemcpyDeviceToDevice, st));
     if (actions)
       CK(launch_action_embed(actions + (long)b0 * act_T * c.action_dim, e->act_w, e->act_b, g.act_emb, dt, Bc * act_T, c.action_dim, H, st));
-    IVG_TRY(prefill(g.ids, g.ids_ld, Bc, L0, actions ? g.act_emb : nullptr, act_T, ctx, false, nullptr, g.logits, g.x));
+    IVG_TRY(prefill(g.ids, g.ids_ld, Bc, L0, actions ? g.act_emb : nullptr, act_T, ctx, true, nullptr, g.logits, g.x));
     // chains: rows split into up to e->chains groups of a multiple of 16 rows
     int nc = std::max(1, std::min(e->chains, MAX_CHAINS));
     int cs = ((Bc + nc - 1) / nc + 15) / 16 * 16;
@@ -261,6 +261,7 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
     sa.forced_period = actions ? 17 : 0; sa.forced_token = V - 1;
     sa.E = e->embed; sa.x = g.x; sa.H = H;
     sa.act = actions ? g.act_emb : nullptr; sa.act_T = act_T; sa.ctx = ctx;
+    sa.slot0 = actions ? (L0 - 257 * ctx) / 17 : 0;  // a prompt that already holds t generated frames (MBRL step-wise rollout)
     sa.state = g.state;
     // step 1 eagerly (also performs every kernel's one-time attribute setup), then replay a captured step graph
     const std::string key = std::to_string(Bc) + ":" + std::to_string(nc) + ":" + (uniforms ? "s" : "g") + ":" + std::to_string(top_k) + ":" +

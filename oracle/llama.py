@@ -120,12 +120,20 @@ def generate_cached(model, input_ids, n_new, top_k=100, uniforms=None, action_em
     B, L0 = input_ids.shape
     x = model.embed(input_ids)
     per = tokens_per_dyn + 1
+    slot0 = 0
     if action_embeds is not None:
+        # every sdf slot already inside the prompt carries its action (slot i at position 257*ctx - 1 + 17*i reads row
+        # i + ctx - 1): one slot for a plain 257*ctx prompt (action_model.py:80-81); t + 1 slots for the step-wise MBRL
+        # rollout, whose embeddings keep the actions added at earlier steps (mbrl/video_predictor.py:295-296, 315-316)
         x = x.clone()
-        x[:, -1] += action_embeds[:, ctx - 1]
-    logits, past = model.forward_embeds(x)
+        slot0 = (L0 - 257 * ctx) // per
+        for i in range(slot0 + 1):
+            x[:, 257 * ctx - 1 + per * i] += action_embeds[:, i + ctx - 1]
+    out_h = model.forward_embeds(x, return_hidden=True)
+    logits, past, hid = out_h
     out = [input_ids]
     last = logits[:, -1]
+    last_hidden = hid[:, -1]
     for j in range(1, n_new + 1):
         forced = action_embeds is not None and j % per == 0
         if forced:
@@ -137,10 +145,12 @@ def generate_cached(model, input_ids, n_new, top_k=100, uniforms=None, action_em
             break
         e = model.embed(tok[:, None])
         if forced:
-            e = e + action_embeds[:, j // per + ctx - 1][:, None]
-        logits, past = model.forward_embeds(e, past)
+            e = e + action_embeds[:, slot0 + j // per + ctx - 1][:, None]
+        logits, past, hid = model.forward_embeds(e, past, return_hidden=True)
         last = logits[:, -1]
-    return torch.cat(out, 1)
+        last_hidden = hid[:, -1]
+    ids = torch.cat(out, 1)
+    return (ids, last_hidden) if return_last_hidden else ids
 
 
 @torch.no_grad()

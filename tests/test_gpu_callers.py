@@ -1,0 +1,157 @@
+"""The boundary callers on the MI355X (-m gpu): the drop-ins for inference/predict.py, vp/ivideogpt_interface.py and
+mbrl/video_predictor.py::rollout run end to end on seeded random checkpoints in the reference's on-disk layout and are
+checked against the CPU oracle fed the same uniforms (fp32 engine mode: tokens identical, pixels within 1e-3)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import oracle_llama, oracle_tokenizer
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = "cuda:0"
+
+TOK_CFG = dict(block_out_channels=(64, 128, 128), layers_per_block=1, latent_channels=64, num_vq_embeddings=512,
+               num_dyn_embeddings=512, mid_block_add_attention=False, context_length=2, resolution=64, max_att_resolution=16)
+LLM_CFG = dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=2,
+               rms_norm_eps=1e-6, rope_theta=10000.0, max_position_embeddings=1024, vocab_size=1026)
+
+
+def write_checkpoint(path, action_dim=None, reward=False):
+    from ivideogpt_amd import weights as W
+    tcfg = W.tokenizer_config(**TOK_CFG)
+    tsd = W.random_tokenizer_state_dict(tcfg, 51, codebook_std=0.4)
+    lsd = W.random_llama_state_dict(LLM_CFG, 52, action_dim=action_dim, reward_prediction=reward)
+    W.save_tokenizer_checkpoint(path, tcfg, tsd, "tokenizer")
+    W.save_transformer_checkpoint(path, LLM_CFG, lsd, "transformer")
+    return tcfg, tsd, lsd
+
+
+def test_predict_cli_matches_oracle(tmp_path, monkeypatch):
+    sys.path.insert(0, os.path.join(ROOT, "inference"))
+    import importlib
+    predict = importlib.import_module("predict")
+    from oracle.llama import generate_cached
+    ck = str(tmp_path / "ckpt")
+    tcfg, tsd, lsd = write_checkpoint(ck)
+    rng = np.random.default_rng(1)
+    ep = rng.integers(0, 256, (12, 64, 64, 3), dtype=np.uint8)
+    np.savez(tmp_path / "clip.npz", image=ep)
+    out_dir = str(tmp_path / "out")
+    argv = ["--pretrained_model_name_or_path", ck, "--input_path", str(tmp_path / "clip.npz"), "--dataset_name", "fractal20220817_data",
+            "--output_path", out_dir, "--context_length", "2", "--segment_length", "5", "--repeat_times", "3", "--seed", "7", "--dtype", "fp32"]
+    rec = predict.main(argv).cpu()
+    saved = np.load(os.path.join(out_dir, "pred-samples.npz"))
+    assert saved["frames"].shape == (3, 5, 64, 128, 3) and rec.shape == (3, 5, 3, 64, 64)
+    # replicate: same seed -> same segment start (np.random) and the same uniforms (torch.rand on the GPU)
+    predict.set_seed(7)
+    from ivideogpt_amd.data import NPZParser
+    frames, _ = NPZParser(5, 64).parse(str(tmp_path / "clip.npz"), "fractal20220817_data")
+    u = torch.rand(3, 17 * 3 - 1, device=DEV).cpu()
+    tok, llm = oracle_tokenizer(tcfg, tsd, 2), oracle_llama(LLM_CFG, lsd)
+    ids_ref, _ = tok.tokenize(frames[None], 2)
+    out_ref = generate_cached(llm, ids_ref[:, :514].repeat(3, 1), 17 * 3 - 1, top_k=100, uniforms=u)
+    assert np.array_equal(saved["tokens"], out_ref.numpy()), "CLI tokens differ from the oracle rollout"
+    rec_ref = tok.detokenize(out_ref, 2).clamp(0, 1)
+    assert (rec - rec_ref).abs().max().item() < 1e-3
+
+
+def test_vp2_interface(tmp_path):
+    sys.path.insert(0, ROOT)
+    from vp.ivideogpt_interface import iVideoGPTPredictor
+    from oracle.llama import generate_cached
+    ck = str(tmp_path / "ckpt")
+    tcfg, tsd, lsd = write_checkpoint(ck, action_dim=4)
+    with open(os.path.join(ck, "llama_cfg.json"), "w") as f:
+        json.dump(LLM_CFG, f)
+    pred = iVideoGPTPredictor(os.path.join(ck, "llama_cfg.json"), seed=3, vqgan_type="ctx_vqgan",
+                              pretrained_vqgan_name_or_path=os.path.join(ck, "tokenizer"),
+                              pretrained_transformer_path=os.path.join(ck, "transformer"), action_dim=4,
+                              generate_max_batchsize=2, decode_max_batchsize=2, action_recon=None, lora=False, lora_r=8, lora_alpha=32,
+                              lora_dropout=0.0, dtype="fp32")
+    assert pred.num_context == 2 and pred.base_prediction_modality == "rgb"
+    g = torch.Generator().manual_seed(4)
+    batch = {"video": torch.rand(3, 2, 64, 64, 3, generator=g).numpy(), "actions": torch.randn(3, 11, 4, generator=g).numpy()}
+    torch.manual_seed(11)
+    out = pred(batch)["rgb"]
+    assert out.shape == (3, 11, 64, 64, 3) and out.dtype == np.float32 and out.min() >= 0 and out.max() <= 1
+    # oracle with the same uniforms: two generate chunks (2 + 1 rows) draw torch.rand in order
+    torch.manual_seed(11)
+    u = torch.cat([torch.rand(2, 169, device=DEV), torch.rand(1, 169, device=DEV)]).cpu()
+    tok = oracle_tokenizer(tcfg, tsd, 2)
+    llm = oracle_llama(LLM_CFG, lsd, prefix="llm.model.")
+    px = torch.from_numpy(batch["video"]).permute(0, 1, 4, 2, 3)
+    ids, _ = tok.tokenize(torch.cat([px, torch.zeros_like(px[:, 1:])], 1), 2)     # the reference's zero-padded tokenize (:158-167)
+    act = torch.from_numpy(batch["actions"])
+    ae = torch.nn.functional.linear(act, lsd["action_linear.weight"], lsd["action_linear.bias"])
+    toks = generate_cached(llm, ids[:, :514], 169, top_k=100, uniforms=u, action_embeds=ae, ctx=2, sdf_token=1025)
+    ref = tok.detokenize(toks, 2).clamp(0, 1)[:, 1:].permute(0, 1, 3, 4, 2).numpy()
+    assert np.abs(out - ref).max() < 1e-3
+
+
+def test_mbrl_rollout_matches_oracle():
+    sys.path.insert(0, ROOT)
+    from ivideogpt_amd import CompressiveVQModel, HeadModelWithAction, LlamaForCausalLM, weights as W
+    from mbrl.video_predictor import VideoPredictor, symexp
+    from oracle.llama import generate_cached
+    tcfg = W.tokenizer_config(**TOK_CFG)
+    tsd = W.random_tokenizer_state_dict(tcfg, 61, codebook_std=0.4)
+    lsd = W.random_llama_state_dict(LLM_CFG, 62, action_dim=4, reward_prediction=True)
+    tok = CompressiveVQModel(tcfg, tsd, encode_dtype="fp32", decode_dtype="fp32").to(DEV)
+    head = HeadModelWithAction(LlamaForCausalLM(LLM_CFG, None, dtype="fp32"), 4, 513, 16, 2, 16, reward_prediction=True)
+    head.load_state_dict(lsd, strict=True)
+    head.to(DEV)
+    vp = VideoPredictor(tok, head, context_length=2, symlog=True)
+    g = torch.Generator().manual_seed(5)
+    obs = torch.randint(0, 256, (2, 9, 64, 64), generator=g).float()
+    acts = torch.randn(3, 2, 4, generator=g)
+    horizon = 3
+    torch.manual_seed(21)
+    obss, actions, rewards = vp.rollout(obs, lambda o, t: acts[t], horizon)
+    assert obss.shape == (2, horizon + 1, 9, 64, 64) and actions.shape == (2, horizon + 1, 4) and rewards.shape == (2, horizon + 1, 1)
+    # oracle restatement of mbrl/video_predictor.py:267-339 with the same uniforms
+    torch.manual_seed(21)
+    otok, ollm = oracle_tokenizer(tcfg, tsd, 2), oracle_llama(LLM_CFG, lsd, prefix="llm.model.")
+    o = obs / 255.
+    frames = list(torch.chunk(o, 3, dim=1))
+    ctx_frames = torch.stack(frames[-2:], 1)
+    tokens, _ = otok.tokenize(torch.cat([ctx_frames, torch.zeros_like(ctx_frames)], 1), 2)
+    tokens = tokens[:, :514]
+    init = tokens
+    act_tab = torch.zeros(2, 1 + horizon + 1, 4)
+    for t in range(horizon):
+        act_tab[:, 1 + t] = acts[t]
+        ae = torch.nn.functional.linear(act_tab, lsd["action_linear.weight"], lsd["action_linear.bias"])
+        u = torch.rand(2, 17, device=DEV).cpu()
+        out, hid = generate_cached(ollm, tokens, 17, top_k=100, uniforms=u, action_embeds=ae, ctx=2, sdf_token=1025, return_last_hidden=True)
+        pred16 = out[:, tokens.shape[1]:tokens.shape[1] + 16]
+        r = torch.nn.functional.linear(hid, lsd["reward_linear.weight"], lsd["reward_linear.bias"])
+        tokens = torch.cat([tokens, pred16, torch.full((2, 1), 1025, dtype=tokens.dtype)], 1)
+        fmap = otok.detokenize(torch.cat([init, pred16], 1), 2).clamp(0, 1)
+        frames.append(fmap[:, -1]); frames.pop(0)
+        assert (obss[:, t + 1].cpu() - torch.cat(frames, 1)).abs().max().item() < 1e-3, f"step {t}: predicted observation differs"
+        assert (rewards[:, t + 1].cpu() - symexp(r)).abs().max().item() < 1e-3, f"step {t}: reward differs"
+
+
+def test_teacher_forced_logits_with_actions():
+    """HeadModelWithAction.forward logits (action_model.py:154-185): action embeddings on every sdf slot."""
+    from ivideogpt_amd import HeadModelWithAction, LlamaForCausalLM, weights as W
+    lsd = W.random_llama_state_dict(LLM_CFG, 71, action_dim=3)
+    head = HeadModelWithAction(LlamaForCausalLM(LLM_CFG, None, dtype="fp32"), 3, 513, 16, 2, 6)
+    head.load_state_dict(lsd, strict=True)
+    head.to(DEV)
+    g = torch.Generator().manual_seed(6)
+    ids = torch.randint(0, 1024, (2, 514 + 17 * 4 - 1), generator=g)
+    action = torch.randn(2, 6, 3, generator=g)
+    lg = head.logits(ids.to(DEV), action.to(DEV)).cpu()
+    ollm = oracle_llama(LLM_CFG, lsd, prefix="llm.model.")
+    ae = torch.nn.functional.linear(action, lsd["action_linear.weight"], lsd["action_linear.bias"])
+    x = ollm.embed(ids).clone()
+    start = 513 + torch.arange(4) * 17                       # start_index, action_model.py:176-178
+    x[:, start] += ae[:, 1:-1]                               # action_embeds[:, context - 1 : -1]
+    ref = ollm.logits(embeds=x)
+    assert (lg - ref).abs().max().item() < 1e-3

@@ -160,3 +160,28 @@ def test_shard_rows_partition():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_npz_ingest_and_resize(tmp_path):
+    """datasets/oxe_data_converter.py:57-59 episode format through the NPZParser mirror (inference/utils.py:12-39)."""
+    from ivideogpt_amd.data import NPZParser, resize_frames
+    rng = np.random.default_rng(0)
+    ep = rng.integers(0, 256, (22, 96, 120, 3), dtype=np.uint8)
+    act = rng.normal(size=(22, 4))
+    f = tmp_path / "ep.npz"
+    np.savez(f, image=ep, action=act)
+    np.random.seed(0)
+    images, actions = NPZParser(16, 64).parse(str(f), "fractal20220817_data", load_action=True)
+    assert images.shape == (16, 3, 64, 64) and actions.shape == (16, 4)
+    assert float(images.min()) >= 0 and float(images.max()) <= 1
+    # antialiased bilinear (triangle filter): constants and linear ramps are preserved, no crop (aspect ratio squashed)
+    const = torch.full((1, 3, 96, 120), 0.37)
+    assert torch.allclose(resize_frames(const, 64), torch.full((1, 3, 64, 64), 0.37), atol=1e-6)
+    ramp = torch.linspace(0, 1, 128)[None, None, None, :].expand(1, 3, 128, 128).contiguous()
+    out = resize_frames(ramp, 64)
+    centres = (torch.arange(64) * 2 + 0.5) / 127
+    assert torch.allclose(out[0, 0, 10, 4:-4], centres[4:-4], atol=1e-5)
+    # bair-style key / dtype (int64 frames under 'aux1_image')
+    np.savez(tmp_path / "b.npz", image=ep.astype(np.int64), aux1_image=ep[:, :64, :64].astype(np.int64), action=act)
+    im2, _ = NPZParser(8, 64).parse(str(tmp_path / "b.npz"), "bair_robot_pushing")
+    assert im2.shape == (8, 3, 64, 64)
