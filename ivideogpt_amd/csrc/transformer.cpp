@@ -267,7 +267,16 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
     const std::string key = std::to_string(Bc) + ":" + std::to_string(nc) + ":" + (uniforms ? "s" : "g") + ":" + std::to_string(top_k) + ":" +
                             std::to_string(sa.forced_period) + ":" + std::to_string(ctx) + ":" + std::to_string(act_T) + ":" +
                             std::to_string(L0);
+    // reward head: reads the residual stream left by the LAST forward pass, i.e. before the final decide-only step
+    // overwrites it with the embedding of the last token (mbrl/video_predictor.py:311-313: hidden state of the last step)
+    auto reward = [&]() -> int {
+      if (!reward_out) return 0;
+      if (!e->rew_w) return e->fail(IVG_ERR_MISSING, "generate: reward requested but reward_linear is not loaded");
+      CK(launch_rowdot(g.x, e->rew_w, e->rew_b, reward_out + b0, Bc, H, c.rms_norm_eps, dt, st));
+      return 0;
+    };
     int j = 1;
+    if (n_new == 1) IVG_TRY(reward());
     if (n_new >= 1) { IVG_TRY(step_body(e, st, g, Bc, nc, cs, sa, j < n_new)); ++j; }
     hipGraphExec_t exec = nullptr;
     if (e->use_graph && st != nullptr && j < n_new) {
@@ -295,13 +304,12 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
       if (exec) CK((int)hipGraphLaunch(exec, st));
       else IVG_TRY(step_body(e, st, g, Bc, nc, cs, sa, true));
     }
-    if (j == n_new && n_new > 1) IVG_TRY(step_body(e, st, g, Bc, nc, cs, sa, false));  // decide the last token (no forward)
+    if (j == n_new && n_new > 1) {
+      IVG_TRY(reward());
+      IVG_TRY(step_body(e, st, g, Bc, nc, cs, sa, false));  // decide the last token (no forward)
+    }
     CK((int)hipMemcpy2DAsync(ids_out + (long)b0 * Ltot, (size_t)Ltot * 8, g.ids, (size_t)g.ids_ld * 8, (size_t)Ltot * 8, Bc,
                              hipMemcpyDeviceToDevice, st));
-    if (reward_out) {
-      if (!e->rew_w) return e->fail(IVG_ERR_MISSING, "generate: reward requested but reward_linear is not loaded");
-      CK(launch_rowdot(g.x, e->rew_w, e->rew_b, reward_out + b0, Bc, H, c.rms_norm_eps, dt, st));
-    }
   }
   return 0;
 }
