@@ -4,16 +4,21 @@
 // Why a second conv kernel: the generic implicit GEMM (igemm.hip) re-gathers the A tile from global memory for every
 // tap, and measured on MI355X it runs at exactly the per-CU ingest limit (~10 B/clk/CU from HBM, ~17 from L2/MALL:
 // 395 TF at Cout = 128, 690 TF at Cout = 512; LDS-DMA staging changes nothing).  Here a workgroup
-//   * owns a TH x TW = 256-pixel spatial tile of one image and BN output channels,
-//   * stages the (TH+2) x (TW+2) input HALO tile of one 64-channel (bf16; 32 fp32) chunk in LDS ONCE and runs all
+//   * owns a TH x TW = 256-pixel spatial tile (16x16 or 8x32) of one image and BN output channels,
+//   * stages the (TH+2) x (TW+2) input HALO tile of one 32-channel (bf16; 16 fp32) chunk in LDS ONCE and runs all
 //     nine taps out of it (A traffic / 9, no im2col), double-buffered across channel chunks, the next chunk's halo
 //     arriving in pieces under the current chunk's taps,
-//   * streams the [BN][128 B] weight tile of each (tap, chunk) through a second double buffer,
-//   * both by LDS-DMA (global_load_lds, 16 B/lane; out-of-image pixels source a zero page), 128-byte LDS rows with
-//     the same XOR swizzle as igemm.hip (swizzle on the SOURCE chunk, conflict-free ds_read_b128),
+//   * streams the [BN][64 B] weight tile of each (tap, chunk) through a ring of three buffers, issued two steps ahead
+//     and retired by COUNTED s_waitcnt vmcnt(n) + raw s_barrier (the DMA queue is never drained inside the loop),
+//   * both by LDS-DMA (global_load_lds, 16 B/lane; out-of-image pixels source a zero page), 64-byte LDS rows with an
+//     XOR swizzle on the SOURCE chunk (conflict-free ds_read_b128 from any start row),
+//   * 72 KiB of LDS per workgroup -> TWO workgroups (16 waves) per CU: measured with cycle stamps, one workgroup per CU
+//     spends 25 % of every step in the barrier and 22 % of its life in an un-overlapped prologue / epilogue; a second
+//     resident workgroup fills exactly those holes,
 //   * 8 waves (2 per SIMD), each a 64 x 64 (or 64 x 32) sub-tile of MFMA fragments, swapped operands so a lane owns
 //     4 consecutive output channels;  the XCD-aware block order keeps the N tiles of one spatial tile on one L2.
-// Bytes per (tap, chunk) step: 16 KiB of weights + 1/9 of a ~50 KiB halo for 4.2 MFLOP -> ~195 FLOP/B (igemm: 64).
+// Bytes per (tap, chunk) step: 8 KiB of weights + 1/9 of a ~24 KiB halo for 2.1 MFLOP -> ~195 FLOP/B (igemm: 64).
+#include <cstdio>
 #include <cstdlib>
 
 #include "igemm.h"
@@ -30,6 +35,8 @@ struct Conv3Dev {
   long c_img, c_pix, c_ch, c_grp_stride;
   int c_grp, flags;
   int hb_bytes;                      // one halo buffer
+  int stage_ok;                      // the 256 x BN staging tile of the epilogue fits in the workgroup's LDS
+  long long* dbg;                    // development: cycle stamps of workgroup 0 / wave 0 (null in production)
 };
 
 // source of every out-of-image 16-byte chunk (zero-initialised device global; one per translation unit, no RDC needed)
@@ -39,19 +46,22 @@ __device__ __forceinline__ void glds16b(const void* gsrc, unsigned char* lds_wav
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
-__device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// XOR key: ds_read_b128 of 16 CONSECUTIVE rows is bank-conflict free from ANY start row (the halo fragments of tap
+// (kh, kw) start at arbitrary rows)
+__device__ __forceinline__ int swz_key(int row) { return (row >> 1) & 3; }   // 64-byte rows, 4 chunks: found by exhaustive search
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 64 + ((chunk ^ swz_key(row)) << 4); }
 
 // ABL (development ablations, 0 in production): 1 no MFMA, 2 no LDS reads + no MFMA, 4 no halo DMA, 8 no weight DMA
 template <typename T, int BN, bool UPS, int ABL = 0>
-__global__ __launch_bounds__(512) void conv3x3_kernel(const Conv3Dev p) {
+__global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
   constexpr int VEC = Traits<T>::VEC;
-  constexpr int CK = 8 * VEC;              // channels per chunk: one 128-byte LDS row per halo pixel
+  constexpr int CK = 4 * VEC;              // channels per chunk: one 64-byte LDS row per halo pixel (one MFMA K-step)
   constexpr int WN = BN / 2;               // 8 waves = 4 (M) x 2 (N)
   constexpr int FM = 4, FN = WN / 16;
-  constexpr int W_BYTES = BN * 128;
+  constexpr int W_BYTES = BN * 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* hbuf0 = smem;
-  unsigned char* wbuf0 = smem + 2 * p.hb_bytes;
+  unsigned char* wbuf0 = smem + 2 * p.hb_bytes;   // three weight buffers
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int lr = lane & 15, lg = lane >> 4;
@@ -77,13 +87,13 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const Conv3Dev p) {
   const T* Wt = (const T*)p.W;
   const int n_base = tile_n * BN;
   const int halo_rows = p.HTH * p.HTW;
-  const int halo_iters = (halo_rows * 8 + 511) / 512;
+  const int halo_iters = (halo_rows * 4 + 511) / 512;
 
   // one 8-KiB piece of a halo tile: 512 lanes x 16 B, lane-linear in LDS
   auto issue_halo_piece = [&](int chunk, int it, unsigned char* hb) {
     const int q = it * 512 + tid;
-    const int row = q >> 3, slot = q & 7;
-    const int c = slot ^ ((row >> 1) & 7);
+    const int row = q >> 2, slot = q & 3;
+    const int c = slot ^ swz_key(row);
     const int hy = row / p.HTW, hx = row - hy * p.HTW;
     const int iy = iy0 + hy, ix = ix0 + hx;
     const bool ok = (row < halo_rows) & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.Wd);
@@ -92,14 +102,13 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const Conv3Dev p) {
   };
   auto issue_w = [&](int step, unsigned char* wb) {
     const int chunk = step / 9, tap = step - chunk * 9;
-#pragma unroll
-    for (int it = 0; it < BN * 8 / 512; ++it) {
-      const int q = it * 512 + tid;
-      const int n = q >> 3, slot = q & 7;
-      const int c = slot ^ ((n >> 1) & 7);
+    if (wave * 64 < BN * 4) {   // BN rows x 4 chunks: all 8 waves for BN = 128, the first 4 for BN = 64 (wave-uniform)
+      const int q = tid;
+      const int n = q >> 2, slot = q & 3;
+      const int c = slot ^ swz_key(n);
       const bool ok = (n_base + n) < p.N;
       const void* src = ok ? (const void*)(Wt + ((long)(n_base + n) * p.ldw + tap * p.Cin + chunk * CK + c * VEC)) : (const void*)g_zero_chunk3;
-      glds16b(src, wb + (it * 512 + wave * 64) * 16);
+      glds16b(src, wb + (wave * 64) * 16);
     }
   };
 
@@ -120,21 +129,37 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const Conv3Dev p) {
 
   const int nchunks = p.Cin / CK;
   const int steps = nchunks * 9;
+  const bool dbg = p.dbg && blockIdx.x == 8 && tid == 0;
+  int dbg_n = 0;
+  auto stamp = [&]() { if (dbg) p.dbg[dbg_n++] = (long long)__builtin_readcyclecounter(); };
+  stamp();
+  // Pipeline: the weight tile of step s+2 and one piece of the next chunk's halo are issued at the top of step s;
+  // the end-of-step wait is COUNTED (all DMA except what this step just issued), so a transfer has two full steps
+  // to land and the barrier never drains the queue (cdna_hip_programming.md 5, "Pipelining across barriers").
+  const int W_IT = (wave * 64 < BN * 4) ? 1 : 0;   // DMA instructions this wave issues per weight tile
   for (int it = 0; it < halo_iters; ++it) issue_halo_piece(0, it, hbuf0);
   issue_w(0, wbuf0);
-  __syncthreads();
+  if (steps > 1) issue_w(1, wbuf0 + W_BYTES);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  stamp();
   for (int s = 0; s < steps; ++s) {
     const int chunk = s / 9, tap = s - chunk * 9;
-    if constexpr (!(ABL & 8)) {
-      if (s + 1 < steps) issue_w(s + 1, wbuf0 + ((s + 1) & 1) * W_BYTES);
-    }
-    if constexpr (!(ABL & 4)) {
-      if (chunk + 1 < nchunks && tap < halo_iters) issue_halo_piece(chunk + 1, tap, hbuf0 + ((chunk + 1) & 1) * p.hb_bytes);
-      if (chunk + 1 < nchunks && tap == 8)
-        for (int it = 9; it < halo_iters; ++it) issue_halo_piece(chunk + 1, it, hbuf0 + ((chunk + 1) & 1) * p.hb_bytes);
-    }
+    int issued = 0;
+    // the two waves of a SIMD (w, w + 4) issue their DMA at different points of the step, so one of them is always
+    // feeding the matrix pipe (an in-order wave cannot issue MFMAs while it is issuing LDS-DMA)
+    auto issue_dma = [&]() {
+      if constexpr (!(ABL & 8)) {
+        if (s + 2 < steps) { issue_w(s + 2, wbuf0 + ((s + 2) % 3) * W_BYTES); issued += W_IT; }
+      }
+      if constexpr (!(ABL & 4)) {
+        if (chunk + 1 < nchunks && tap < halo_iters) { issue_halo_piece(chunk + 1, tap, hbuf0 + ((chunk + 1) & 1) * p.hb_bytes); issued += 1; }
+      }
+    };
+    const bool early = __builtin_amdgcn_readfirstlane(wave) < 4;
+    if (early) issue_dma();
     const unsigned char* hb = hbuf0 + (chunk & 1) * p.hb_bytes;
-    const unsigned char* wb = wbuf0 + (s & 1) * W_BYTES;
+    const unsigned char* wb = wbuf0 + (s % 3) * W_BYTES;
     const int kh = tap / 3, kw = tap - kh * 3;
     int hr[FM];
 #pragma unroll
@@ -142,10 +167,9 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const Conv3Dev p) {
       if constexpr (UPS) hr[b] = (((y0 + py[b] + kh - 1) >> 1) - iy0) * p.HTW + (((x0 + px[b] + kw - 1) >> 1) - ix0);
       else hr[b] = (py[b] + kh) * p.HTW + (px[b] + kw);
     }
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      if constexpr (ABL & 2) break;
-      const int c = kk * 4 + lg;
+    {
+      if (!early) issue_dma();
+      const int c = lg;
       Chunk16 xa[FM], wv[FN];
 #pragma unroll
       for (int b = 0; b < FM; ++b) xa[b] = *(const Chunk16*)(hb + swz(hr[b], c));
@@ -156,8 +180,8 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const Conv3Dev p) {
         for (int b = 0; b < FM; ++b) asm volatile("" :: "v"(xa[b]));
 #pragma unroll
         for (int a = 0; a < FN; ++a) asm volatile("" :: "v"(wv[a]));
-        continue;
       }
+      if constexpr (!(ABL & 1))
 #pragma unroll
       for (int a = 0; a < FN; ++a)
 #pragma unroll
@@ -172,11 +196,24 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const Conv3Dev p) {
           }
         }
     }
-    __syncthreads();  // also drains this step's DMA (the compiler puts vmcnt(0) in front of the barrier)
+    if (s < 16) stamp();
+    // everything issued BEFORE this step has landed once at most `issued` transfers are still in flight
+    if (issued == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if (issued == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+    else if (issued == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (s < 16) stamp();
   }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  stamp();
 
   // ---- epilogue (same contract as igemm.hip): lane holds 4 consecutive n of pixel (py, px)
   const int flags = p.flags;
+  // dense NHWC output of element type T: stage the 256 x BN tile through LDS (the halo buffers are free now) and store
+  // whole pixel rows, 16 B per lane, instead of 8-byte pieces at a 256-byte stride (store-issue bound otherwise)
+  const bool staged = !(flags & IG_OUT_F32) && p.c_ch == 1 && p.c_pix == p.N && (p.N % BN) == 0 && p.stage_ok;
+  constexpr int PITCH = BN * (int)sizeof(T) + 16;   // bytes per staged pixel row (+16: spreads the 16 pixel rows of a fragment over banks)
 #pragma unroll
   for (int b = 0; b < FM; ++b) {
     const int pix = (y0 + py[b]) * p.Wo + (x0 + px[b]);
@@ -215,7 +252,11 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const Conv3Dev p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
       }
-      if (flags & IG_OUT_F32) {
+      if (staged) {
+        unsigned char* dst = smem + (wm * 64 + b * 16 + lr) * PITCH + (wn * WN + a * 16 + lg * 4) * (int)sizeof(T);
+        if constexpr (sizeof(T) == 2) *(bf16x4*)dst = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        else *(f32x4*)dst = f32x4{v[0], v[1], v[2], v[3]};
+      } else if (flags & IG_OUT_F32) {
         float* Y = (float*)p.Y;
         if (vec_ok && ((o & 3) == 0)) *(f32x4*)(Y + o) = f32x4{v[0], v[1], v[2], v[3]};
         else {
@@ -234,11 +275,28 @@ __global__ __launch_bounds__(512) void conv3x3_kernel(const Conv3Dev p) {
       }
     }
   }
+  if (staged) {
+    __syncthreads();
+    constexpr int CPR = BN * (int)sizeof(T) / 16;   // 16-byte chunks per staged pixel row
+    T* Y = (T*)p.Y;
+    const long ibase = (long)(img / p.c_grp) * p.c_grp_stride + (long)(img % p.c_grp) * p.c_img;
+    for (int q = tid; q < 256 * CPR; q += 512) {
+      const int pl = q / CPR, ch = q - pl * CPR;
+      const int oy = y0 + (pl >> p.tw_shift), ox = x0 + (pl & (p.TW - 1));
+      const Chunk16 val = *(const Chunk16*)(smem + pl * PITCH + ch * 16);
+      *(Chunk16*)(Y + ibase + (long)(oy * p.Wo + ox) * p.c_pix + n_base + ch * (16 / (int)sizeof(T))) = val;
+    }
+  }
+  if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(); p.dbg[63] = dbg_n; }
 }
 
 template <typename T, int BN, bool UPS, int ABL = 0>
 static int launch_c3(const Conv3Dev& d, int nimg, hipStream_t stream) {
-  const int smem = 2 * d.hb_bytes + 2 * BN * 128;
+  int smem = 2 * d.hb_bytes + 3 * BN * 64;
+  const int stage = 256 * (BN * (int)sizeof(T) + 16);   // LDS-staged epilogue tile
+  Conv3Dev dd = d;
+  dd.stage_ok = stage <= 80 * 1024;                      // keep two workgroups per CU (fp32 x 128 channels stores directly)
+  if (dd.stage_ok && smem < stage) smem = stage;
   static int attr_set = 0;
   auto kfn = conv3x3_kernel<T, BN, UPS, ABL>;
   if (attr_set < smem) {
@@ -247,7 +305,7 @@ static int launch_c3(const Conv3Dev& d, int nimg, hipStream_t stream) {
     attr_set = 160 * 1024;
   }
   const long blocks = (long)nimg * d.tiles_per_img * d.tiles_n;
-  hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(512), smem, stream, d);
+  hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(512), smem, stream, dd);
   return (int)hipGetLastError();
 }
 
@@ -262,18 +320,18 @@ int launch_conv3x3(const IgemmArgs& a, DType dtype, hipStream_t stream) {
   if (!conv3x3_enabled()) return -1;
   if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1) return -1;
   if (a.nb0 * a.nb1 * a.nb2 != 1 || a.alpha != 1.0f || (a.flags & (IG_GLU | IG_BIAS_M))) return -1;
-  const int ck = dtype == BF16 ? 64 : 32;
+  const int ck = dtype == BF16 ? 32 : 16;
   if (a.Cin % ck != 0 || a.ldx != a.Cin) return -1;
   const int Ho = a.Hout, Wo = a.Wout;
   if (a.ups ? (Ho != 2 * a.Hin || Wo != 2 * a.Win) : (Ho != a.Hin || Wo != a.Win)) return -1;
-  int TW = Wo >= 64 ? 64 : Wo;
-  if (TW != 16 && TW != 32 && TW != 64) return -1;
+  int TW = Wo >= 32 ? 32 : Wo;   // 16x16 or 8x32 output tiles: halo <= 10 x 34 pixels = 49 KiB per buffer
+  if (TW != 16 && TW != 32) return -1;
   const int TH = 256 / TW;
   if (Wo % TW != 0 || Ho % TH != 0) return -1;
   Conv3Dev d;
   d.X = a.X; d.W = a.W; d.Y = a.Y; d.R = a.R; d.bias = a.bias;
   d.H = a.Hin; d.Wd = a.Win; d.Cin = a.Cin; d.Ho = Ho; d.Wo = Wo;
-  d.TH = TH; d.TW = TW; d.tw_shift = TW == 64 ? 6 : (TW == 32 ? 5 : 4);
+  d.TH = TH; d.TW = TW; d.tw_shift = TW == 32 ? 5 : 4;
   if (a.ups) { d.HTH = TH / 2 + 2; d.HTW = TW / 2 + 2; }
   else { d.HTH = TH + 2; d.HTW = TW + 2; }
   d.tiles_x = Wo / TW; d.tiles_per_img = d.tiles_x * (Ho / TH); d.n_sp = a.Nimg * d.tiles_per_img;
@@ -283,8 +341,24 @@ int launch_conv3x3(const IgemmArgs& a, DType dtype, hipStream_t stream) {
   d.c_img = a.c_img; d.c_pix = a.c_pix; d.c_ch = a.c_ch; d.c_grp = a.c_grp > 0 ? a.c_grp : 1; d.c_grp_stride = a.c_grp_stride;
   if (a.c_grp <= 1 && a.c_grp_stride == 0) d.c_grp_stride = a.c_img;
   d.flags = a.flags;
-  d.hb_bytes = cdiv(d.HTH * d.HTW * 8, 512) * 8192;
-  if (2 * d.hb_bytes + 2 * bn * 128 > 160 * 1024) return -1;
+  d.hb_bytes = cdiv(d.HTH * d.HTW * 4, 512) * 8192;
+  {
+    static long long* dbg_buf = nullptr;
+    static int want = -1;
+    if (want < 0) { const char* e = getenv("IVG_C3_DEBUG"); want = (e && e[0] == '1') ? 1 : 0; if (want) (void)hipMalloc((void**)&dbg_buf, 64 * 8); }
+    d.dbg = dbg_buf;
+    if (want) {
+      static int calls = 0;
+      if (++calls == 8) {  // after warm-up: dump the previous launch's stamps
+        long long h[64]; (void)hipDeviceSynchronize(); (void)hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost);
+        const int n = (int)h[63];
+        fprintf(stderr, "[c3 dbg] stamps=%d total=%lld cycles: prologue %lld", n, h[n - 1] - h[0], h[1] - h[0]);
+        for (int i = 2; i + 1 < n - 2; i += 2) fprintf(stderr, " | step %d: compute %lld wait+bar %lld", (i - 2) / 2, h[i] - h[i - 1], h[i + 1] - h[i]);
+        fprintf(stderr, " | drain %lld epilogue %lld\n", h[n - 2] - h[n - 3], h[n - 1] - h[n - 2]);
+      }
+    }
+  }
+  if (2 * d.hb_bytes + 3 * bn * 64 > 80 * 1024) return -1;
   if (((uintptr_t)a.X & 15) || ((uintptr_t)a.W & 15)) return -1;
   {  // development ablations of the bf16 / BN = 128 / no-upsample instance (IVG_C3_ABLATE=<mask>)
     static int abl = -1;
