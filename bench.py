@@ -12,7 +12,7 @@ Multi-GPU: independent trajectories shard by batch rows (weak scaling: 64 per GP
 per-sample metric rows are all-gathered over RCCL once per step (the reference's accelerator.gather, train_gpt.py:476-479).
 
 Prints ONE JSON line on rank 0 (see the task contract): value = predicted frames / s over all GPUs, plus
-  "roofline"     : the dominant kernel (bf16 implicit-GEMM conv / GEMM), algorithmic FLOPs / HIP-event durations
+  "roofline"     : the kernel with the most time per step (decode attention: HBM; conv3x3 / igemm: MFMA); the others in "roofline_other"
   "cpu_baseline" : the oracle's restatement of the reference algorithm timed on this box's host cores (N = 1 only).
 """
 import argparse
@@ -32,6 +32,7 @@ from ivideogpt_amd import _lib, parallel  # noqa: E402
 from ivideogpt_amd.pipeline import frame_metrics, predict_frames  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3     # f32-input MFMA peak (same guide)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -107,6 +108,51 @@ def cpu_baseline(res, medium, ctx, T, sample_b, threads, budget_s=150):
                 "sample": f"{sample_b} trajectories did not finish within the {budget_s} s budget"}
 
 
+KERNEL_NAMES = {
+    "decode_attn": "ivg::decode_attn_kernel (RoPE + KV append + single-query attention over the KV cache)",
+    "conv3x3": "ivg::conv3x3_kernel (LDS-halo 3x3 convolution, MFMA)",
+    "igemm": "ivg::igemm_kernel<128,128,64> (implicit-GEMM conv / GEMM, MFMA)",
+}
+
+
+def _pmc_traffic(name):
+    """HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json: separate rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE runs of this same command, gfx950 corrections applied as the file states) or None."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["per_launch_bytes"].get(name)
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def rooflines(kstats, a):
+    """One roofline object per measured kernel class, the one with the most kernel time per step first.
+    decode_attn is HBM-bound (algorithmic bytes = the K and V rows one launch reads: 2 * B * heads * n_keys * head_dim *
+    esize); the conv / GEMM classes are MFMA-bound (2 * M * N * K flops per launch)."""
+    peak_f = PEAK_BF16_TFLOPS if a.decode_dtype == "bf16" else PEAK_F32_TFLOPS
+    out = []
+    for name, s in kstats.items():
+        if not s["launches"] or s["total_ms"] <= 0:
+            continue
+        sec = s["total_ms"] * 1e-3
+        common = {"kernel": KERNEL_NAMES[name], "launches_per_step": s["launches"], "avg_launch_ms": s["total_ms"] / s["launches"],
+                  "kernel_ms_per_step": s["total_ms"]}
+        if name == "decode_attn":
+            ach = s["total_bytes"] / sec / 1e9
+            r = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
+                 "algorithmic_bytes_per_launch": s["total_bytes"] / s["launches"]}
+        else:
+            ach = s["total_flops"] / sec / 1e12
+            r = {"bound": "mfma", "achieved": ach, "peak": peak_f, "unit": "TFLOP/s", "frac": ach / peak_f,
+                 "algorithmic_flops_per_launch": s["total_flops"] / s["launches"]}
+        r["traffic"] = _pmc_traffic(name)
+        r.update(common)
+        out.append(r)
+    out.sort(key=lambda r: -r["kernel_ms_per_step"])
+    return out or [{"bound": "hbm", "achieved": 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": 0.0, "traffic": None}]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,10 +205,15 @@ def main():
 
     llm_engine = (model.llm if a.action_dim else model)._engine
     prof_engines = [tok._engine, llm_engine]
-    kclass = _lib.IVG_K_IGEMM_BF16 if a.decode_dtype == "bf16" else _lib.IVG_K_IGEMM_F32
+    bf = a.decode_dtype == "bf16"
+    ev_classes = {"igemm": _lib.IVG_K_IGEMM_BF16 if bf else _lib.IVG_K_IGEMM_F32,
+                  "conv3x3": _lib.IVG_K_CONV3X3_BF16 if bf else _lib.IVG_K_CONV3X3_F32}
     for e in prof_engines:
-        e.profile_read(kclass)
-        e.profile_enable(kclass, True)
+        for k in ev_classes.values():
+            e.profile_read(k)
+            e.profile_enable(k, True)
+    llm_engine.profile_enable(_lib.IVG_K_DECODE_ATTN, True)   # re-captures the step graph with the stamps on: do it untimed
+    step()
 
     parallel.barrier()
     torch.cuda.synchronize()
@@ -174,12 +225,16 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = parallel.max_over_ranks(elapsed, dev)
 
-    stats = [e.profile_read(kclass) for e in prof_engines]
-    for e in prof_engines:
-        e.profile_enable(kclass, False)
-    launches = sum(s["launches"] for s in stats)
-    k_ms = sum(s["total_ms"] for s in stats)
-    k_flops = sum(s["total_flops"] for s in stats)
+    # HIP-event classes: every launch of the timed region.  Decode attention: stamped by the kernel itself (it runs inside
+    # the replayed step graph), launches of the last timed step.
+    kstats = {}
+    for name, k in ev_classes.items():
+        st = [e.profile_read(k) for e in prof_engines]
+        for e in prof_engines:
+            e.profile_enable(k, False)
+        kstats[name] = {key: sum(x[key] for x in st) / max(1, a.steps) for key in ("launches", "total_ms", "total_flops", "total_bytes")}
+    kstats["decode_attn"] = llm_engine.profile_read(_lib.IVG_K_DECODE_ATTN)
+    llm_engine.profile_enable(_lib.IVG_K_DECODE_ATTN, False)
 
     # one extra, untimed pass for the per-stage split (events on the engine streams' parent stream)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -196,7 +251,7 @@ def main():
 
     if rank == 0:
         units = world * B * F * a.steps
-        achieved = k_flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        rl = rooflines(kstats, a)
         out = {
             "metric": "predicted frames/sec (encode+GPT rollout+decode), 64x64x16f" if a.res == 64 else
                       "predicted frames/sec (encode+GPT rollout+decode), 256x256x16f",
@@ -211,10 +266,7 @@ def main():
                        "global_batch": world * B, "frames": T, "resolution": a.res,
                        "arith": {"encode": a.encode_dtype, "rollout": a.llm_dtype, "decode": a.decode_dtype},
                        "parallelism": f"batch-shard x{world} (no data-path collective; 1 RCCL all-gather of [B,4] metric rows per step)"},
-            "roofline": {"bound": "mfma", "kernel": "ivg::igemm_kernel<bf16,128,128,64,64> (implicit-GEMM conv / GEMM)",
-                         "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
-                         "launches_per_step": launches / max(1, a.steps), "avg_launch_ms": k_ms / max(1, launches),
-                         "kernel_ms_per_step": k_ms / max(1, a.steps), "traffic": None},
+            "roofline": rl[0], "roofline_other": rl[1:],
             "stage_ms": stage,
         }
         if world == 1 and not a.no_cpu_baseline:

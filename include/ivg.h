@@ -130,8 +130,10 @@ int ivg_generate(ivg_engine* e, const int64_t* prompt, int64_t prompt_stride, in
 int ivg_logits(ivg_engine* e, const int64_t* ids, int B, int L, const float* actions, int act_T, int ctx, float* logits_out,
                ivg_stream stream);
 
-/* ---- measurement hooks (bench.py): time one kernel class with HIP events on the launching stream */
-enum ivg_kernel_class { IVG_K_IGEMM_BF16 = 0, IVG_K_IGEMM_F32 = 1, IVG_K_CONV3X3_BF16 = 2, IVG_K_CONV3X3_F32 = 3, IVG_K_COUNT = 4 };
+/* ---- measurement hooks (bench.py): time one kernel class with HIP events on the launching stream; the decode attention
+ * (which runs inside a replayed hipGraph) stamps its own launch windows with the 100 MHz wall clock instead */
+enum ivg_kernel_class { IVG_K_IGEMM_BF16 = 0, IVG_K_IGEMM_F32 = 1, IVG_K_CONV3X3_BF16 = 2, IVG_K_CONV3X3_F32 = 3, IVG_K_DECODE_ATTN = 4,
+                        IVG_K_COUNT = 5 };
 typedef struct {
   int64_t launches;
   double total_ms;      /* sum of per-launch durations (hipEventElapsedTime) */

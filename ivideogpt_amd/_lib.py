@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libivg.so")
 
 IVG_F32, IVG_BF16 = 0, 1
-IVG_K_IGEMM_BF16, IVG_K_IGEMM_F32, IVG_K_CONV3X3_BF16, IVG_K_CONV3X3_F32 = 0, 1, 2, 3
+IVG_K_IGEMM_BF16, IVG_K_IGEMM_F32, IVG_K_CONV3X3_BF16, IVG_K_CONV3X3_F32, IVG_K_DECODE_ATTN = 0, 1, 2, 3, 4
 # igemm epilogue flags (csrc/igemm.h)
 IG_BIAS_N, IG_BIAS_M, IG_RESIDUAL, IG_SILU, IG_GLU, IG_OUT_F32 = 1, 2, 4, 8, 16, 32
 

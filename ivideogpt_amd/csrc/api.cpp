@@ -268,6 +268,7 @@ void ivg_destroy(ivg_engine* e) {
   if (e->vt) (void)hipFree(e->vt);
   if (e->gen_buf) (void)hipFree(e->gen_buf);
   if (e->ones) (void)hipFree(e->ones);
+  if (e->attn_prof) (void)hipFree(e->attn_prof);
   delete e;
 }
 
@@ -311,6 +312,8 @@ int ivg_create(const ivg_config* cfg, const ivg_tensor* weights, int n_weights, 
         e->err = "hipMalloc failed"; return bail(IVG_ERR_HIP);
       }
     }
+    if (hipMalloc((void**)&e->attn_prof, (size_t)cfg->num_layers * IVG_ATTN_PROF_SLOTS * 2 * e->Lmax * 8) != hipSuccess) { e->err = "hipMalloc failed"; return bail(IVG_ERR_HIP); }
+    (void)hipMemset(e->attn_prof, 0, (size_t)cfg->num_layers * IVG_ATTN_PROF_SLOTS * 2 * e->Lmax * 8);
     (void)hipMemset(e->vt, 0, vtb);
     (void)hipMemset(e->gen_buf, 0, e->gen_bytes);
     {
@@ -430,6 +433,7 @@ int ivg_logits(ivg_engine* e, const int64_t* ids, int B, int L, const float* act
 
 int ivg_profile_enable(ivg_engine* e, int k, int enable) {
   if (!e || k < 0 || k >= IVG_K_COUNT) return IVG_ERR_INVALID;
+  if (k == IVG_K_DECODE_ATTN) { e->attn_prof_on = enable != 0 && e->attn_prof; return IVG_OK; }
   e->prof[k].enabled = enable != 0;
   return IVG_OK;
 }
@@ -437,6 +441,30 @@ int ivg_profile_enable(ivg_engine* e, int k, int enable) {
 int ivg_profile_read(ivg_engine* e, int k, ivg_profile_stats* out) {
   if (!e || !out || k < 0 || k >= IVG_K_COUNT) return IVG_ERR_INVALID;
   API_CK(hipDeviceSynchronize());
+  if (k == IVG_K_DECODE_ATTN) {
+    // launch windows stamped by the kernel itself (it runs inside a replayed hipGraph, where HIP events cannot bracket
+    // single launches): last ivg_generate call only; bytes = K and V rows read per launch
+    out->launches = 0; out->total_ms = 0; out->total_flops = 0; out->total_bytes = 0;
+    if (!e->attn_prof) return IVG_OK;
+    const int L = e->Lmax, nl = e->cfg.num_layers, NS = IVG_ATTN_PROF_SLOTS;
+    std::vector<unsigned long long> h((size_t)nl * NS * 2 * L);
+    API_CK(hipMemcpy(h.data(), e->attn_prof, h.size() * 8, hipMemcpyDeviceToHost));
+    for (int l = 0; l < nl; ++l)
+      for (int p = 0; p < L; ++p) {
+        unsigned long long s = ~0ull, t = 0;
+        for (int k = 0; k < NS; ++k) {
+          const unsigned long long cs = h[((size_t)(l * NS + k) * 2) * L + p], ct = h[((size_t)(l * NS + k) * 2 + 1) * L + p];
+          if (cs) s = std::min(s, ~cs);
+          t = std::max(t, ct);
+        }
+        if (t == 0 || s == ~0ull || t < s) continue;
+        out->launches++;
+        out->total_ms += (double)(t - s) * 1e-5;   // 100 MHz wall clock -> ms
+        out->total_bytes += 2.0 * e->attn_prof_B * e->heads * (double)(p + 1) * e->hd * dtype_size(e->llm_dt);
+        out->total_flops += 4.0 * e->attn_prof_B * e->heads * (double)(p + 1) * e->hd;
+      }
+    return IVG_OK;
+  }
   ProfClass& pc = e->prof[k];
   out->launches = 0; out->total_ms = 0; out->total_flops = 0; out->total_bytes = 0;
   for (auto& s : pc.used) {

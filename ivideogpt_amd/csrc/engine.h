@@ -92,6 +92,9 @@ struct ivg_engine {
   hipEvent_t fork_ev = nullptr;
   hipEvent_t join_ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   ivg::ProfClass prof[IVG_K_COUNT];
+  unsigned long long* attn_prof = nullptr;  // [layers][IVG_ATTN_PROF_SLOTS][2][Lmax] wall-clock stamps of the decode attention
+  bool attn_prof_on = false;                // ivg_profile_enable(IVG_K_DECODE_ATTN): part of the step-graph key
+  int attn_prof_B = 0;
 
   int fail(int code, const std::string& msg) { err = msg; return code; }
 };

@@ -118,9 +118,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
                                                           T* __restrict__ out, const float* __restrict__ cosT,
                                                           const float* __restrict__ sinT, int heads, int hd, int Lmax,
-                                                          const StepState* __restrict__ state) {
+                                                          const StepState* __restrict__ state, unsigned long long* prof) {
   constexpr int VEC = Traits<T>::VEC;
   constexpr int UNR = 4;
+  // measurement hook (bench.py roofline): launch window = [min start, max end] over workgroups on the 100 MHz wall clock,
+  // reduced per slot here (min kept as max of the complement so that 0 = not stamped) and over slots by the host
+  const unsigned long long t_start = prof ? wall_clock64() : 0ull;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lpk = hd / VEC;          // lanes per key row (8 for bf16 hd=64, 16 for fp32)
   const int gpb = 256 / lpk;         // key groups per workgroup
@@ -224,10 +227,15 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
     for (int g = 0; g < gpb; ++g) a += red[g * hd + tid];
     out[(long)b * H + h * hd + tid] = from_f32<T>(a / sum);
   }
+  if (prof && tid == 0) {
+    unsigned long long* slot = prof + (size_t)((blockIdx.x * 7 + blockIdx.y) % IVG_ATTN_PROF_SLOTS) * 2 * Lmax;
+    atomicMax(slot + pos, ~t_start);
+    atomicMax(slot + Lmax + pos, (unsigned long long)wall_clock64());
+  }
 }
 
 int launch_decode_attn(const void* qkv, void* kc, void* vc, void* out, const float* cosT, const float* sinT, int B, int heads, int hd,
-                       int Lmax, const StepState* state, DType dt, hipStream_t st) {
+                       int Lmax, const StepState* state, unsigned long long* prof, DType dt, hipStream_t st) {
   const int vec = dt == BF16 ? 8 : 4;
   if (hd % vec != 0 || hd > 256 || 256 % (hd / vec) != 0 || (hd & 1)) return (int)hipErrorInvalidValue;
   const int gpb = 256 / (hd / vec);
@@ -235,10 +243,10 @@ int launch_decode_attn(const void* qkv, void* kc, void* vc, void* out, const flo
   dim3 g(B * heads);
   if (dt == BF16)
     hipLaunchKernelGGL(decode_attn_kernel<bf16_t>, g, dim3(256), smem, st, (const bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc, (bf16_t*)out,
-                       cosT, sinT, heads, hd, Lmax, state);
+                       cosT, sinT, heads, hd, Lmax, state, prof);
   else
     hipLaunchKernelGGL(decode_attn_kernel<float>, g, dim3(256), smem, st, (const float*)qkv, (float*)kc, (float*)vc, (float*)out, cosT,
-                       sinT, heads, hd, Lmax, state);
+                       sinT, heads, hd, Lmax, state, prof);
   return (int)hipGetLastError();
 }
 

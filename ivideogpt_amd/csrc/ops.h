@@ -56,8 +56,11 @@ int launch_rope_kv(void* qkv, void* kc, void* vc, void* vt, int ldvt, const floa
                    int heads, int hd, int Lmax, const StepState* state, int pos0, DType dt, hipStream_t st);
 // single-token step: RoPE of q / new k at position *pos, append k, v to the cache, then
 // out[b][h*hd..] = softmax(q.K^T / sqrt(hd)) V over positions [0, *pos]
+// prof (nullable): [IVG_ATTN_PROF_SLOTS][Lmax starts | Lmax ends] wall-clock stamps (100 MHz) of the launch at each cache
+// position; workgroups spread over the slots so the atomics do not serialise on one address
+#define IVG_ATTN_PROF_SLOTS 32
 int launch_decode_attn(const void* qkv, void* kc, void* vc, void* out, const float* cosT, const float* sinT, int B, int heads, int hd,
-                       int Lmax, const StepState* state, DType dt, hipStream_t st);
+                       int Lmax, const StepState* state, unsigned long long* prof, DType dt, hipStream_t st);
 // token decision + embedding of the decided token (+ action embedding on forced sdf slots) + state advance
 struct SampleArgs {
   const float* logits; int V;            // [B][V] fp32 (row stride V)

@@ -185,7 +185,7 @@ static int step_chain(ivg_engine* e, hipStream_t st, const GenBuf& g, int chain,
     s.flags = SK_NORM; s.eps = c.rms_norm_eps;
     CK(launch_skinny(s, dt, st));
     CK(launch_decode_attn(qkv, kc_ptr(e, l, 0) + kv_off, kc_ptr(e, l, 1) + kv_off, attn, e->rope_cos, e->rope_sin, B, e->heads, e->hd,
-                          e->Lmax, state, dt, st));
+                          e->Lmax, state, e->attn_prof_on ? e->attn_prof + (size_t)l * IVG_ATTN_PROF_SLOTS * 2 * e->Lmax : nullptr, dt, st));
     SkinnyArgs o;
     o.X = attn; o.W = w.wo; o.Y = x; o.M = B; o.N = H; o.K = H; o.ldx = H; o.ldw = H; o.ldy = H; o.flags = IG_RESIDUAL;
     CK(launch_skinny(o, dt, st));
@@ -239,6 +239,10 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
   }
   for (int b0 = 0; b0 < B; b0 += g.Bc) {
     const int Bc = std::min(g.Bc, B - b0);
+    if (e->attn_prof_on) {  // fresh launch windows for this call: every stamp slot back to 0 (= not stamped)
+      CK((int)hipMemsetAsync(e->attn_prof, 0, (size_t)c.num_layers * IVG_ATTN_PROF_SLOTS * 2 * e->Lmax * 8, st));
+      e->attn_prof_B = Bc;
+    }
     CK((int)hipMemcpy2DAsync(g.ids, (size_t)g.ids_ld * 8, prompt + (long)b0 * prompt_stride, (size_t)prompt_stride * 8, (size_t)L0 * 8, Bc,
                              hipMemcpyDeviceToDevice, st));
     if (uniforms)
@@ -266,7 +270,7 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
     // step 1 eagerly (also performs every kernel's one-time attribute setup), then replay a captured step graph
     const std::string key = std::to_string(Bc) + ":" + std::to_string(nc) + ":" + (uniforms ? "s" : "g") + ":" + std::to_string(top_k) + ":" +
                             std::to_string(sa.forced_period) + ":" + std::to_string(ctx) + ":" + std::to_string(act_T) + ":" +
-                            std::to_string(L0);
+                            std::to_string(L0) + (e->attn_prof_on ? ":p" : "");
     // reward head: reads the residual stream left by the LAST forward pass, i.e. before the final decide-only step
     // overwrites it with the embedding of the last token (mbrl/video_predictor.py:311-313: hidden state of the last step)
     auto reward = [&]() -> int {
