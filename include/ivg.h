@@ -166,6 +166,9 @@ int ivg_op_add_rmsnorm(void* x, const float* part, int splits, const float* w, v
                        ivg_stream stream);
 int ivg_op_conv_in(const void* video, int video_dtype, const float* w, const float* bias, void* Y, int dtype, int N, int per,
                    int T_total, int t0, int H, int W, int C0, ivg_stream stream);
+/* one top-k draw per logits row [B][V] fp32 with the rollout's sampler (uniforms [B] in [0,1), or NULL = greedy): HF
+ * TopKLogitsWarper + softmax + draw as restated by oracle/llama.py sample_from_logits */
+int ivg_op_sample(const float* logits, int B, int V, int top_k, const float* uniforms, int64_t* out, ivg_stream stream);
 
 #ifdef __cplusplus
 }

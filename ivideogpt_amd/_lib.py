@@ -75,6 +75,7 @@ EXPORTS = {
     "ivg_op_add_rmsnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
                                      C.c_int, C.c_void_p]),
     "ivg_op_conv_in": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]),
+    "ivg_op_sample": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

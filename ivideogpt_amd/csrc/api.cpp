@@ -522,4 +522,20 @@ int ivg_op_conv_in(const void* video, int video_dtype, const float* w, const flo
   return launch_conv_in(video, (DType)video_dtype, w, bias, Y, (DType)dtype, N, per, T_total, t0, H, W, C0, (hipStream_t)stream) ? IVG_ERR_HIP : IVG_OK;
 }
 
+int ivg_op_sample(const float* logits, int B, int V, int top_k, const float* uniforms, int64_t* out, ivg_stream stream) {
+  // one draw per row through the rollout's sampler kernel (token j = 1 of a prompt of length 0; no embedding: H = 0)
+  StepState* state = nullptr;
+  if (hipMalloc((void**)&state, sizeof(StepState)) != hipSuccess) return IVG_ERR_HIP;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = launch_state_set(state, 0, 1, st);
+  SampleArgs sa{};
+  sa.logits = logits; sa.V = V; sa.uniforms = uniforms; sa.n_uni = 1; sa.top_k = top_k;
+  sa.ids_out = out; sa.ids_stride = 1; sa.L0 = 0; sa.forced_period = 0; sa.forced_token = 0;
+  sa.E = logits; sa.x = out; sa.H = 0; sa.act = nullptr; sa.act_T = 0; sa.ctx = 1; sa.slot0 = 0; sa.state = state;
+  if (!rc) rc = launch_sample_embed(sa, B, F32, st);
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(state);
+  return rc ? IVG_ERR_HIP : IVG_OK;
+}
+
 }  // extern "C"

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
                                                           const float* __restrict__ sinT, int heads, int hd, int Lmax,
                                                           const StepState* __restrict__ state, unsigned long long* prof) {
   constexpr int VEC = Traits<T>::VEC;
-  constexpr int UNR = 4;
+  constexpr int UNR = 8;   // 16-byte loads in flight per lane: 3 workgroups x 256 lanes x 8 x 16 B = 96 KiB per CU
   // measurement hook (bench.py roofline): launch window = [min start, max end] over workgroups on the 100 MHz wall clock,
   // reduced per slot here (min kept as max of the complement so that 0 = not stamped) and over slots by the host
   const unsigned long long t_start = prof ? wall_clock64() : 0ull;
@@ -142,6 +142,16 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   const float scale = rsqrtf((float)hd);
   T* kb = kc + ((long)b * heads + h) * Lmax * hd;
   T* vb = vc + ((long)b * heads + h) * Lmax * hd;
+  const int step = gpb * UNR;
+  auto load_rows = [&](Chunk16 (&dst)[UNR], const T* base, int t0) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int t = t0 + u * gpb + grp;
+      dst[u] = t < pos ? *(const Chunk16*)(base + (long)t * hd + sub * VEC) : Chunk16{0u, 0u, 0u, 0u};
+    }
+  };
+  Chunk16 cur[UNR], nxt[UNR];
+  load_rows(cur, kb, 0);  // the first key rows are in flight while q is roped
   if (tid < half) {  // RoPE (HF rotate_half) of q and the new k; append k, v to the cache
     const T* row = qkv + (long)b * 3 * H + h * hd;
     const float c = cosT[(long)pos * half + tid], s = sinT[(long)pos * half + tid];
@@ -160,21 +170,20 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   float qf[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) qf[j] = sq[sub * VEC + j];
-  // pass A: scores of the cached keys (the new key comes from LDS)
-  for (int t0 = 0; t0 < pos; t0 += gpb * UNR) {
-    Chunk16 raw[UNR];
+  // pass A: scores of the cached keys (the new key comes from LDS); the next rows are requested before the current
+  // ones are consumed, and the first value rows before the softmax statistics
+  for (int t0 = 0; t0 < pos; t0 += step) {
+    if (t0 + step < pos) load_rows(nxt, kb, t0 + step);
+    else load_rows(nxt, vb, 0);
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int t = t0 + u * gpb + grp;
-      raw[u] = t < pos ? *(const Chunk16*)(kb + (long)t * hd + sub * VEC) : Chunk16{0u, 0u, 0u, 0u};
-    }
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const int t = t0 + u * gpb + grp;
-      float d = dot_chunk<T>(qf, raw[u]);
+      float d = dot_chunk<T>(qf, cur[u]);
       for (int o = 1; o < lpk; o <<= 1) d += __shfl_xor(d, o, 64);
       if (t < pos && sub == 0) sc[t] = d * scale;
     }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) cur[u] = nxt[u];
   }
   if (grp == 0) {
     float d = 0.f;
@@ -201,18 +210,15 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   float of[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) of[j] = 0.f;
-  for (int t0 = 0; t0 < pos; t0 += gpb * UNR) {
-    Chunk16 raw[UNR];
+  for (int t0 = 0; t0 < pos; t0 += step) {  // cur holds value rows [t0, t0 + step) (requested during pass A / the last iteration)
+    if (t0 + step < pos) load_rows(nxt, vb, t0 + step);
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int t = t0 + u * gpb + grp;
-      raw[u] = t < pos ? *(const Chunk16*)(vb + (long)t * hd + sub * VEC) : Chunk16{0u, 0u, 0u, 0u};
+      if (t < pos) axpy_chunk<T>(of, sc[t], cur[u]);
     }
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const int t = t0 + u * gpb + grp;
-      if (t < pos) axpy_chunk<T>(of, sc[t], raw[u]);
-    }
+    for (int u = 0; u < UNR; ++u) cur[u] = nxt[u];
   }
   if (grp == 0) {
     const float pw = sc[pos];
@@ -260,15 +266,36 @@ __device__ __forceinline__ unsigned f2key(float f) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotone: larger float -> larger key
 }
 
-constexpr int SAMPLE_KPT = 72;  // logits per thread (contiguous segment): vocab <= 256 * 72 = 18432
+constexpr int SAMPLE_CAP = 1024;  // kept-token list (ids + values) of the fast inverse-CDF path
 
-template <typename T>
+// exclusive suffix sum over the 256 threads of a workgroup (thread t receives the sum of threads t+1 .. 255)
+__device__ __forceinline__ int block_suffix_excl(int x, int* s4, int lane, int wv) {
+  int incl = x;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int dn = __shfl_down(incl, o, 64);
+    if (lane + o < 64) incl += dn;
+  }
+  if (lane == 0) s4[wv] = incl;  // wave total
+  __syncthreads();
+  int above = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) if (w > wv) above += s4[w];
+  __syncthreads();
+  return incl - x + above;
+}
+
+template <typename T, int KPT>  // KPT logits per thread (contiguous segment): vocab <= 256 * KPT
 __global__ __launch_bounds__(256) void sample_embed_kernel(SampleArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* lg = (float*)smem;  // [V] staging: coalesced global read, then each thread takes a contiguous segment
+  float* lg = (float*)smem;  // [V] staging: coalesced global read, then each thread takes a contiguous segment;
+                             // afterwards the values of the kept tokens (fast path)
   __shared__ float s_f[4];
   __shared__ int s_i[4];
-  __shared__ int s_cnt[2][4];
+  __shared__ int s4[4];
+  __shared__ int s_sel[2];
+  __shared__ int hist[2048];
+  __shared__ int kid[SAMPLE_CAP];
   __shared__ double s_w[4];
   __shared__ long s_tok;
   __shared__ double s_target;
@@ -286,11 +313,11 @@ __global__ __launch_bounds__(256) void sample_embed_kernel(SampleArgs a) {
     __syncthreads();
     const int seg = (V + 255) / 256;
     const int i0 = tid * seg;
-    float v[SAMPLE_KPT];
+    float v[KPT];
     float mx = -INFINITY;
     int mi = 0x7fffffff;
 #pragma unroll
-    for (int q = 0; q < SAMPLE_KPT; ++q) {
+    for (int q = 0; q < KPT; ++q) {
       const int i = i0 + q;
       v[q] = (q < seg && i < V) ? lg[i] : -INFINITY;
       if (v[q] > mx) { mx = v[q]; mi = i; }  // ascending index: the first maximum is kept
@@ -309,64 +336,129 @@ __global__ __launch_bounds__(256) void sample_embed_kernel(SampleArgs a) {
     if (a.uniforms == nullptr) {
       tok = mi;
     } else {
-      // ---- key of the k-th largest logit: bitwise binary search (largest T with #{key >= T} >= k)
-      unsigned key[SAMPLE_KPT];
+      // ---- key of the k-th largest logit (= largest T with #{key >= T} >= k): radix select, digits of 11 / 11 / 10 bits,
+      //      one LDS histogram per digit over the keys that match the digits found so far (integer counts: exact)
+      unsigned key[KPT];
 #pragma unroll
-      for (int q = 0; q < SAMPLE_KPT; ++q) key[q] = f2key(v[q]);
-      const int k = a.top_k < V ? a.top_k : V;
-      unsigned prefix = 0u;
-      for (int bit = 31; bit >= 0; --bit) {
-        const unsigned cand = prefix | (1u << bit);
-        int cnt = 0;
+      for (int q = 0; q < KPT; ++q) key[q] = f2key(v[q]);
+      int kk = a.top_k < V ? a.top_k : V;
+      unsigned prefix = 0u, pmask = 0u;
 #pragma unroll
-        for (int q = 0; q < SAMPLE_KPT; ++q) cnt += (key[q] >= cand) ? 1 : 0;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-        if (lane == 0) s_cnt[bit & 1][wv] = cnt;
+      for (int pass = 0; pass < 3; ++pass) {
+        const int shift = pass == 0 ? 21 : (pass == 1 ? 10 : 0);
+        const int nb = pass == 2 ? 1024 : 2048, per = nb / 256;
+        for (int i = tid; i < nb; i += 256) hist[i] = 0;
         __syncthreads();
-        const int total = s_cnt[bit & 1][0] + s_cnt[bit & 1][1] + s_cnt[bit & 1][2] + s_cnt[bit & 1][3];
-        if (total >= k) prefix = cand;
+#pragma unroll
+        for (int q = 0; q < KPT; ++q)
+          if (q < seg && i0 + q < V && (key[q] & pmask) == prefix) atomicAdd(&hist[(key[q] >> shift) & (nb - 1)], 1);
+        __syncthreads();
+        int mine = 0;
+        for (int r = 0; r < per; ++r) mine += hist[tid * per + r];
+        const int above = block_suffix_excl(mine, s4, lane, wv);  // keys in bins above this thread's bins
+        if (above < kk && kk <= above + mine) {                    // exactly one thread: the digit is in its bins
+          int acc = above, d = tid * per + per - 1;
+          for (; d > tid * per; --d) { if (acc + hist[d] >= kk) break; acc += hist[d]; }
+          s_sel[0] = d; s_sel[1] = kk - acc;
+        }
+        __syncthreads();
+        prefix |= (unsigned)s_sel[0] << shift;
+        pmask |= (unsigned)(nb - 1) << shift;
+        kk = s_sel[1];
       }
       const unsigned thr = prefix;  // everything >= thr is kept (ties at the threshold included, as HF's masked_fill)
       // ---- inverse CDF in ascending id order, fp64 (oracle: double cumsum of exp(logit - max) over the kept ids)
-      double part = 0.0;
+      int cnt = 0;
 #pragma unroll
-      for (int q = 0; q < SAMPLE_KPT; ++q)
-        if (key[q] >= thr && v[q] > -INFINITY) part += exp((double)(v[q] - mx));
-      double incl = part;  // inclusive scan over threads (thread order == id order)
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const double up = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += up;
-      }
-      if (lane == 63) s_w[wv] = incl;
+      for (int q = 0; q < KPT; ++q) cnt += (key[q] >= thr && v[q] > -INFINITY) ? 1 : 0;
+      const int after = block_suffix_excl(cnt, s4, lane, wv);
+      if (tid == 0) s_sel[0] = after + cnt;  // number of kept tokens
       __syncthreads();
-      double base = 0.0, total = 0.0;
+      const int n_kept = s_sel[0];
+      if (n_kept <= SAMPLE_CAP) {
+        // fast path: the kept tokens (about top_k of them) are compacted in ascending id order and spread over the threads,
+        // so the fp64 exponentials run once each, in parallel
+        int off = n_kept - after - cnt;  // kept tokens in lower threads = lower ids
 #pragma unroll
-      for (int w = 0; w < 4; ++w) { if (w < wv) base += s_w[w]; total += s_w[w]; }
-      incl += base;
-      double excl = __shfl_up(incl, 1, 64);
-      if (lane == 0) excl = base;
-      if (tid == 0) s_target = (double)a.uniforms[(long)b * a.n_uni + (j - 1)] * total;
-      __syncthreads();
-      const double target = s_target;
-      // intervals [excl, incl) tile [0, total) exactly (incl of thread t IS excl of thread t+1)
-      if (part > 0.0 && excl <= target && target < incl) {
-        double run = excl;
-        long found = -1, last = -1;
+        for (int q = 0; q < KPT; ++q)
+          if (key[q] >= thr && v[q] > -INFINITY) { lg[off] = v[q]; kid[off] = i0 + q; ++off; }
+        __syncthreads();
+        const int per = (n_kept + 255) / 256;  // <= 4
+        const int e0 = tid * per, e1 = min(n_kept, e0 + per);
+        double ex[SAMPLE_CAP / 256];
+        double part = 0.0;
 #pragma unroll
-        for (int q = 0; q < SAMPLE_KPT; ++q) {
-          if (key[q] >= thr && v[q] > -INFINITY) {
-            run += exp((double)(v[q] - mx));
-            last = i0 + q;
-            if (found < 0 && run > target) found = i0 + q;
-          }
+        for (int r = 0; r < SAMPLE_CAP / 256; ++r) {
+          ex[r] = (e0 + r < e1) ? exp((double)(lg[e0 + r] - mx)) : 0.0;
+          part += ex[r];
         }
-        s_tok = found >= 0 ? found : last;  // rounding at the segment edge: the segment's last kept token
+        double incl = part;  // inclusive scan over threads (thread order == id order)
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const double up = __shfl_up(incl, o, 64);
+          if (lane >= o) incl += up;
+        }
+        if (lane == 63) s_w[wv] = incl;
+        __syncthreads();
+        double base = 0.0, total = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { if (w < wv) base += s_w[w]; total += s_w[w]; }
+        incl += base;
+        double excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = base;
+        const double target = (double)a.uniforms[(long)b * a.n_uni + (j - 1)] * total;
+        // intervals [excl, incl) tile [0, total) exactly (incl of thread t IS excl of thread t+1)
+        if (e0 < e1 && excl <= target && target < incl) {
+          double run = excl;
+          int found = -1;
+#pragma unroll
+          for (int r = 0; r < SAMPLE_CAP / 256; ++r)
+            if (e0 + r < e1) { run += ex[r]; if (found < 0 && run > target) found = kid[e0 + r]; }
+          s_tok = found >= 0 ? found : kid[e1 - 1];  // rounding at the chunk edge: the chunk's last kept token
+        }
+        __syncthreads();
+        tok = s_tok;
+        if (tok < 0) tok = mi;  // unreachable for u in [0, 1): defensive
+      } else {
+        // general path (massive ties at the threshold): every thread walks its own id segment
+        double part = 0.0;
+#pragma unroll
+        for (int q = 0; q < KPT; ++q)
+          if (key[q] >= thr && v[q] > -INFINITY) part += exp((double)(v[q] - mx));
+        double incl = part;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const double up = __shfl_up(incl, o, 64);
+          if (lane >= o) incl += up;
+        }
+        if (lane == 63) s_w[wv] = incl;
+        __syncthreads();
+        double base = 0.0, total = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { if (w < wv) base += s_w[w]; total += s_w[w]; }
+        incl += base;
+        double excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = base;
+        if (tid == 0) s_target = (double)a.uniforms[(long)b * a.n_uni + (j - 1)] * total;
+        __syncthreads();
+        const double target = s_target;
+        if (part > 0.0 && excl <= target && target < incl) {
+          double run = excl;
+          long found = -1, last = -1;
+#pragma unroll
+          for (int q = 0; q < KPT; ++q) {
+            if (key[q] >= thr && v[q] > -INFINITY) {
+              run += exp((double)(v[q] - mx));
+              last = i0 + q;
+              if (found < 0 && run > target) found = i0 + q;
+            }
+          }
+          s_tok = found >= 0 ? found : last;
+        }
+        __syncthreads();
+        tok = s_tok;
+        if (tok < 0) tok = mi;
       }
-      __syncthreads();
-      tok = s_tok;
-      if (tok < 0) tok = mi;  // unreachable for u in [0, 1): defensive
     }
   }
   if (tid == 0) a.ids_out[(long)b * a.ids_stride + a.L0 + (j - 1)] = (int64_t)tok;
@@ -382,17 +474,22 @@ __global__ __launch_bounds__(256) void sample_embed_kernel(SampleArgs a) {
   }
 }
 
-int launch_sample_embed(const SampleArgs& a, int B, DType dt, hipStream_t st) {
-  const size_t smem = (size_t)a.V * sizeof(float);
+template <typename T, int KPT>
+static void launch_sample_t(const SampleArgs& a, int B, size_t smem, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)sample_embed_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    (void)hipFuncSetAttribute((const void*)sample_embed_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void*)sample_embed_kernel<T, KPT>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     attr_set = true;
   }
-  if (a.V > 256 * SAMPLE_KPT || smem > 96 * 1024) return (int)hipErrorInvalidValue;
-  if (dt == BF16) hipLaunchKernelGGL(sample_embed_kernel<bf16_t>, dim3(B), dim3(256), smem, st, a);
-  else hipLaunchKernelGGL(sample_embed_kernel<float>, dim3(B), dim3(256), smem, st, a);
+  hipLaunchKernelGGL((sample_embed_kernel<T, KPT>), dim3(B), dim3(256), smem, st, a);
+}
+
+int launch_sample_embed(const SampleArgs& a, int B, DType dt, hipStream_t st) {
+  const size_t smem = (size_t)std::max(a.V, SAMPLE_CAP) * sizeof(float);
+  if (a.V > 256 * 72 || smem > 96 * 1024) return (int)hipErrorInvalidValue;
+  const bool small = a.V <= 256 * 36;
+  if (dt == BF16) { if (small) launch_sample_t<bf16_t, 36>(a, B, smem, st); else launch_sample_t<bf16_t, 72>(a, B, smem, st); }
+  else { if (small) launch_sample_t<float, 36>(a, B, smem, st); else launch_sample_t<float, 72>(a, B, smem, st); }
   return (int)hipGetLastError();
 }
 

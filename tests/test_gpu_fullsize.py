@@ -1,0 +1,174 @@
+"""BASELINE.json full sizes (config 2: 64 trajectories x 16 frames of 64x64, ctx_vae64 tokenizer, 12-layer Llama, bf16 decode +
+rollout as benchmarked): the CPU oracle cannot finish these in seconds, so the checks are the size-independent properties
+the prediction path offers -- all of them exact (the engine has no atomics on data and fixed reduction orders):
+
+  * batch invariance: a trajectory's tokens / pixels / rollout do not depend on the rows it shares a batch with
+    (what makes the weak-scaling batch shard of bench.py exact);
+  * prefix property of the rollout: the first n tokens of a long rollout == a short rollout with the same uniforms;
+  * graph replay == eager launches;  detokenize with a reused context cache == detokenize from scratch;
+  * token layout of the reference (compressive_vq_model.py:204-218): context codes < n_vq, dynamics codes in
+    [n_vq, n_vq + n_dyn), separator n_vq + n_dyn between context frames and n_vq + n_dyn + 1 (``sdf``) in front of every
+    future frame; forced ``sdf`` in action mode;
+  * the three-call composition == pipeline.predict_frames.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+B, T, CTX, RES = 64, 16, 2, 64
+
+
+@pytest.fixture(scope="module")
+def models():
+    from ivideogpt_amd import CompressiveVQModel, LlamaForCausalLM
+    from ivideogpt_amd import weights as W
+    tcfg = W.tokenizer_config(**W.CTX_VAE64)
+    tok = CompressiveVQModel(tcfg, W.random_tokenizer_state_dict(tcfg, 5, codebook_std=0.4), encode_dtype="fp32",
+                             decode_dtype="bf16").to(DEV)
+    lcfg = dict(W.LLAMA_SMALL)
+    llm = LlamaForCausalLM(lcfg, W.random_llama_state_dict(lcfg, 6), dtype="bf16").to(DEV)
+    g = torch.Generator().manual_seed(17)
+    base = torch.rand(B, 1, 3, RES, RES, generator=g)
+    px = (base + 0.15 * torch.rand(B, T, 3, RES, RES, generator=g)).clamp(0, 1).to(DEV)   # correlated frames, like a clip
+    return tok, llm, px, tcfg, lcfg
+
+
+def test_tokenize_full_batch_layout_and_batch_invariance(models):
+    tok, llm, px, tcfg, lcfg = models
+    ids, labels = tok.tokenize(px, CTX)
+    F = T - CTX
+    assert ids.shape == (B, 257 * CTX - 1 + 17 * F) and labels.shape == ids.shape
+    n_vq, n_dyn = tcfg["num_vq_embeddings"], tcfg["num_dyn_embeddings"]
+    scf = n_vq + n_dyn                        # context-frame separator; scf + 1 opens every future frame (``sdf``)
+    host = ids.cpu()
+    pos = torch.arange(host.shape[1])
+    in_ctx = pos < 257 * CTX - 1
+    is_sep = torch.where(in_ctx, (pos % 257) == 256, ((pos - (257 * CTX - 1)) % 17) == 0)
+    assert (host[:, in_ctx & is_sep] == scf).all() and (host[:, ~in_ctx & is_sep] == scf + 1).all()
+    assert (host[:, in_ctx & ~is_sep] < n_vq).all() and (host[:, in_ctx & ~is_sep] >= 0).all()
+    dyn = host[:, ~in_ctx & ~is_sep]
+    assert (dyn >= n_vq).all() and (dyn < n_vq + n_dyn).all()
+    lab = labels.cpu()
+    assert (lab[:, :257 * CTX] == -100).all() and torch.equal(lab[:, 257 * CTX:], host[:, 257 * CTX:])   # :216-218 context is not a target
+    again, _ = tok.tokenize(px, CTX)
+    assert torch.equal(again, ids)
+    for b in (0, 17, 63):
+        one, _ = tok.tokenize(px[b:b + 1], CTX)
+        assert torch.equal(one[0], ids[b]), f"row {b} depends on its batch"
+    sub, _ = tok.tokenize(px[32:], CTX)       # the second rank's shard of a 2-GPU run
+    assert torch.equal(sub, ids[32:])
+    assert torch.equal(tok.encode_context(px, CTX), ids[:, :257 * CTX])
+
+
+def test_detokenize_full_batch_invariance_and_cache(models):
+    tok, llm, px, tcfg, lcfg = models
+    ids, _ = tok.tokenize(px, CTX)
+    rec = tok.detokenize(ids, CTX)
+    assert rec.shape == (B, T, 3, RES, RES) and torch.isfinite(rec).all()
+    assert torch.equal(tok.detokenize(ids, CTX), rec)
+    for b in (0, 40, 63):
+        assert torch.equal(tok.detokenize(ids[b:b + 1], CTX)[0], rec[b]), f"row {b} depends on its batch"
+    assert torch.equal(tok.detokenize(ids[32:], CTX), rec[32:])
+    # context frames decode independently of how many future frames follow; a reused context cache changes nothing
+    short = ids[:, :257 * CTX - 1 + 17 * 3]
+    rec3, cache = tok.detokenize(short, CTX, return_cache=True)
+    assert torch.equal(rec3, rec[:, :CTX + 3])
+    assert torch.equal(tok.detokenize(ids, CTX, cache=cache), rec)
+
+
+def test_rollout_full_batch_properties(models, monkeypatch):
+    tok, llm, px, tcfg, lcfg = models
+    prompt = tok.encode_context(px, CTX)
+    F = T - CTX
+    n_new = 17 * F - 1
+    u = torch.rand(B, n_new, generator=torch.Generator().manual_seed(3)).to(DEV)
+    out = llm.generate(prompt, do_sample=True, top_k=100, max_new_tokens=n_new, uniforms=u)
+    assert out.shape == (B, 257 * CTX + n_new) and torch.equal(out[:, :257 * CTX], prompt)
+    assert (out >= 0).all() and (out < lcfg["vocab_size"]).all()
+    assert torch.equal(llm.generate(prompt, do_sample=True, top_k=100, max_new_tokens=n_new, uniforms=u), out)
+    # rows do not see each other: a permuted batch gives permuted rollouts; a 2-rank shard equals the whole
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(4)).to(DEV)
+    assert torch.equal(llm.generate(prompt[perm], do_sample=True, top_k=100, max_new_tokens=n_new, uniforms=u[perm]), out[perm])
+    assert torch.equal(llm.generate(prompt[32:], do_sample=True, top_k=100, max_new_tokens=n_new, uniforms=u[32:]), out[32:])
+    # prefix property
+    n_short = 40
+    short = llm.generate(prompt, do_sample=True, top_k=100, max_new_tokens=n_short, uniforms=u[:, :n_short].contiguous())
+    assert torch.equal(short, out[:, :257 * CTX + n_short])
+    # top_k = 1 sampling == greedy
+    greedy = llm.generate(prompt[:8], do_sample=False, max_new_tokens=n_short)
+    top1 = llm.generate(prompt[:8], do_sample=True, top_k=1, max_new_tokens=n_short, uniforms=u[:8, :n_short].contiguous())
+    assert torch.equal(greedy, top1)
+    # eager launches == replayed step graph
+    monkeypatch.setenv("IVG_NO_GRAPH", "1")
+    from ivideogpt_amd import LlamaForCausalLM
+    from ivideogpt_amd import weights as W
+    eager = LlamaForCausalLM(lcfg, W.random_llama_state_dict(lcfg, 6), dtype="bf16").to(DEV)
+    assert torch.equal(eager.generate(prompt[:16], do_sample=True, top_k=100, max_new_tokens=60, uniforms=u[:16, :60].contiguous()),
+                       out[:16, :257 * CTX + 60])
+
+
+def test_teacher_forced_logits_agree_with_rollout_decisions(models):
+    """the cached single-token steps and the one-shot causal forward are two schedules of the same network: the greedy
+    token at every step must be the argmax of the teacher-forced logits of the finished sequence (bf16: a logit gap
+    below the bf16 noise floor may flip, so near-ties are exempt)."""
+    tok, llm, px, tcfg, lcfg = models
+    prompt = tok.encode_context(px[:8], CTX)
+    n_new = 50
+    out = llm.generate(prompt, do_sample=False, max_new_tokens=n_new)
+    lg = llm.logits(out)[:, 257 * CTX - 1:-1]            # logits that decided tokens L0 .. L0 + n_new - 1
+    chosen = out[:, 257 * CTX:]
+    top2 = lg.topk(2, dim=-1)
+    agree = top2.indices[..., 0] == chosen
+    near_tie = (top2.values[..., 0] - top2.values[..., 1]) < 0.3    # bf16 logits carry ~0.1 of rounding noise
+    assert (agree | near_tie).all(), f"{(~(agree | near_tie)).sum().item()} greedy decisions disagree with the teacher-forced argmax"
+    assert agree.float().mean() > 0.9
+
+
+def test_action_conditioned_full_batch(models):
+    from ivideogpt_amd import HeadModelWithAction, LlamaForCausalLM
+    from ivideogpt_amd import weights as W
+    tok, _, px, tcfg, _ = models
+    ctx, adim, Bc = 1, 4, 64
+    lcfg = dict(W.LLAMA_SMALL)
+    head = HeadModelWithAction(LlamaForCausalLM(lcfg, None, dtype="bf16"), adim, 257 * ctx - 1, 16, ctx, T)
+    head.load_state_dict(W.random_llama_state_dict(lcfg, 8, action_dim=adim), strict=True)
+    head.to(DEV)
+    tok.set_context_length(ctx)
+    try:
+        prompt = tok.encode_context(px[:Bc], ctx)
+    finally:
+        tok.set_context_length(CTX)
+    F = T - ctx
+    n_new = 17 * F - 1
+    g = torch.Generator().manual_seed(12)
+    act = torch.randn(Bc, T, adim, generator=g).to(DEV)
+    u = torch.rand(Bc, n_new, generator=g).to(DEV)
+    out = head.generate(prompt, do_sample=True, top_k=100, max_new_tokens=n_new, action=act, uniforms=u)
+    new = out[:, 257 * ctx:]
+    slots = torch.arange(1, n_new + 1) % 17 == 0
+    assert (new[:, slots] == lcfg["vocab_size"] - 1).all()                       # forced sdf after every 16 tokens (action_model.py:112)
+    assert torch.equal(head.generate(prompt[20:30], do_sample=True, top_k=100, max_new_tokens=n_new, action=act[20:30], uniforms=u[20:30]),
+                       out[20:30])
+    # actions matter, and only from their own frame on: changing the action of frame t leaves the tokens before slot t alone
+    act2 = act.clone()
+    t_change = 6
+    act2[:, t_change] += 3.0
+    out2 = head.generate(prompt, do_sample=True, top_k=100, max_new_tokens=n_new, action=act2, uniforms=u)
+    first = 257 * ctx + 17 * (t_change - ctx + 1) - 1    # the sdf slot that carries action[t_change] (i + ctx - 1 = t_change)
+    assert torch.equal(out2[:, :first + 1], out[:, :first + 1])
+    assert not torch.equal(out2[:, first + 1:], out[:, first + 1:])
+
+
+def test_predict_frames_equals_three_calls(models):
+    from ivideogpt_amd.pipeline import predict_frames
+    tok, llm, px, tcfg, lcfg = models
+    F = T - CTX
+    g1 = torch.Generator(device=DEV).manual_seed(5)
+    frames = predict_frames(tok, llm, px, CTX, F, do_sample=True, top_k=100, generator=g1)
+    g2 = torch.Generator(device=DEV).manual_seed(5)
+    prompt = tok.encode_context(px, CTX)
+    toks = llm.generate(prompt, do_sample=True, top_k=100, max_new_tokens=17 * F - 1, generator=g2)
+    want = tok.detokenize(toks, CTX).clamp(0.0, 1.0)
+    assert frames.shape == (B, T, 3, RES, RES) and torch.equal(frames, want)
+    assert frames.min() >= 0 and frames.max() <= 1

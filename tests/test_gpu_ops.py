@@ -323,3 +323,38 @@ def test_conv_in_from_video(dt):
     assert l.ivg_op_conv_in(P(vd), 0, P(wd), P(bd), P(Y), code(dt), B * per, per, T, t0, H, H, C0, stream()) == 0
     torch.cuda.synchronize()
     assert rel_err(Y.float().permute(0, 3, 1, 2), ref) < (1e-5 if dt == "fp32" else 1e-2)
+
+
+@pytest.mark.parametrize("case", ["normal", "wide_vocab", "ties_at_threshold", "all_equal", "topk_ge_vocab", "tiny_vocab", "heavy_ties"])
+def test_sampler_matches_oracle(case):
+    """top-k(100) + softmax + draw: radix-select threshold, ties at the threshold kept (HF masked_fill semantics), explicit
+    uniform inverse CDF in ascending id order -- bit-identical tokens to oracle/llama.py sample_from_logits."""
+    from oracle.llama import sample_from_logits
+    L, l = lib()
+    g = torch.Generator().manual_seed(sum(map(ord, case)))
+    B, V, k = 64, 8194, 100
+    if case == "wide_vocab":
+        V = 16386
+    if case == "tiny_vocab":
+        V, k = 70, 100
+    logits = torch.randn(B, V, generator=g) * 3
+    if case == "ties_at_threshold":      # 300 copies of the 100-th largest value: all of them stay in the kept set
+        kth = torch.topk(logits, k, dim=-1).values[:, -1:]
+        idx = torch.randint(0, V, (B, 300), generator=g)
+        logits.scatter_(1, idx, kth.expand(B, 300))
+    if case == "all_equal":              # every token kept: the general (non-compacted) CDF path
+        logits = torch.full((B, V), 1.25)
+    if case == "heavy_ties":             # quantised logits: ~2,000 tokens tie at the threshold (> the compaction capacity)
+        logits = torch.round(logits)
+    if case == "topk_ge_vocab":
+        k = V + 5
+    logits[1, 7] = float("-inf")
+    u = torch.rand(B, generator=g)
+    u[0], u[2] = 0.0, 0.99999994
+    want = sample_from_logits(logits, k, u)
+    lg, ud = logits.to(DEV), u.to(DEV)
+    out = torch.full((B,), -7, dtype=torch.int64, device=DEV)
+    assert l.ivg_op_sample(P(lg), B, V, k, P(ud), P(out), stream()) == 0
+    assert torch.equal(out.cpu(), want), (out.cpu() != want).nonzero().flatten().tolist()
+    assert l.ivg_op_sample(P(lg), B, V, k, None, P(out), stream()) == 0
+    assert torch.equal(out.cpu(), sample_from_logits(logits, k, None))
