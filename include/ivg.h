@@ -4,7 +4,7 @@
  *   CompressiveVQModel.{tokenize, detokenize, set_context_length}   ivideogpt/vq_model/compressive_vq_model.py:154-277
  *   LlamaForCausalLM.generate / HeadModelWithAction.generate       ivideogpt/transformer/action_model.py:56-121
  * (SURVEY.md 8b).  Each entry point below replaces one of those methods; the Python mirror of the
- * reference classes (ivideogpt_amd/*.py) binds them with ctypes, and INTEGRATION.md shows the stub a
+ * reference classes (the ivideogpt_amd package) binds them with ctypes, and INTEGRATION.md shows the stub a
  * maintainer of the reference would add.
  *
  * Conventions

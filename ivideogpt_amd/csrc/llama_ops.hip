@@ -2,6 +2,8 @@
 // All step-dependent scalars (cache length, index of the token being decided) live in a device-side
 // StepState so the whole per-token kernel sequence has constant arguments and can be captured once
 // into a hipGraph and replayed for every generated token.
+#include <cstdlib>
+
 #include "ops.h"
 
 namespace ivg {
@@ -80,6 +82,116 @@ int launch_rope_kv(void* qkv, void* kc, void* vc, void* vt, int ldvt, const floa
   else
     hipLaunchKernelGGL(rope_kv_kernel<float>, g, dim3(256), 0, st, (float*)qkv, (float*)kc, (float*)vc, (float*)vt, ldvt, cosT, sinT,
                        B, L, heads, hd, Lmax, state, pos0);
+  return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ prefill attention
+// Causal self-attention of a prompt (positions 0 .. L-1) in one pass, bf16 / head_dim 64: replaces the score GEMM, the row
+// softmax and the P.V GEMM of the prefill (and their fp32 score matrix in HBM: 910 MB per layer at config 2).
+// Workgroup = 64 query rows of one (trajectory, head); wave = 16 query rows against every key tile up to the diagonal:
+//   S = K Q^T      a = K rows (cache, roped), b = Q rows (roped in place by rope_kv)  -> lane: S[key = 4*lg + r][q = lr]
+//   online softmax in fp32 (running max / sum per query row; a row lives in the 4 lanes lr, lr+16, lr+32, lr+48)
+//   O += V^T P     a = rows of V^T (vt, [d][key]), b = P cast to bf16: the lane's own S registers ARE its P fragment when
+//                  the K dimension of this MFMA enumerates the keys as (4*lg + r, 16 + 4*lg + r) -- V^T is read in the
+//                  same order, so no cross-lane movement is needed          -> lane: O[d = 4*lg + r][q = lr]
+// Key rows beyond the diagonal are masked by select (never by arithmetic: cache rows past L may hold anything).
+__global__ __launch_bounds__(256) void flash_prefill_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ kc,
+                                                            const bf16_t* __restrict__ vt, bf16_t* __restrict__ out, int L, int Lp,
+                                                            int heads, int Lmax, float scale) {
+  constexpr int HD = 64;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lg = lane >> 4;
+  const int qt = gridDim.x - 1 - blockIdx.x;   // long rows (many key tiles) are scheduled first
+  const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
+  const int H = heads * HD;
+  const int q = qt * 64 + wave * 16 + lr;
+  const int qc = q < L ? q : L - 1;
+  const bf16_t* qrow = qkv + ((long)b * L + qc) * 3 * H + h * HD;
+  const bf16x8 qf0 = *(const bf16x8*)(qrow + lg * 8), qf1 = *(const bf16x8*)(qrow + 32 + lg * 8);
+  const bf16_t* kb = kc + (long)bh * Lmax * HD;
+  const bf16_t* vb = vt + (long)bh * HD * Lp;
+  f32x4 o[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, lsum = 0.f;
+  for (int kt = 0; kt <= qt; ++kt) {
+    const int k0 = kt * 64;
+    bf16x8 kf[4][2];
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      const int kr = k0 + sub * 16 + lr;
+      const bf16_t* krow = kb + (long)(kr < Lmax ? kr : Lmax - 1) * HD;   // rows past the diagonal are masked below
+      kf[sub][0] = *(const bf16x8*)(krow + lg * 8);
+      kf[sub][1] = *(const bf16x8*)(krow + 32 + lg * 8);
+    }
+    bf16x4 vf[4][2][2];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const bf16_t* vrow = vb + (long)(d * 16 + lr) * Lp + k0 + pr * 32 + lg * 4;
+        vf[d][pr][0] = *(const bf16x4*)vrow;
+        vf[d][pr][1] = *(const bf16x4*)(vrow + 16);
+      }
+    f32x4 sc[4];
+    float mt = -INFINITY;
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      sc[sub] = f32x4{0.f, 0.f, 0.f, 0.f};
+      sc[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[sub][0], qf0, sc[sub], 0, 0, 0);
+      sc[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[sub][1], qf1, sc[sub], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = k0 + sub * 16 + lg * 4 + r;
+        sc[sub][r] = key <= q ? sc[sub][r] * scale : -INFINITY;
+        mt = fmaxf(mt, sc[sub][r]);
+      }
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float mn = fmaxf(m, mt);            // finite: key 0 <= q is in the first tile of every row
+    const float alpha = expf(m - mn);         // first tile: exp(-inf) = 0
+    m = mn;
+    float ps = 0.f;
+    bf16x8 pf[2];
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pv = expf(sc[sub][r] - mn);
+        ps += pv;
+        pf[sub >> 1][(sub & 1) * 4 + r] = (bf16_t)pv;
+      }
+    lsum = lsum * alpha + ps;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[d][r] *= alpha;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const bf16x8 va = __builtin_shufflevector(vf[d][pr][0], vf[d][pr][1], 0, 1, 2, 3, 4, 5, 6, 7);
+        o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pf[pr], o[d], 0, 0, 0);
+      }
+    }
+  }
+  lsum += __shfl_xor(lsum, 16, 64);
+  lsum += __shfl_xor(lsum, 32, 64);
+  if (q < L) {
+    const float inv = 1.0f / lsum;
+    bf16_t* orow = out + ((long)b * L + q) * H + h * HD + lg * 4;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+      *(bf16x4*)(orow + d * 16) = bf16x4{(bf16_t)(o[d][0] * inv), (bf16_t)(o[d][1] * inv), (bf16_t)(o[d][2] * inv), (bf16_t)(o[d][3] * inv)};
+  }
+}
+
+// qkv: [B*L][3H] with q already roped in place; kc: roped keys [B][heads][Lmax][64]; vt: V^T [B][heads][64][Lp] (finite
+// beyond L); out [B*L][H].  bf16, head_dim 64 only (returns -1 otherwise: the caller keeps the three-kernel path).
+int launch_flash_prefill(const void* qkv, const void* kc, const void* vt, void* out, int B, int L, int Lp, int heads, int hd, int Lmax,
+                         DType dt, hipStream_t st) {
+  if (dt != BF16 || hd != 64 || L <= 0 || Lp % 64 != 0 || Lp < L) return -1;
+  dim3 grid((unsigned)cdiv(L, 64), (unsigned)(B * heads));
+  hipLaunchKernelGGL(flash_prefill_kernel, grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)kc, (const bf16_t*)vt, (bf16_t*)out, L,
+                     Lp, heads, Lmax, 1.0f / sqrtf((float)hd));
   return (int)hipGetLastError();
 }
 

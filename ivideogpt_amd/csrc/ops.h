@@ -56,6 +56,9 @@ int launch_rope_kv(void* qkv, void* kc, void* vc, void* vt, int ldvt, const floa
                    int heads, int hd, int Lmax, const StepState* state, int pos0, DType dt, hipStream_t st);
 // single-token step: RoPE of q / new k at position *pos, append k, v to the cache, then
 // out[b][h*hd..] = softmax(q.K^T / sqrt(hd)) V over positions [0, *pos]
+// causal prompt attention in one kernel (bf16, head_dim 64); -1 = not covered, use the score GEMM / softmax / P.V path
+int launch_flash_prefill(const void* qkv, const void* kc, const void* vt, void* out, int B, int L, int Lp, int heads, int hd, int Lmax,
+                         DType dt, hipStream_t st);
 // prof (nullable): [IVG_ATTN_PROF_SLOTS][Lmax starts | Lmax ends] wall-clock stamps (100 MHz) of the launch at each cache
 // position; workgroups spread over the slots so the atomics do not serialise on one address
 #define IVG_ATTN_PROF_SLOTS 32

@@ -63,6 +63,11 @@ static char* kc_ptr(const ivg_engine* e, int layer, int which) {
 }
 
 // -------------------------------------------------------------------------------------------- prefill
+static bool flash_prefill_covers(DType dt, int hd) {
+  const char* v = getenv("IVG_FLASH_PREFILL");   // IVG_FLASH_PREFILL=0: score GEMM + softmax + P.V GEMM (A/B tests)
+  return !(v && v[0] == '0') && dt == BF16 && hd == 64;
+}
+
 int Run::prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const void* act_emb, int act_T, int ctx, bool all_slots,
                  float* logits_all, float* logits_last, void* hidden_last) {
   const ivg_config& c = e->cfg;
@@ -76,8 +81,9 @@ int Run::prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const voi
   char* qkv = (char*)e->ws.alloc((size_t)M * 3 * H * esz(dt));
   char* attn = (char*)e->ws.alloc((size_t)M * H * esz(dt));
   char* act = (char*)e->ws.alloc((size_t)M * I * esz(dt));
-  float* S = (float*)e->ws.alloc((size_t)B * heads * L * Lp * 4);
-  char* Pm = (char*)e->ws.alloc((size_t)B * heads * L * Lp * esz(dt));
+  const bool flash = flash_prefill_covers(dt, hd);   // one-pass causal attention: no score matrix in HBM
+  float* S = flash ? nullptr : (float*)e->ws.alloc((size_t)B * heads * L * Lp * 4);
+  char* Pm = flash ? nullptr : (char*)e->ws.alloc((size_t)B * heads * L * Lp * esz(dt));
   if (!planning) {
     CK(launch_embed(ids, ids_stride, e->embed, x, dt, B, L, H, st));
     if (act_emb) {  // action embedding on the sdf slot(s): slot i (position 257*ctx - 1 + 17*i) gets action i + ctx - 1
@@ -97,6 +103,9 @@ int Run::prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const voi
     IVG_TRY(linear(dt, xn, M, wq, qkv, nullptr, 0, 0));
     if (!planning)
       CK(launch_rope_kv(qkv, kc_ptr(e, l, 0), kc_ptr(e, l, 1), e->vt, Lp, e->rope_cos, e->rope_sin, B, L, heads, hd, Lmax, nullptr, 0, dt, st));
+    if (flash) {
+      if (!planning) CK(launch_flash_prefill(qkv, kc_ptr(e, l, 0), e->vt, attn, B, L, Lp, heads, hd, Lmax, dt, st));
+    } else {
     {  // S[b][h] = Q K^T / sqrt(hd)
       IgemmArgs g;
       g.X = qkv; g.W = kc_ptr(e, l, 0); g.Y = S;
@@ -119,6 +128,7 @@ int Run::prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const voi
       g.sw[0] = (long)heads * hd * Lp; g.sw[1] = (long)hd * Lp;
       g.sy[0] = (long)L * H; g.sy[1] = hd;
       IVG_TRY(gemm(dt, g, 2.0 * B * heads * (double)L * Lp * hd, (double)esz(dt) * ((double)B * heads * L * Lp + 2.0 * M * H)));
+    }
     }
     ConvW wo; wo.w = w.wo; wo.cin = H; wo.cout = H;
     IVG_TRY(linear(dt, attn, M, wo, x, x, 0, 0));  // in-place residual
