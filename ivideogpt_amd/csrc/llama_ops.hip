@@ -11,20 +11,21 @@ namespace ivg {
 // ------------------------------------------------------------------------------------------------ embedding
 template <typename T>
 __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ ids, long id_stride, const T* __restrict__ E,
-                                                    T* __restrict__ x, int L, int H) {
+                                                    T* __restrict__ x, int L, int H, int V) {
   constexpr int VEC = Traits<T>::VEC;
   const int row = blockIdx.x;  // b * L + l
   const int b = row / L, l = row - b * L;
-  const long id = ids[(long)b * id_stride + l];
+  long id = ids[(long)b * id_stride + l];
+  id = id < 0 ? 0 : (id >= V ? V - 1 : id);  // memory safety only: the mirror's callers pass ids < vocab_size
   const T* src = E + id * H;
   T* dst = x + (long)row * H;
   for (int c = threadIdx.x * VEC; c < H; c += 256 * VEC) *(Chunk16*)(dst + c) = *(const Chunk16*)(src + c);
 }
 
-int launch_embed(const int64_t* ids, long id_stride, const void* E, void* x, DType dt, int B, int L, int H, hipStream_t st) {
+int launch_embed(const int64_t* ids, long id_stride, const void* E, void* x, DType dt, int B, int L, int H, int V, hipStream_t st) {
   if (B * L <= 0) return 0;
-  if (dt == BF16) hipLaunchKernelGGL(embed_kernel<bf16_t>, dim3(B * L), dim3(256), 0, st, ids, id_stride, (const bf16_t*)E, (bf16_t*)x, L, H);
-  else hipLaunchKernelGGL(embed_kernel<float>, dim3(B * L), dim3(256), 0, st, ids, id_stride, (const float*)E, (float*)x, L, H);
+  if (dt == BF16) hipLaunchKernelGGL(embed_kernel<bf16_t>, dim3(B * L), dim3(256), 0, st, ids, id_stride, (const bf16_t*)E, (bf16_t*)x, L, H, V);
+  else hipLaunchKernelGGL(embed_kernel<float>, dim3(B * L), dim3(256), 0, st, ids, id_stride, (const float*)E, (float*)x, L, H, V);
   return (int)hipGetLastError();
 }
 
@@ -71,10 +72,109 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(T* __restrict__ qkv, T* __
   }
 }
 
+// Vectorised form for head_dim 64 prompts (pos0 known on the host): a workgroup owns ROWS consecutive positions of one
+// (trajectory, head); 16-byte loads / stores throughout, and V^T leaves through an LDS transpose as whole 32-byte runs
+// along the position axis (the scalar kernel above writes V^T 2 bytes at a stride of ldvt).
+template <typename T>
+__global__ __launch_bounds__(256) void rope_kv64_kernel(T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
+                                                        T* __restrict__ vt, int ldvt, const float* __restrict__ cosT,
+                                                        const float* __restrict__ sinT, int L, int heads, int Lmax, int pos0) {
+  constexpr int VEC = Traits<T>::VEC, HD = 64, HALF = 32;
+  constexpr int CH = HALF / VEC;        // threads per position (each owns chunk c of both halves)
+  constexpr int ROWS = 256 / CH;        // positions per workgroup: 64 (bf16) / 32 (fp32)
+  constexpr int PITCH = HD * (int)sizeof(T) / 4 + 1;   // dwords per staged V row: odd -> transposed reads spread over banks
+  __shared__ unsigned sv[ROWS * PITCH];
+  const int tid = threadIdx.x;
+  const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
+  const int H = heads * HD;
+  const int l0 = blockIdx.x * ROWS;
+  {
+    const int lr_ = tid / CH, c = tid - lr_ * CH;
+    const int l = l0 + lr_;
+    unsigned* dst = sv + lr_ * PITCH;
+    constexpr int DW = 16 / 4;           // dwords per 16-byte chunk
+    if (l < L) {
+      const int pos = pos0 + l;
+      T* row = qkv + ((long)b * L + l) * 3 * H + h * HD;
+      float cs[VEC], sn[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; j += 4) {
+        const f32x4 cv = *(const f32x4*)(cosT + (long)pos * HALF + c * VEC + j), sv4 = *(const f32x4*)(sinT + (long)pos * HALF + c * VEC + j);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { cs[j + r] = cv[r]; sn[j + r] = sv4[r]; }
+      }
+      auto rope = [&](T* lo_p, T* hi_p, T* lo_dst, T* hi_dst) {
+        const Chunk16 lo = *(const Chunk16*)lo_p, hi = *(const Chunk16*)hi_p;
+        Chunk16 olo, ohi;
+        if constexpr (sizeof(T) == 2) {
+          const bf16x8 a = __builtin_bit_cast(bf16x8, lo), bb = __builtin_bit_cast(bf16x8, hi);
+          bf16x8 oa, ob;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float x1 = (float)a[j], x2 = (float)bb[j];
+            oa[j] = (bf16_t)(x1 * cs[j] - x2 * sn[j]);
+            ob[j] = (bf16_t)(x2 * cs[j] + x1 * sn[j]);
+          }
+          olo = __builtin_bit_cast(Chunk16, oa); ohi = __builtin_bit_cast(Chunk16, ob);
+        } else {
+          const f32x4 a = __builtin_bit_cast(f32x4, lo), bb = __builtin_bit_cast(f32x4, hi);
+          f32x4 oa, ob;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { oa[j] = a[j] * cs[j] - bb[j] * sn[j]; ob[j] = bb[j] * cs[j] + a[j] * sn[j]; }
+          olo = __builtin_bit_cast(Chunk16, oa); ohi = __builtin_bit_cast(Chunk16, ob);
+        }
+        *(Chunk16*)lo_dst = olo; *(Chunk16*)hi_dst = ohi;
+      };
+      T* q = row + c * VEC;
+      rope(q, q + HALF, q, q + HALF);
+      T* k = row + H + c * VEC;
+      T* kd = kc + ((long)bh * Lmax + pos) * HD + c * VEC;
+      rope(k, k + HALF, kd, kd + HALF);
+      const T* v = row + 2 * H + c * VEC;
+      const Chunk16 vlo = *(const Chunk16*)v, vhi = *(const Chunk16*)(v + HALF);
+      T* vd = vc + ((long)bh * Lmax + pos) * HD + c * VEC;
+      *(Chunk16*)vd = vlo; *(Chunk16*)(vd + HALF) = vhi;
+#pragma unroll
+      for (int r = 0; r < DW; ++r) { dst[c * DW + r] = vlo[r]; dst[HALF * (int)sizeof(T) / 4 + c * DW + r] = vhi[r]; }
+    } else {
+#pragma unroll
+      for (int r = 0; r < DW; ++r) { dst[c * DW + r] = 0u; dst[HALF * (int)sizeof(T) / 4 + c * DW + r] = 0u; }   // zero padding of V^T
+    }
+  }
+  __syncthreads();
+  if (vt) {   // thread (d, lc): ROWS / 4 consecutive positions of channel d
+    constexpr int PER = ROWS / 4;
+    const int d = tid >> 2, lc = tid & 3;
+    const T* svT = (const T*)sv;
+    T* out = vt + ((long)bh * HD + d) * ldvt + l0 + lc * PER;
+    T vals[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) vals[j] = svT[(long)(lc * PER + j) * (PITCH * 4 / (int)sizeof(T)) + d];
+#pragma unroll
+    for (int j = 0; j < PER; j += VEC) {
+      Chunk16 o;
+      if constexpr (sizeof(T) == 2) { bf16x8 t8; for (int r = 0; r < 8; ++r) t8[r] = vals[j + r]; o = __builtin_bit_cast(Chunk16, t8); }
+      else { f32x4 t4; for (int r = 0; r < 4; ++r) t4[r] = vals[j + r]; o = __builtin_bit_cast(Chunk16, t4); }
+      *(Chunk16*)(out + j) = o;
+    }
+  }
+}
+
 int launch_rope_kv(void* qkv, void* kc, void* vc, void* vt, int ldvt, const float* cosT, const float* sinT, int B, int L,
                    int heads, int hd, int Lmax, const StepState* state, int pos0, DType dt, hipStream_t st) {
   const long total = (long)B * L * heads * (hd / 2);
   if (total <= 0) return 0;
+  const int rows = dt == BF16 ? 64 : 32;
+  if (hd == 64 && !state && (!vt || (ldvt % rows == 0 && ldvt >= cdiv(L, rows) * rows)) && ((uintptr_t)qkv & 15) == 0) {
+    dim3 g2((unsigned)cdiv(L, rows), (unsigned)(B * heads));
+    if (dt == BF16)
+      hipLaunchKernelGGL(rope_kv64_kernel<bf16_t>, g2, dim3(256), 0, st, (bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc, (bf16_t*)vt, ldvt, cosT, sinT,
+                         L, heads, Lmax, pos0);
+    else
+      hipLaunchKernelGGL(rope_kv64_kernel<float>, g2, dim3(256), 0, st, (float*)qkv, (float*)kc, (float*)vc, (float*)vt, ldvt, cosT, sinT, L,
+                         heads, Lmax, pos0);
+    return (int)hipGetLastError();
+  }
   dim3 g(cdiv(total, 256));
   if (dt == BF16)
     hipLaunchKernelGGL(rope_kv_kernel<bf16_t>, g, dim3(256), 0, st, (bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc, (bf16_t*)vt, ldvt, cosT,

@@ -49,7 +49,7 @@ struct StepState {  // device-resident per-generate state (so one captured step 
   int j;            // 1-based index of the NEW token being decided at this step
 };
 // x[b][:] = E[tok[b]] (+ act[b][slot][:] when add_act), T
-int launch_embed(const int64_t* ids, long id_stride, const void* E, void* x, DType dt, int B, int L, int H, hipStream_t st);
+int launch_embed(const int64_t* ids, long id_stride, const void* E, void* x, DType dt, int B, int L, int H, int V, hipStream_t st);
 // RoPE on q,k of qkv[M][3H] (in place) and append k,v to the cache [B][heads][Lmax][hd]; position of row (b, l) = pos0 + l
 // (pos0 from *state when state != null).  vt (optional): transposed V scratch [B][heads][hd][ldvt] for the prefill P.V GEMM.
 int launch_rope_kv(void* qkv, void* kc, void* vc, void* vt, int ldvt, const float* cosT, const float* sinT, int B, int L,

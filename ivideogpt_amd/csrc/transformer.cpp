@@ -85,7 +85,7 @@ int Run::prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const voi
   float* S = flash ? nullptr : (float*)e->ws.alloc((size_t)B * heads * L * Lp * 4);
   char* Pm = flash ? nullptr : (char*)e->ws.alloc((size_t)B * heads * L * Lp * esz(dt));
   if (!planning) {
-    CK(launch_embed(ids, ids_stride, e->embed, x, dt, B, L, H, st));
+    CK(launch_embed(ids, ids_stride, e->embed, x, dt, B, L, H, V, st));
     if (act_emb) {  // action embedding on the sdf slot(s): slot i (position 257*ctx - 1 + 17*i) gets action i + ctx - 1
       for (int i = 0;; ++i) {
         const int pos = 257 * ctx - 1 + 17 * i;

@@ -1,0 +1,152 @@
+"""Edge cases of the prediction path on the MI355X (-m gpu): shortest / longest rollouts, ragged and single-row batches,
+input dtypes and layouts, context-length switching, error behaviour (the reference asserts; so does the mirror)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import llama_fixture, oracle_llama, oracle_tokenizer, tokenizer_fixture
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def make_tok(cfg, sd, ctx, enc="fp32", dec="fp32"):
+    from ivideogpt_amd import CompressiveVQModel
+    m = CompressiveVQModel(cfg, sd, encode_dtype=enc, decode_dtype=dec).to(DEV)
+    if ctx != cfg["context_length"]:
+        m.set_context_length(ctx)
+    return m
+
+
+def make_llm(cfg, sd, dtype="fp32"):
+    from ivideogpt_amd import LlamaForCausalLM
+    return LlamaForCausalLM(cfg, sd, dtype=dtype).to(DEV)
+
+
+@pytest.mark.parametrize("n_new", [1, 2, 3, 17, 18])
+def test_shortest_rollouts_match_oracle(n_new):
+    """1 new token = prefill + one decision (no cached step); 2 = one eager step; >= 3 enters the replayed step graph."""
+    from oracle.llama import generate_cached
+    cfg, sd, g = llama_fixture("llama_tiny_ctx1_free.npz")
+    m, ora = make_llm(cfg, sd), oracle_llama(cfg, sd)
+    prompt = torch.from_numpy(g["prompt"])
+    out = m.generate(prompt.to(DEV), do_sample=False, max_new_tokens=n_new).cpu()
+    assert torch.equal(out, generate_cached(ora, prompt, n_new, uniforms=None))
+    u = torch.rand(prompt.shape[0], n_new, generator=torch.Generator().manual_seed(n_new))
+    out = m.generate(prompt.to(DEV), do_sample=True, top_k=100, max_new_tokens=n_new, uniforms=u.to(DEV)).cpu()
+    assert torch.equal(out, generate_cached(ora, prompt, n_new, top_k=100, uniforms=u))
+
+
+def test_rollout_to_the_last_position_and_beyond():
+    """max_position_embeddings = 1024: a rollout may fill the KV cache to the last slot; one more token is an error, not a
+    silent overrun."""
+    from oracle.llama import generate_cached
+    cfg, sd, g = llama_fixture("llama_tiny_ctx1_free.npz")
+    m = make_llm(cfg, sd)
+    Lmax = cfg["max_position_embeddings"]
+    prompt = torch.from_numpy(g["prompt"])[:2]
+    L0 = prompt.shape[1]
+    out = m.generate(prompt.to(DEV), do_sample=False, max_new_tokens=Lmax - L0).cpu()
+    assert out.shape == (2, Lmax)
+    ref = generate_cached(oracle_llama(cfg, sd), prompt[:1], Lmax - L0, uniforms=None)
+    assert torch.equal(out[:1], ref)
+    with pytest.raises((AssertionError, RuntimeError)):
+        m.generate(prompt.to(DEV), do_sample=False, max_new_tokens=Lmax - L0 + 2)
+
+
+def test_long_teacher_forced_sequence_matches_oracle():
+    """logits over a full 1024-token sequence (every RoPE position, the longest causal attention)."""
+    cfg, sd, g = llama_fixture("llama_tiny_ctx1_free.npz")
+    ids = torch.randint(0, cfg["vocab_size"], (1, cfg["max_position_embeddings"]), generator=torch.Generator().manual_seed(5))
+    ref = oracle_llama(cfg, sd).logits(ids)
+    lg = make_llm(cfg, sd).logits(ids.to(DEV)).cpu()
+    err = (lg - ref).abs().max().item()
+    assert err < 1e-3, f"max abs err {err:.2e}"
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_single_and_odd_batches_match_reference_vectors(B):
+    cfg, sd, ctx, px, g = tokenizer_fixture("tok_mini64_ctx2.npz")
+    m = make_tok(cfg, sd, ctx)
+    rows = [0] if B == 1 else [1, 0, 1]
+    ids, labels = m.tokenize(px[rows].to(DEV), ctx)
+    assert np.array_equal(ids.cpu().numpy(), g["indices"][rows]) and np.array_equal(labels.cpu().numpy(), g["labels"][rows])
+    rec = m.detokenize(ids, ctx).cpu().numpy()
+    assert np.abs(rec - g["recon"][rows]).max() < 1e-3
+
+
+def test_pixel_dtypes_and_layouts():
+    """bf16 pixels are read as such (the benchmark keeps clips in bf16): same tokens as the rounded values in fp32;
+    uint8-derived, non-contiguous and CPU tensors are accepted like any torch module would."""
+    cfg, sd, ctx, px, g = tokenizer_fixture("tok_mini64_ctx2.npz")
+    m = make_tok(cfg, sd, ctx)
+    base, _ = m.tokenize(px.to(DEV), ctx)
+    p16 = px.to(torch.bfloat16)
+    a, _ = m.tokenize(p16.to(DEV), ctx)
+    b, _ = m.tokenize(p16.float().to(DEV), ctx)
+    assert torch.equal(a, b)
+    wide = torch.zeros(px.shape[0], px.shape[1], 3, 64, 128)
+    wide[..., ::2] = px
+    c, _ = m.tokenize(wide[..., ::2].to(DEV), ctx)        # strided view
+    d, _ = m.tokenize(px, ctx)                            # host tensor: moved by the mirror
+    e, _ = m.tokenize(px.double().to(DEV), ctx)           # other float types are converted to fp32
+    assert torch.equal(c, base) and torch.equal(d, base) and torch.equal(e, base)
+
+
+def test_context_length_switching_is_stateless():
+    """set_context_length (compressive_vq_model.py:154-158) re-slices the position embeddings; going 2 -> 1 -> 2 gives the
+    first answer again and the ctx = 1 answer equals the oracle switched the same way."""
+    cfg, sd, ctx, px, g = tokenizer_fixture("tok_mini64_ctx2.npz")
+    m = make_tok(cfg, sd, ctx)
+    first, _ = m.tokenize(px.to(DEV), 2)
+    m.set_context_length(1)
+    one, _ = m.tokenize(px.to(DEV), 1)
+    want, _ = oracle_tokenizer(cfg, sd, 1).tokenize(px, 1)
+    assert torch.equal(one.cpu(), want)
+    with pytest.raises(AssertionError):
+        m.tokenize(px.to(DEV), 2)                          # stale context_length (:166)
+    m.set_context_length(2)
+    again, _ = m.tokenize(px.to(DEV), 2)
+    assert torch.equal(first, again)
+
+
+def test_error_behaviour():
+    cfg, sd, ctx, px, g = tokenizer_fixture("tok_mini64_ctx2.npz")
+    m = make_tok(cfg, sd, ctx)
+    with pytest.raises(AssertionError):
+        m.tokenize(px[:, :ctx].to(DEV), ctx)               # no future frame: the reference cannot reshape an empty batch either
+    with pytest.raises(AssertionError):
+        m.tokenize(px[:, :, :, :32].to(DEV), ctx)          # wrong resolution
+    with pytest.raises(AssertionError):
+        m.tokenize(px[:, :, :2].to(DEV), ctx)              # not RGB
+    ids, _ = m.tokenize(px.to(DEV), ctx)
+    with pytest.raises(AssertionError):
+        m.detokenize(ids[:, :-1], ctx)                     # (L + 1 - 257 ctx) % 17 != 0 (:230)
+    rec, cache = m.detokenize(ids, ctx, return_cache=True)
+    with pytest.raises(AssertionError):
+        m.detokenize(ids[:1], ctx, cache=cache)            # cache of another batch size
+    assert torch.equal(m.encode_context(px[:, :ctx].to(DEV), ctx), ids[:, :257 * ctx])   # context only needs the context frames
+    # the engine stays usable after every rejected call
+    assert torch.equal(m.detokenize(ids, ctx), rec)
+    cfg2, sd2, g2 = llama_fixture("llama_tiny_ctx1_free.npz")
+    llm = make_llm(cfg2, sd2)
+    bad = torch.full((1, 257), cfg2["vocab_size"] + 7, dtype=torch.int64)
+    out = llm.generate(bad.to(DEV), do_sample=False, max_new_tokens=4)   # ids outside the vocabulary: no out-of-bounds gather
+    torch.cuda.synchronize()
+    assert (out[:, 257:] >= 0).all() and (out[:, 257:] < cfg2["vocab_size"]).all()
+    with pytest.raises((AssertionError, RuntimeError)):
+        llm.generate(torch.zeros(1, 1020, dtype=torch.int64).to(DEV), do_sample=False, max_new_tokens=10)   # past the KV cache
+
+
+def test_out_of_range_dynamics_tokens_are_clamped_like_the_reference():
+    """a rollout may emit any id < vocab in a dynamics slot; detokenize maps it with (id - n_vq).clamp(0, n_dyn - 1)
+    (compressive_vq_model.py:236-237)."""
+    cfg, sd, ctx, px, g = tokenizer_fixture("tok_mini64_ctx2.npz")
+    m, ora = make_tok(cfg, sd, ctx), oracle_tokenizer(cfg, sd, ctx)
+    ids = torch.from_numpy(g["indices"]).clone()
+    start = 257 * ctx
+    ids[:, start + 0] = 3                                            # a context code in a dynamics slot -> clamps to 0
+    ids[:, start + 5] = cfg["num_vq_embeddings"] + cfg["num_dyn_embeddings"] + 1   # separator id -> clamps to n_dyn - 1
+    want = ora.detokenize(ids, ctx)
+    got = m.detokenize(ids.to(DEV), ctx).cpu()
+    assert (got - want).abs().max().item() < 1e-3
