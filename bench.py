@@ -234,6 +234,7 @@ def main():
             e.profile_enable(k, False)
         kstats[name] = {key: sum(x[key] for x in st) / max(1, a.steps) for key in ("launches", "total_ms", "total_flops", "total_bytes")}
     kstats["decode_attn"] = llm_engine.profile_read(_lib.IVG_K_DECODE_ATTN)
+    attn_fit = llm_engine.profile_attn_fit()
     llm_engine.profile_enable(_lib.IVG_K_DECODE_ATTN, False)
 
     # one extra, untimed pass for the per-stage split (events on the engine streams' parent stream)
@@ -252,6 +253,9 @@ def main():
     if rank == 0:
         units = world * B * F * a.steps
         rl = rooflines(kstats, a)
+        for r in rl:
+            if r.get("bound") == "hbm" and attn_fit[1] > 0:   # launch duration = fixed + bytes / rate over the 237 cache lengths
+                r["fit"] = {"fixed_us_per_launch": attn_fit[0], "streaming_GBps": attn_fit[1]}
         out = {
             "metric": "predicted frames/sec (encode+GPT rollout+decode), 64x64x16f" if a.res == 64 else
                       "predicted frames/sec (encode+GPT rollout+decode), 256x256x16f",

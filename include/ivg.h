@@ -142,6 +142,9 @@ typedef struct {
 } ivg_profile_stats;
 int ivg_profile_enable(ivg_engine* e, int kernel_class, int enable);
 int ivg_profile_read(ivg_engine* e, int kernel_class, ivg_profile_stats* out);   /* synchronises, then resets */
+/* after ivg_profile_read(IVG_K_DECODE_ATTN): least-squares line  launch duration = fixed_us + bytes / gbps  over the launches
+ * of the last ivg_generate (their cache lengths differ) -- separates the per-launch overhead from the streaming rate */
+int ivg_profile_attn_fit(ivg_engine* e, double* fixed_us, double* gbps);
 
 /* ---- op-level entry points (unit parity tests call the kernels through these) */
 typedef struct {

@@ -67,6 +67,7 @@ EXPORTS = {
     "ivg_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ivg_profile_enable": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ivg_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(IvgProfileStats)]),
+    "ivg_profile_attn_fit": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ivg_op_igemm": (C.c_int, [C.POINTER(IvgIgemmArgs), C.c_int, C.c_void_p]),
     "ivg_op_skinny": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 9 + [C.c_void_p]),
     "ivg_op_groupnorm": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_float, C.c_int, C.c_int, C.c_void_p]),

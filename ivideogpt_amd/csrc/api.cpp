@@ -431,6 +431,12 @@ int ivg_logits(ivg_engine* e, const int64_t* ids, int B, int L, const float* act
   });
 }
 
+int ivg_profile_attn_fit(ivg_engine* e, double* fixed_us, double* gbps) {
+  if (!e || !fixed_us || !gbps) return IVG_ERR_INVALID;
+  *fixed_us = e->attn_fit_fixed_us; *gbps = e->attn_fit_gbps;
+  return IVG_OK;
+}
+
 int ivg_profile_enable(ivg_engine* e, int k, int enable) {
   if (!e || k < 0 || k >= IVG_K_COUNT) return IVG_ERR_INVALID;
   if (k == IVG_K_DECODE_ATTN) { e->attn_prof_on = enable != 0 && e->attn_prof; return IVG_OK; }
@@ -449,6 +455,8 @@ int ivg_profile_read(ivg_engine* e, int k, ivg_profile_stats* out) {
     const int L = e->Lmax, nl = e->cfg.num_layers, NS = IVG_ATTN_PROF_SLOTS;
     std::vector<unsigned long long> h((size_t)nl * NS * 2 * L);
     API_CK(hipMemcpy(h.data(), e->attn_prof, h.size() * 8, hipMemcpyDeviceToHost));
+    // least-squares line  duration = fixed + bytes / rate  over the launches (they differ in cache length)
+    double sn = 0, sx = 0, sy = 0, sxx = 0, sxy = 0;
     for (int l = 0; l < nl; ++l)
       for (int p = 0; p < L; ++p) {
         unsigned long long s = ~0ull, t = 0;
@@ -458,11 +466,21 @@ int ivg_profile_read(ivg_engine* e, int k, ivg_profile_stats* out) {
           t = std::max(t, ct);
         }
         if (t == 0 || s == ~0ull || t < s) continue;
+        const double ms = (double)(t - s) * 1e-5;   // 100 MHz wall clock -> ms
+        const double bytes = 2.0 * e->attn_prof_B * e->heads * (double)(p + 1) * e->hd * dtype_size(e->llm_dt);
         out->launches++;
-        out->total_ms += (double)(t - s) * 1e-5;   // 100 MHz wall clock -> ms
-        out->total_bytes += 2.0 * e->attn_prof_B * e->heads * (double)(p + 1) * e->hd * dtype_size(e->llm_dt);
+        out->total_ms += ms;
+        out->total_bytes += bytes;
         out->total_flops += 4.0 * e->attn_prof_B * e->heads * (double)(p + 1) * e->hd;
+        sn += 1; sx += bytes; sy += ms; sxx += bytes * bytes; sxy += bytes * ms;
       }
+    const double den = sn * sxx - sx * sx;
+    e->attn_fit_fixed_us = 0; e->attn_fit_gbps = 0;
+    if (sn > 2 && den > 0) {
+      const double slope = (sn * sxy - sx * sy) / den;            // ms per byte
+      e->attn_fit_fixed_us = (sy - slope * sx) / sn * 1e3;
+      e->attn_fit_gbps = slope > 0 ? 1e-6 / slope : 0;             // bytes/ms -> GB/s
+    }
     return IVG_OK;
   }
   ProfClass& pc = e->prof[k];

@@ -95,6 +95,7 @@ struct ivg_engine {
   unsigned long long* attn_prof = nullptr;  // [layers][IVG_ATTN_PROF_SLOTS][2][Lmax] wall-clock stamps of the decode attention
   bool attn_prof_on = false;                // ivg_profile_enable(IVG_K_DECODE_ATTN): part of the step-graph key
   int attn_prof_B = 0;
+  double attn_fit_fixed_us = 0, attn_fit_gbps = 0;   // line fit of the last ivg_profile_read(IVG_K_DECODE_ATTN)
 
   int fail(int code, const std::string& msg) { err = msg; return code; }
 };

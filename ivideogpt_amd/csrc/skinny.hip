@@ -22,6 +22,7 @@ struct SkinnyDev {
   int M, N, K, ldx, ldw, ldy, splits, flags;
   float eps;       // SK_NORM: y = rsqrt(mean_k x^2 + eps) * (x . W)   (RMSNorm weight pre-folded into W)
   int* bump;       // optional: two ints incremented by one thread at the end (device-side step state)
+  int tail_split;  // the ragged last column tile is computed by one extra workgroup PER ROW TILE (see launch_sk)
 };
 
 template <typename T, int MF, int FN, int WAVES>
@@ -33,7 +34,13 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(const SkinnyDev p) {
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int lr = lane & 15, lg = lane >> 4;
-  const int n_tile = blockIdx.x * (16 * FN);
+  // tail_split: N = q * (16 FN) + r.  Workgroups [0, q) own the full column tiles; the r ragged columns go to MF extra
+  // workgroups, one per 16-row tile, instead of one workgroup that would pull all of X for a sliver of W (lm_head:
+  // 16386 = 256 * 64 + 2 -> the 257th workgroup doubled the kernel's time on 256 CUs)
+  const int main_tiles = p.tail_split ? p.N / (16 * FN) : (int)gridDim.x;
+  const bool tail = (int)blockIdx.x >= main_tiles;
+  const int tail_row = tail ? (int)blockIdx.x - main_tiles : -1;
+  const int n_tile = (tail ? main_tiles : (int)blockIdx.x) * (16 * FN);
   const int m_tile = blockIdx.y * (16 * MF);
   const int s = blockIdx.z;
   const int ks = p.K / p.splits, kw = ks / WAVES;
@@ -64,7 +71,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(const SkinnyDev p) {
 #pragma unroll
   for (int b = 0; b < MF; ++b) {
     const int m = m_tile + b * 16 + lr;
-    xok[b] = m < p.M;
+    xok[b] = m < p.M && (!tail || b == tail_row);
     xoff[b] = (long)(xok[b] ? m : 0) * p.ldx + lg * VEC;
   }
 
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(const SkinnyDev p) {
     for (int w = 1; w < WAVES; ++w) v += red[((w * FN + a) * MF + b) * 64 + lane];
     const int m = m_tile + b * 16 + lr;
     int n0 = n_tile + a * 16 + lg * 4;
-    if (m >= p.M || n0 >= p.N) continue;
+    if (m >= p.M || n0 >= p.N || (tail && b != tail_row)) continue;
     int nlim = p.N;
     float rs = 1.0f;
     if (do_norm) {
@@ -193,8 +200,11 @@ static int launch_sk(const SkinnyDev& d, hipStream_t stream) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  dim3 grid((unsigned)cdiv(d.N, 16 * FN), (unsigned)cdiv(d.M, 16 * MF), (unsigned)d.splits);
-  hipLaunchKernelGGL(kfn, grid, dim3(WAVES * 64), smem, stream, d);
+  SkinnyDev dd = d;
+  dd.tail_split = (MF > 1 && d.M <= 16 * MF && d.splits == 1 && d.N % (16 * FN) != 0 && d.N > 16 * FN && !(d.flags & IG_GLU)) ? 1 : 0;
+  const unsigned gx = dd.tail_split ? (unsigned)(d.N / (16 * FN) + cdiv(d.M, 16)) : (unsigned)cdiv(d.N, 16 * FN);
+  dim3 grid(gx, (unsigned)cdiv(d.M, 16 * MF), (unsigned)d.splits);
+  hipLaunchKernelGGL(kfn, grid, dim3(WAVES * 64), smem, stream, dd);
   return (int)hipGetLastError();
 }
 
@@ -257,7 +267,7 @@ int skinny_pick_splits(int N, int K, DType dtype) {
 }
 
 int launch_skinny(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
-  SkinnyDev d{a.X, a.W, a.Y, a.M, a.N, a.K, a.ldx, a.ldw, a.ldy, a.splits < 1 ? 1 : a.splits, a.flags, a.eps, a.bump};
+  SkinnyDev d{a.X, a.W, a.Y, a.M, a.N, a.K, a.ldx, a.ldw, a.ldy, a.splits < 1 ? 1 : a.splits, a.flags, a.eps, a.bump, 0};
   const int kstep = (dtype == BF16) ? 32 : 16, vec = (dtype == BF16) ? 8 : 4;
   if (a.M <= 0 || a.N <= 0) return 0;
   if (a.M > 128 || a.K % (d.splits * 4 * kstep) != 0 || a.ldx % vec != 0 || a.ldw % vec != 0)

@@ -153,6 +153,12 @@ class Engine:
     def profile_enable(self, kclass, on=True):
         self.check(self.lib.ivg_profile_enable(self.h, kclass, int(on)), "profile_enable")
 
+    def profile_attn_fit(self):
+        """(fixed microseconds per launch, streaming GB/s) of the decode attention, after profile_read(IVG_K_DECODE_ATTN)."""
+        f, r = C.c_double(0), C.c_double(0)
+        self.check(self.lib.ivg_profile_attn_fit(self.h, C.byref(f), C.byref(r)), "profile_attn_fit")
+        return f.value, r.value
+
     def profile_read(self, kclass):
         st = _lib.IvgProfileStats()
         self.check(self.lib.ivg_profile_read(self.h, kclass, C.byref(st)), "profile_read")

@@ -358,3 +358,20 @@ def test_sampler_matches_oracle(case):
     assert torch.equal(out.cpu(), want), (out.cpu() != want).nonzero().flatten().tolist()
     assert l.ivg_op_sample(P(lg), B, V, k, None, P(out), stream()) == 0
     assert torch.equal(out.cpu(), sample_from_logits(logits, k, None))
+
+
+@pytest.mark.parametrize("M", [64, 50, 16])
+def test_skinny_gemm_lm_head_shape_with_ragged_vocab(M):
+    """lm_head of the released models: 16386 = 256 * 64 + 2 columns -- the two ragged columns are computed by one extra
+    workgroup per 16-row tile (tail split); every logit must still be written exactly once."""
+    L, l = lib()
+    g = torch.Generator().manual_seed(M)
+    N, K = 16386, 768
+    x, w = q(torch.randn(M, K, generator=g), "bf16"), q(torch.randn(N, K, generator=g) / K ** 0.5, "bf16")
+    ref = x.double() @ w.double().T
+    xd, wd = x.to(DEV, torch.bfloat16), w.to(DEV, torch.bfloat16)
+    Yf = torch.full((M, N), float("nan"), device=DEV)
+    assert l.ivg_op_skinny(P(xd), P(wd), P(Yf), M, N, K, K, K, N, 1, 32, code("bf16"), stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(Yf).all() and rel_err(Yf, ref) < 2e-5
+    assert rel_err(Yf[:, -2:], ref[:, -2:]) < 2e-5
