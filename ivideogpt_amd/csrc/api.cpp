@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <cstdio>
 #include "engine_impl.h"
 
 using namespace ivg;
@@ -550,8 +551,18 @@ int ivg_op_sample(const float* logits, int B, int V, int top_k, const float* uni
   sa.logits = logits; sa.V = V; sa.uniforms = uniforms; sa.n_uni = 1; sa.top_k = top_k;
   sa.ids_out = out; sa.ids_stride = 1; sa.L0 = 0; sa.forced_period = 0; sa.forced_token = 0;
   sa.E = logits; sa.x = out; sa.H = 0; sa.act = nullptr; sa.act_T = 0; sa.ctx = 1; sa.slot0 = 0; sa.state = state;
+  long long* dbg = nullptr;
+  if (getenv("IVG_SAMPLE_DEBUG")) { (void)hipMalloc((void**)&dbg, 32 * 8); (void)hipMemset(dbg, 0, 32 * 8); }
+  sa.dbg = dbg;
   if (!rc) rc = launch_sample_embed(sa, B, F32, st);
   (void)hipStreamSynchronize(st);
+  if (dbg) {
+    long long h[32]; (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[sample dbg] %d stamps, cycles between:", (int)h[31]);
+    for (int i = 1; i < (int)h[31] && i < 31; ++i) fprintf(stderr, " %lld", h[i] - h[i - 1]);
+    fprintf(stderr, "\n");
+    (void)hipFree(dbg);
+  }
   (void)hipFree(state);
   return rc ? IVG_ERR_HIP : IVG_OK;
 }

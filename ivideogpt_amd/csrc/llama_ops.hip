@@ -500,40 +500,62 @@ __device__ __forceinline__ int block_suffix_excl(int x, int* s4, int lane, int w
 template <typename T, int KPT>  // KPT logits per thread (contiguous segment): vocab <= 256 * KPT
 __global__ __launch_bounds__(256) void sample_embed_kernel(SampleArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* lg = (float*)smem;  // [V] staging: coalesced global read, then each thread takes a contiguous segment;
-                             // afterwards the values of the kept tokens (fast path)
+  float* lg = (float*)smem;  // [V] staging: coalesced global read, then each thread takes a contiguous segment
   __shared__ float s_f[4];
   __shared__ int s_i[4];
   __shared__ int s4[4];
   __shared__ int s_sel[2];
-  __shared__ int hist[2048];
+  __shared__ __attribute__((aligned(16))) int hist[2048];
   __shared__ int kid[SAMPLE_CAP];
+  __shared__ float cval[SAMPLE_CAP];
   __shared__ double s_w[4];
   __shared__ long s_tok;
   __shared__ double s_target;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int j = a.state->j;
   const int V = a.V;
+  int dbg_n = 0;
+  auto stamp = [&]() { if (a.dbg && b == 0 && tid == 0) a.dbg[dbg_n++] = (long long)__builtin_readcyclecounter(); };
+  stamp();
   const bool forced = a.forced_period > 0 && (j % a.forced_period) == 0;
   long tok = 0;
   if (forced) {
     tok = a.forced_token;
   } else {
     const float* src = a.logits + (long)b * V;
-    for (int i = tid; i < V; i += 256) lg[i] = src[i];
+    if ((V & 1) == 0 && (((uintptr_t)src) & 7) == 0) {
+      // 8-byte loads, 16 in flight per lane (one workgroup per trajectory: only B CUs pull the logits, so the row must
+      // arrive in as few round trips as possible; a scalar loop here was most of the kernel's time)
+      const float2* src2 = (const float2*)src;
+      float2* lg2 = (float2*)lg;
+      const int n2 = V >> 1;
+      for (int i0b = 0; i0b < n2; i0b += 256 * 16) {
+        float2 tmp[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const int i = i0b + r * 256 + tid; tmp[r] = i < n2 ? src2[i] : float2{0.f, 0.f}; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const int i = i0b + r * 256 + tid; if (i < n2) lg2[i] = tmp[r]; }
+      }
+    } else {
+      for (int i = tid; i < V; i += 256) lg[i] = src[i];
+    }
     if (tid == 0) s_tok = -1;
     __syncthreads();
+    stamp();
     const int seg = (V + 255) / 256;
     const int i0 = tid * seg;
+    const int nvalid = max(0, min(seg, V - i0));   // this thread owns ids [i0, i0 + nvalid)
     float v[KPT];
     float mx = -INFINITY;
     int mi = 0x7fffffff;
 #pragma unroll
+    for (int q = 0; q < KPT; ++q) v[q] = lg[min(i0 + q, V - 1)];   // unconditional: all reads are issued back to back
+#pragma unroll
     for (int q = 0; q < KPT; ++q) {
-      const int i = i0 + q;
-      v[q] = (q < seg && i < V) ? lg[i] : -INFINITY;
-      if (v[q] > mx) { mx = v[q]; mi = i; }  // ascending index: the first maximum is kept
+      if (q >= nvalid) v[q] = -INFINITY;
+      if (v[q] > mx) { mx = v[q]; mi = i0 + q; }  // ascending index: the first maximum is kept
     }
+    const float tmax = mx;   // this thread's own maximum (pivot pre-filter of the sampler below)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {  // (max, lowest index) reduction
       const float ov = __shfl_xor(mx, o, 64);
@@ -545,15 +567,97 @@ __global__ __launch_bounds__(256) void sample_embed_kernel(SampleArgs a) {
     mx = s_f[0]; mi = s_i[0];
 #pragma unroll
     for (int w = 1; w < 4; ++w) if (s_f[w] > mx || (s_f[w] == mx && s_i[w] < mi)) { mx = s_f[w]; mi = s_i[w]; }
+    stamp();
     if (a.uniforms == nullptr) {
       tok = mi;
     } else {
-      // ---- key of the k-th largest logit (= largest T with #{key >= T} >= k): radix select, digits of 11 / 11 / 10 bits,
-      //      one LDS histogram per digit over the keys that match the digits found so far (integer counts: exact)
-      unsigned key[KPT];
+      // ---- key of the k-th largest logit (= largest T with #{key >= T} >= k).  General method: radix select, digits of
+      //      11 / 11 / 10 bits, one LDS histogram per digit over the keys that match the digits found so far (exact counts)
+      unsigned key[KPT];   // filled by the radix path only
+      int kk = a.top_k < V ? a.top_k : V;
+      unsigned thr = 0u;
+      bool have_thr = false;
+      int n_list = -1;                              // >= 0: (key, id, value) lists in LDS, ascending id order
+      unsigned* s_ck = (unsigned*)hist + 256;       // [SAMPLE_CAP] keys of the listed tokens (hist is free when they are written)
+      if (kk <= 256) {
+        // Pre-filter (k <= 256): in every wave take the ceil(k/4)-th largest of its 64 per-thread maxima; the smallest of the
+        // four is a lower bound of the k-th largest logit (at least k distinct elements are >= it), so only the tokens >=
+        // that pivot -- a few more than k of them -- can hold the threshold.  They are listed once (key, id, value;
+        // ascending id) and ranked against each other by counting: no histogram atomics and no second sweep over the
+        // vocabulary on the hot path.
+        const unsigned mine = f2key(tmax);
+        int rank = 0;
+#pragma unroll
+        for (int jl = 0; jl < 64; ++jl) {
+          const unsigned o = (unsigned)__builtin_amdgcn_readlane((int)mine, jl);
+          rank += (o > mine || (o == mine && jl < lane)) ? 1 : 0;
+        }
+        stamp();
+        if (rank == (kk + 3) / 4 - 1) s4[wv] = (int)mine;   // ranks are a permutation of 0..63: one writer per wave
+        __syncthreads();
+        stamp();
+        unsigned pivot = (unsigned)s4[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) pivot = (unsigned)s4[w] < pivot ? (unsigned)s4[w] : pivot;
+        const float pivf = __uint_as_float((pivot & 0x80000000u) ? (pivot & 0x7fffffffu) : ~pivot);   // inverse of f2key
+        unsigned cm[(KPT + 31) / 32];
+#pragma unroll
+        for (int w = 0; w < (KPT + 31) / 32; ++w) cm[w] = 0u;
+#pragma unroll
+        for (int q = 0; q < KPT; ++q) cm[q >> 5] |= (q < nvalid && v[q] >= pivf) ? (1u << (q & 31)) : 0u;
+        int cc = 0;
+#pragma unroll
+        for (int w = 0; w < (KPT + 31) / 32; ++w) cc += __builtin_popcount(cm[w]);
+        __syncthreads();                             // every thread has read s4
+        const int hi = block_suffix_excl(cc, s4, lane, wv);
+        if (tid == 0) s_sel[1] = hi + cc;           // number of candidates (>= k)
+        __syncthreads();
+        const int n_c = s_sel[1];
+        stamp();
+        if (n_c <= SAMPLE_CAP) {
+          int off = n_c - hi - cc;                   // candidates in lower threads = lower ids
+#pragma unroll
+          for (int w = 0; w < (KPT + 31) / 32; ++w) {
+            unsigned mm = cm[w];
+            while (mm) {                             // a thread holds 0-3 candidates: read them back from the staged row
+              const int id = i0 + w * 32 + __builtin_ctz(mm);
+              mm &= mm - 1;
+              const float val = lg[id];
+              s_ck[off] = f2key(val); kid[off] = id; cval[off] = val; ++off;
+            }
+          }
+          if (tid < 4) s_ck[n_c + tid] = 0u;           // pad to a multiple of 4 (hist has room beyond CAP)
+          __syncthreads();
+          stamp();
+          unsigned best = 0xffffffffu;               // smallest candidate with fewer than k strictly larger ones = k-th largest
+          const uint4* c4 = (const uint4*)s_ck;
+          const int n4 = (n_c + 3) >> 2;
+          for (int i = tid; i < n_c; i += 256) {
+            const unsigned ci = s_ck[i];
+            int g = 0;
+#pragma unroll 8
+            for (int j4 = 0; j4 < n4; ++j4) {
+              const uint4 o = c4[j4];
+              g += (o.x > ci ? 1 : 0) + (o.y > ci ? 1 : 0) + (o.z > ci ? 1 : 0) + (o.w > ci ? 1 : 0);
+            }
+            if (g < kk && ci < best) best = ci;
+          }
+          stamp();
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) { const unsigned ob = __shfl_xor(best, o, 64); best = ob < best ? ob : best; }
+          if (lane == 0) s4[wv] = (int)best;
+          __syncthreads();
+          thr = (unsigned)s4[0];
+#pragma unroll
+          for (int w = 1; w < 4; ++w) thr = (unsigned)s4[w] < thr ? (unsigned)s4[w] : thr;
+          have_thr = true;
+          n_list = n_c;
+          __syncthreads();                           // s4 is reused below
+        }
+      }
+      if (!have_thr) {   // k > 256 or a flood of candidates (massive ties): radix select over all keys
 #pragma unroll
       for (int q = 0; q < KPT; ++q) key[q] = f2key(v[q]);
-      int kk = a.top_k < V ? a.top_k : V;
       unsigned prefix = 0u, pmask = 0u;
 #pragma unroll
       for (int pass = 0; pass < 3; ++pass) {
@@ -578,32 +682,46 @@ __global__ __launch_bounds__(256) void sample_embed_kernel(SampleArgs a) {
         pmask |= (unsigned)(nb - 1) << shift;
         kk = s_sel[1];
       }
-      const unsigned thr = prefix;  // everything >= thr is kept (ties at the threshold included, as HF's masked_fill)
+      thr = prefix;
+      }
+      stamp();
+      // everything >= thr is kept (ties at the threshold included, as HF's masked_fill)
       // ---- inverse CDF in ascending id order, fp64 (oracle: double cumsum of exp(logit - max) over the kept ids)
-      int cnt = 0;
+      if (n_list < 0) {   // radix path: list the kept tokens now
+        int cnt = 0;
 #pragma unroll
-      for (int q = 0; q < KPT; ++q) cnt += (key[q] >= thr && v[q] > -INFINITY) ? 1 : 0;
-      const int after = block_suffix_excl(cnt, s4, lane, wv);
-      if (tid == 0) s_sel[0] = after + cnt;  // number of kept tokens
-      __syncthreads();
-      const int n_kept = s_sel[0];
-      if (n_kept <= SAMPLE_CAP) {
-        // fast path: the kept tokens (about top_k of them) are compacted in ascending id order and spread over the threads,
-        // so the fp64 exponentials run once each, in parallel
-        int off = n_kept - after - cnt;  // kept tokens in lower threads = lower ids
-#pragma unroll
-        for (int q = 0; q < KPT; ++q)
-          if (key[q] >= thr && v[q] > -INFINITY) { lg[off] = v[q]; kid[off] = i0 + q; ++off; }
+        for (int q = 0; q < KPT; ++q) cnt += (key[q] >= thr && v[q] > -INFINITY) ? 1 : 0;
+        const int after = block_suffix_excl(cnt, s4, lane, wv);
+        if (tid == 0) s_sel[0] = after + cnt;  // number of kept tokens
         __syncthreads();
-        const int per = (n_kept + 255) / 256;  // <= 4
-        const int e0 = tid * per, e1 = min(n_kept, e0 + per);
+        const int n_kept = s_sel[0];
+        if (n_kept <= SAMPLE_CAP) {
+          int off = n_kept - after - cnt;  // kept tokens in lower threads = lower ids
+#pragma unroll
+          for (int q = 0; q < KPT; ++q)
+            if (key[q] >= thr && v[q] > -INFINITY) { s_ck[off] = key[q]; cval[off] = v[q]; kid[off] = i0 + q; ++off; }
+          __syncthreads();
+          n_list = n_kept;
+        }
+      }
+      stamp();
+      if (n_list >= 0) {
+        // the listed tokens (about top_k of them) are spread over the threads, so the fp64 exponentials run once each, in
+        // parallel; listed tokens below the threshold (pre-filter path) weigh zero, exactly as in the oracle's masked sum
+        stamp();
+        const int per = (n_list + 255) / 256;  // <= 4
+        const int e0 = tid * per, e1 = min(n_list, e0 + per);
         double ex[SAMPLE_CAP / 256];
         double part = 0.0;
 #pragma unroll
         for (int r = 0; r < SAMPLE_CAP / 256; ++r) {
-          ex[r] = (e0 + r < e1) ? exp((double)(lg[e0 + r] - mx)) : 0.0;
-          part += ex[r];
+          ex[r] = 0.0;
+          if (r < per) {   // uniform across the workgroup
+            if (e0 + r < e1 && s_ck[e0 + r] >= thr && cval[e0 + r] > -INFINITY) ex[r] = exp((double)(cval[e0 + r] - mx));
+            part += ex[r];
+          }
         }
+        stamp();
         double incl = part;  // inclusive scan over threads (thread order == id order)
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -620,17 +738,18 @@ __global__ __launch_bounds__(256) void sample_embed_kernel(SampleArgs a) {
         if (lane == 0) excl = base;
         const double target = (double)a.uniforms[(long)b * a.n_uni + (j - 1)] * total;
         // intervals [excl, incl) tile [0, total) exactly (incl of thread t IS excl of thread t+1)
-        if (e0 < e1 && excl <= target && target < incl) {
+        if (part > 0.0 && excl <= target && target < incl) {
           double run = excl;
-          int found = -1;
+          int found = -1, last = -1;
 #pragma unroll
           for (int r = 0; r < SAMPLE_CAP / 256; ++r)
-            if (e0 + r < e1) { run += ex[r]; if (found < 0 && run > target) found = kid[e0 + r]; }
-          s_tok = found >= 0 ? found : kid[e1 - 1];  // rounding at the chunk edge: the chunk's last kept token
+            if (r < per && ex[r] > 0.0) { run += ex[r]; last = kid[e0 + r]; if (found < 0 && run > target) found = last; }
+          s_tok = found >= 0 ? found : last;  // rounding at the chunk edge: the chunk's last kept token
         }
         __syncthreads();
         tok = s_tok;
         if (tok < 0) tok = mi;  // unreachable for u in [0, 1): defensive
+        stamp();
       } else {
         // general path (massive ties at the threshold): every thread walks its own id segment
         double part = 0.0;
@@ -673,6 +792,7 @@ __global__ __launch_bounds__(256) void sample_embed_kernel(SampleArgs a) {
       }
     }
   }
+  if (a.dbg && b == 0 && tid == 0) a.dbg[31] = dbg_n;
   if (tid == 0) a.ids_out[(long)b * a.ids_stride + a.L0 + (j - 1)] = (int64_t)tok;
   // ---- next input embedding
   const T* src = (const T*)a.E + tok * a.H;

@@ -75,6 +75,7 @@ struct SampleArgs {
   const void* act; int act_T; int ctx;         // act[B][act_T][H] (T) or null: added on forced slots, index slot0 + j/period + ctx - 1
   int slot0;                                   // sdf slots already inside the prompt beyond the first: (L0 - 257*ctx) / 17
   StepState* state;
+  long long* dbg;                              // development: cycle stamps of workgroup 0 (null in production)
 };
 int launch_sample_embed(const SampleArgs& a, int B, DType dt, hipStream_t st);
 int launch_step_advance(StepState* state, hipStream_t st);

@@ -267,7 +267,7 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
     nc = (Bc + cs - 1) / cs;
     if (st == nullptr) { nc = 1; cs = Bc; }  // side streams cannot fork from the legacy default stream under capture
     for (int c = 0; c < nc; ++c) CK(launch_state_set(chain_state(g, c), L0, 1, st));
-    SampleArgs sa;
+    SampleArgs sa{};
     sa.logits = g.logits; sa.V = V;
     sa.uniforms = uniforms ? g.uni : nullptr; sa.n_uni = g.ids_ld;
     sa.top_k = top_k;
