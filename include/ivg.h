@@ -125,6 +125,14 @@ void ivg_cache_destroy(ivg_engine* e, ivg_cache* c);
 int ivg_generate(ivg_engine* e, const int64_t* prompt, int64_t prompt_stride, int B, int L0, int n_new, const float* actions,
                  int act_T, int ctx, const float* uniforms, int top_k, int64_t* ids_out, float* reward_out, ivg_stream stream);
 
+/* Step-wise rollout (mbrl/video_predictor.py:286-317 calls generate once per environment step on a prompt that grew by the 17
+ * tokens of the previous step): same contract as ivg_generate with actions != NULL, but the engine's KV cache is taken to
+ * hold positions [0, L0 - 1) of these B trajectories from the previous ivg_generate / ivg_generate_continue call, so only
+ * the prompt's last token (the sdf slot that receives the new action) is fed before the 16 + 1 new tokens -- no prefill.
+ * Returns IVG_ERR_INVALID when the cache does not hold exactly that (other batch, other length, cache never filled). */
+int ivg_generate_continue(ivg_engine* e, const int64_t* prompt, int64_t prompt_stride, int B, int L0, int n_new, const float* actions,
+                          int act_T, int ctx, const float* uniforms, int top_k, int64_t* ids_out, float* reward_out, ivg_stream stream);
+
 /* Teacher-forced logits (LlamaForCausalLM.forward / HeadModelWithAction.forward, action_model.py:154-185):
  * ids int64 (B, L); actions as above or NULL (added on every sdf slot 257*ctx - 1 + 17*i < L); logits_out float32 (B, L, vocab). */
 int ivg_logits(ivg_engine* e, const int64_t* ids, int B, int L, const float* actions, int act_T, int ctx, float* logits_out,

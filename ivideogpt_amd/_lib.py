@@ -64,6 +64,8 @@ EXPORTS = {
     "ivg_cache_destroy": (None, [C.c_void_p, C.c_void_p]),
     "ivg_generate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ivg_generate_continue": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ivg_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ivg_profile_enable": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ivg_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(IvgProfileStats)]),

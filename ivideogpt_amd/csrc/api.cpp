@@ -413,6 +413,23 @@ int ivg_generate(ivg_engine* e, const int64_t* prompt, int64_t prompt_stride, in
     return r.generate(prompt, prompt_stride, B, L0, n_new, actions, act_T, ctx, uniforms, top_k, ids_out, reward_out); });
 }
 
+int ivg_generate_continue(ivg_engine* e, const int64_t* prompt, int64_t prompt_stride, int B, int L0, int n_new, const float* actions,
+                          int act_T, int ctx, const float* uniforms, int top_k, int64_t* ids_out, float* reward_out, ivg_stream stream) {
+  if (!e) return IVG_ERR_INVALID;
+  if (e->cfg.num_layers <= 0) return e->fail(IVG_ERR_INVALID, "generate: engine was created without a transformer");
+  if (!actions || e->cfg.action_dim <= 0 || !e->act_w) return e->fail(IVG_ERR_INVALID, "generate_continue: action-conditioned models only");
+  if (B <= 0 || n_new < 1 || L0 < 2 || L0 + n_new > e->Lmax)
+    return e->fail(IVG_ERR_CAPACITY, "generate: sequence of " + std::to_string(L0 + n_new) + " tokens exceeds the KV cache (" + std::to_string(e->Lmax) + ")");
+  if (L0 < 257 * ctx || (L0 - 257 * ctx) % 17 != 0) return e->fail(IVG_ERR_INVALID, "generate: action-conditioned prompt must hold 257*ctx + 17*t tokens");
+  const int last = (L0 - 257 * ctx) / 17 + n_new / 17 + ctx - 1;
+  if (last >= act_T || act_T > e->cfg.max_frames) return e->fail(IVG_ERR_INVALID, "generate: action tensor too short (or longer than max_frames)");
+  if (e->kv_B != B || e->kv_len != L0 - 1)
+    return e->fail(IVG_ERR_INVALID, "generate_continue: the KV cache holds " + std::to_string(e->kv_len) + " positions of " + std::to_string(e->kv_B) +
+                                        " trajectories, the call needs " + std::to_string(L0 - 1) + " of " + std::to_string(B));
+  return plan_then_run(e, (hipStream_t)stream, [&](Run& r) {
+    return r.generate(prompt, prompt_stride, B, L0, n_new, actions, act_T, ctx, uniforms, top_k, ids_out, reward_out, true); });
+}
+
 int ivg_logits(ivg_engine* e, const int64_t* ids, int B, int L, const float* actions, int act_T, int ctx, float* logits_out, ivg_stream stream) {
   if (!e) return IVG_ERR_INVALID;
   if (e->cfg.num_layers <= 0) return e->fail(IVG_ERR_INVALID, "logits: engine was created without a transformer");

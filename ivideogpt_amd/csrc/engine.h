@@ -94,6 +94,7 @@ struct ivg_engine {
   ivg::ProfClass prof[IVG_K_COUNT];
   unsigned long long* attn_prof = nullptr;  // [layers][IVG_ATTN_PROF_SLOTS][2][Lmax] wall-clock stamps of the decode attention
   bool attn_prof_on = false;                // ivg_profile_enable(IVG_K_DECODE_ATTN): part of the step-graph key
+  int kv_len = 0, kv_B = 0;                 // the KV cache holds positions [0, kv_len) of kv_B trajectories (last generate call)
   int attn_prof_B = 0;
   double attn_fit_fixed_us = 0, attn_fit_gbps = 0;   // line fit of the last ivg_profile_read(IVG_K_DECODE_ATTN)
 

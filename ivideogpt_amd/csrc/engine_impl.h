@@ -38,7 +38,7 @@ struct Run {
               float* logits_all /* [B][L][V] or null */, float* logits_last /* [B][V] or null */, void* hidden_last);
   int decode_step(int B, const SampleArgs& sa);
   int generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, int n_new, const float* actions, int act_T, int ctx,
-               const float* uniforms, int top_k, int64_t* ids_out, float* reward_out);
+               const float* uniforms, int top_k, int64_t* ids_out, float* reward_out, bool reuse_kv = false);
 
   // ---- measurement
   void prof_begin(DType dt, double flops, double bytes, int base = 0);   // base 0: igemm classes, 2: conv3x3 classes

@@ -85,6 +85,7 @@ int Run::prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const voi
   float* S = flash ? nullptr : (float*)e->ws.alloc((size_t)B * heads * L * Lp * 4);
   char* Pm = flash ? nullptr : (char*)e->ws.alloc((size_t)B * heads * L * Lp * esz(dt));
   if (!planning) {
+    e->kv_len = 0; e->kv_B = 0;   // the cache rows are about to be overwritten (ivg_generate re-validates them at its end)
     CK(launch_embed(ids, ids_stride, e->embed, x, dt, B, L, H, V, st));
     if (act_emb) {  // action embedding on the sdf slot(s): slot i (position 257*ctx - 1 + 17*i) gets action i + ctx - 1
       for (int i = 0;; ++i) {
@@ -236,7 +237,7 @@ static int step_body(ivg_engine* e, hipStream_t st, const GenBuf& g, int B, int 
 }
 
 int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, int n_new, const float* actions, int act_T, int ctx,
-                  const float* uniforms, int top_k, int64_t* ids_out, float* reward_out) {
+                  const float* uniforms, int top_k, int64_t* ids_out, float* reward_out, bool reuse_kv) {
   const ivg_config& c = e->cfg;
   const DType dt = e->llm_dt;
   const int H = c.hidden_size, V = c.vocab_size;
@@ -245,8 +246,9 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
   gen_layout(e, g, e->gen_buf, &tot);
   const long Ltot = (long)L0 + n_new;
   if (planning) {
-    return prefill(nullptr, 0, std::min(B, g.Bc), L0, nullptr, 0, ctx, false, nullptr, nullptr, nullptr);
+    return reuse_kv ? 0 : prefill(nullptr, 0, std::min(B, g.Bc), L0, nullptr, 0, ctx, false, nullptr, nullptr, nullptr);
   }
+  e->kv_len = 0; e->kv_B = 0;   // set again once every launch of this call is queued
   for (int b0 = 0; b0 < B; b0 += g.Bc) {
     const int Bc = std::min(g.Bc, B - b0);
     if (e->attn_prof_on) {  // fresh launch windows for this call: every stamp slot back to 0 (= not stamped)
@@ -260,13 +262,16 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
                                hipMemcpyDeviceToDevice, st));
     if (actions)
       CK(launch_action_embed(actions + (long)b0 * act_T * c.action_dim, e->act_w, e->act_b, g.act_emb, dt, Bc * act_T, c.action_dim, H, st));
-    IVG_TRY(prefill(g.ids, g.ids_ld, Bc, L0, actions ? g.act_emb : nullptr, act_T, ctx, true, nullptr, g.logits, g.x));
+    if (!reuse_kv) IVG_TRY(prefill(g.ids, g.ids_ld, Bc, L0, actions ? g.act_emb : nullptr, act_T, ctx, true, nullptr, g.logits, g.x));
     // chains: rows split into up to e->chains groups of a multiple of 16 rows
     int nc = std::max(1, std::min(e->chains, MAX_CHAINS));
     int cs = ((Bc + nc - 1) / nc + 15) / 16 * 16;
     nc = (Bc + cs - 1) / cs;
     if (st == nullptr) { nc = 1; cs = Bc; }  // side streams cannot fork from the legacy default stream under capture
-    for (int c = 0; c < nc; ++c) CK(launch_state_set(chain_state(g, c), L0, 1, st));
+    // reuse_kv: the cache already holds positions [0, L0 - 1); the step counter starts at j = 0, whose "decision" is the
+    // forced sdf the prompt ends with (0 % 17 == 0): the sampler re-embeds it with the new action and the forward pass of
+    // that step appends position L0 - 1 and yields the logits of new token 1 -- exactly what the prefill would have left
+    for (int c = 0; c < nc; ++c) CK(launch_state_set(chain_state(g, c), reuse_kv ? L0 - 1 : L0, reuse_kv ? 0 : 1, st));
     SampleArgs sa{};
     sa.logits = g.logits; sa.V = V;
     sa.uniforms = uniforms ? g.uni : nullptr; sa.n_uni = g.ids_ld;
@@ -280,7 +285,7 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
     // step 1 eagerly (also performs every kernel's one-time attribute setup), then replay a captured step graph
     const std::string key = std::to_string(Bc) + ":" + std::to_string(nc) + ":" + (uniforms ? "s" : "g") + ":" + std::to_string(top_k) + ":" +
                             std::to_string(sa.forced_period) + ":" + std::to_string(ctx) + ":" + std::to_string(act_T) + ":" +
-                            std::to_string(L0) + (e->attn_prof_on ? ":p" : "");
+                            std::to_string(L0) + (e->attn_prof_on ? ":p" : "");   // (the same step graph serves both entry modes)
     // reward head: reads the residual stream left by the LAST forward pass, i.e. before the final decide-only step
     // overwrites it with the embedding of the last token (mbrl/video_predictor.py:311-313: hidden state of the last step)
     auto reward = [&]() -> int {
@@ -290,6 +295,7 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
       return 0;
     };
     int j = 1;
+    if (reuse_kv) IVG_TRY(step_body(e, st, g, Bc, nc, cs, sa, true));   // j = 0: feed the prompt's last token
     if (n_new == 1) IVG_TRY(reward());
     if (n_new >= 1) { IVG_TRY(step_body(e, st, g, Bc, nc, cs, sa, j < n_new)); ++j; }
     hipGraphExec_t exec = nullptr;
@@ -325,6 +331,7 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
     CK((int)hipMemcpy2DAsync(ids_out + (long)b0 * Ltot, (size_t)Ltot * 8, g.ids, (size_t)g.ids_ld * 8, (size_t)Ltot * 8, Bc,
                              hipMemcpyDeviceToDevice, st));
   }
+  if (B <= g.Bc) { e->kv_len = L0 + n_new - 1; e->kv_B = B; }   // the last new token is decided but never fed
   return 0;
 }
 

@@ -131,11 +131,12 @@ class Engine:
     def cache_destroy(self, h):
         self.lib.ivg_cache_destroy(self.h, h)
 
-    def generate(self, prompt, n_new, out, actions=None, ctx=1, uniforms=None, top_k=100, reward=None):
+    def generate(self, prompt, n_new, out, actions=None, ctx=1, uniforms=None, top_k=100, reward=None, reuse_kv=False):
         B, L0 = prompt.shape
         act_T = actions.shape[1] if actions is not None else 0
+        fn = self.lib.ivg_generate_continue if reuse_kv else self.lib.ivg_generate
         with self.stream() as s:
-            self.check(self.lib.ivg_generate(self.h, _ptr(prompt), prompt.stride(0), B, L0, int(n_new), _ptr(actions), act_T, int(ctx),
+            self.check(fn(self.h, _ptr(prompt), prompt.stride(0), B, L0, int(n_new), _ptr(actions), act_T, int(ctx),
                                              _ptr(uniforms), int(top_k), _ptr(out), _ptr(reward), s), "generate")
             for t in (prompt, out, actions, uniforms, reward):
                 if t is not None:

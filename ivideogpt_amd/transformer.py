@@ -172,9 +172,12 @@ class HeadModelWithAction:
 
     @torch.no_grad()
     def generate(self, inputs_token, do_sample=True, temperature=1.0, top_k=100, max_new_tokens=None, pad_token_id=50256,
-                 action=None, generator=None, uniforms=None, return_reward=False):
+                 action=None, generator=None, uniforms=None, return_reward=False, reuse_cache=False):
         """action_model.py:56-121: action (B, T, D); new token j is the forced sdf when j % 17 == 0; the i-th sdf slot's
-        embedding gets ``action_linear(action[:, i + context - 1])``.  -> int64 (B, L0 + max_new_tokens)."""
+        embedding gets ``action_linear(action[:, i + context - 1])``.  -> int64 (B, L0 + max_new_tokens).
+        ``reuse_cache=True`` (step-wise rollouts, mbrl/video_predictor.py:286-317): the prompt is the previous call's full
+        output plus the forced ``sdf``; the engine keeps the KV cache of that call and feeds only the last prompt token
+        instead of prefilling the grown prompt again (raises AssertionError when the cache holds something else)."""
         assert temperature == 1.0
         llm = self.llm
         ids = inputs_token.to(device=llm.device, dtype=torch.int64).contiguous()
@@ -184,7 +187,7 @@ class HeadModelWithAction:
         u = uniforms if uniforms is not None else llm._uniforms(B, max_new_tokens, do_sample, generator)
         reward = torch.empty(B, dtype=torch.float32, device=llm.device) if return_reward else None
         llm._ensure(B, act.shape[1]).generate(ids, max_new_tokens, out, actions=act, ctx=self.context, uniforms=u,
-                                              top_k=top_k or llm._cfg["vocab_size"], reward=reward)
+                                              top_k=top_k or llm._cfg["vocab_size"], reward=reward, reuse_kv=reuse_cache)
         return (out, reward) if return_reward else out
 
     @torch.no_grad()

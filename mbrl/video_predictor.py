@@ -4,8 +4,9 @@ Model / tokenizer TRAINING (``update_*``, :152-265) is out of scope.
 Step t: action_t is added to the embedding of the current last token (the t-th ``sdf`` slot, :295-296), 16 dynamics tokens are
 sampled, reward = ``reward_linear`` of the last layer's hidden state at the last generation step (:311-313), the predicted
 tokens plus a forced ``sdf`` extend the sequence (:315-317), the new frame is decoded with the detokenizer cache (:320-321) and
-pushed onto the 3-frame stack (:323-325).  The engine keeps tokens (not embeddings) and re-prefills the grown prompt each step
-(a persistent cross-step KV cache is the next optimisation)."""
+pushed onto the 3-frame stack (:323-325).  The engine keeps tokens (not embeddings); from the second step on it also keeps the KV
+cache of the previous step (``reuse_cache``), so a step costs 17 cached decode steps instead of a prefill of the grown prompt
+(the reference re-runs the whole prefix through ``llm.generate(inputs_embeds=...)`` every step)."""
 import os
 import sys
 
@@ -19,10 +20,10 @@ def symexp(x):
 
 
 class VideoPredictor:
-    def __init__(self, tokenizer, model, context_length=2, symlog=True, device="cuda"):
+    def __init__(self, tokenizer, model, context_length=2, symlog=True, device="cuda", reuse_cache=True):
         """tokenizer: ivideogpt_amd.CompressiveVQModel; model: ivideogpt_amd.HeadModelWithAction(reward_prediction=True)."""
         self.tokenizer, self.model, self.device = tokenizer, model, torch.device(device)
-        self.context_length, self.symlog = context_length, symlog
+        self.context_length, self.symlog, self.reuse_cache = context_length, symlog, reuse_cache
 
     @torch.no_grad()
     def rollout(self, obs, policy, horizon):
@@ -44,8 +45,11 @@ class VideoPredictor:
             if act is None:  # fixed-size action table: slot i of the sequence reads row i + ctx - 1 (+1 never-fed row at the end)
                 act = torch.zeros(B, ctx - 1 + horizon + 1, action.shape[-1], device=self.device)
             act[:, ctx - 1 + t] = action
-            out, reward = self.model.generate(tokens, do_sample=True, temperature=1.0, top_k=100, max_new_tokens=17, pad_token_id=50256,
-                                              action=act, return_reward=True)
+            kw = dict(do_sample=True, temperature=1.0, top_k=100, max_new_tokens=17, pad_token_id=50256, action=act, return_reward=True)
+            try:
+                out, reward = self.model.generate(tokens, reuse_cache=self.reuse_cache and t > 0, **kw)
+            except AssertionError:    # the policy (or anyone else) used the transformer in between: prefill again
+                out, reward = self.model.generate(tokens, **kw)
             predicted = out[:, tokens.shape[1]:tokens.shape[1] + 16]
             tokens = torch.cat([tokens, predicted, torch.full((B, 1), sdf, dtype=tokens.dtype, device=self.device)], 1)
             fmap, cache = self.tokenizer.detokenize(torch.cat([init_tokens, predicted], 1), ctx, cache=cache, return_cache=True)

@@ -155,3 +155,42 @@ def test_teacher_forced_logits_with_actions():
     x[:, start] += ae[:, 1:-1]                               # action_embeds[:, context - 1 : -1]
     ref = ollm.logits(embeds=x)
     assert (lg - ref).abs().max().item() < 1e-3
+
+
+def test_stepwise_rollout_with_kept_kv_cache_equals_re_prefill():
+    """HeadModelWithAction.generate(reuse_cache=True): step t feeds only the last prompt token against the KV cache of step
+    t - 1 (17 cached decode steps per environment step) -- same tokens as prefilling the grown prompt every step, rewards
+    within 1e-3; a prompt the cache does not match is refused (AssertionError), never silently mis-decoded."""
+    from ivideogpt_amd import HeadModelWithAction, LlamaForCausalLM, weights as W
+    lsd = W.random_llama_state_dict(LLM_CFG, 81, action_dim=4, reward_prediction=True)
+    head = HeadModelWithAction(LlamaForCausalLM(LLM_CFG, None, dtype="fp32"), 4, 513, 16, 2, 16, reward_prediction=True)
+    head.load_state_dict(lsd, strict=True)
+    head.to(DEV)
+    g = torch.Generator().manual_seed(8)
+    B, horizon = 5, 4
+    prompt0 = torch.randint(0, 1024, (B, 514), generator=g)
+    prompt0[:, -1] = 1025                                          # the sdf slot that receives the first action
+    act = torch.randn(B, 1 + horizon + 1, 4, generator=g).to(DEV)
+    us = [torch.rand(B, 17, generator=g).to(DEV) for _ in range(horizon)]
+    sdf = torch.full((B, 1), 1025, dtype=torch.int64, device=DEV)
+
+    def run(reuse):
+        tokens, outs, rews = prompt0.to(DEV), [], []
+        for t in range(horizon):
+            out, r = head.generate(tokens, do_sample=True, top_k=100, max_new_tokens=17, action=act, uniforms=us[t],
+                                   return_reward=True, reuse_cache=reuse and t > 0)
+            outs.append(out.cpu()); rews.append(r.cpu())
+            tokens = torch.cat([tokens, out[:, tokens.shape[1]:tokens.shape[1] + 16], sdf], 1)
+        return outs, rews
+
+    a, ra = run(False)
+    b, rb = run(True)
+    for t in range(horizon):
+        assert torch.equal(a[t], b[t]), f"step {t}: {(a[t] != b[t]).sum().item()} tokens differ"
+        assert (ra[t] - rb[t]).abs().max().item() < 1e-3
+    assert (b[-1][:, 514 + 16::17] == 1025).all()                  # every 17th new token is the forced sdf
+    with pytest.raises(AssertionError):                            # cache holds 514 + 17 * 4 - 1 positions, not 513
+        head.generate(prompt0.to(DEV), do_sample=False, max_new_tokens=17, action=act, reuse_cache=True)
+    with pytest.raises(AssertionError):                            # other batch size
+        head.generate(torch.cat([prompt0, b[0][:, 514:530], sdf.cpu()], 1)[:3].to(DEV), do_sample=False, max_new_tokens=17,
+                      action=act[:3], reuse_cache=True)
