@@ -280,6 +280,8 @@ def main():
                 out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     parallel.barrier()
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
