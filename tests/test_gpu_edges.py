@@ -150,3 +150,63 @@ def test_out_of_range_dynamics_tokens_are_clamped_like_the_reference():
     want = ora.detokenize(ids, ctx)
     got = m.detokenize(ids.to(DEV), ctx).cpu()
     assert (got - want).abs().max().item() < 1e-3
+
+
+def test_tokenize_many_clips_bit_exact_vs_oracle():
+    """24 more clips through the mini tokenizer (13,128 token ids): uniform noise, smooth ramps, constant and saturated frames,
+    zero-padded futures (the reference's callers pad with zero frames: vp/ivideogpt_interface.py:158-169) -- every id equal
+    to the CPU oracle's, and the decoded frames within 1e-3."""
+    cfg, sd, ctx, _, _ = tokenizer_fixture("tok_mini64_ctx2.npz")
+    m, ora = make_tok(cfg, sd, ctx), oracle_tokenizer(cfg, sd, ctx)
+    g = torch.Generator().manual_seed(77)
+    T = 4
+    clips = []
+    clips.append(torch.rand(6, T, 3, 64, 64, generator=g))                                   # noise
+    ramp = torch.linspace(0, 1, 64)[None, :].expand(64, 64)
+    smooth = torch.stack([ramp, ramp.T, 1 - ramp], 0)[None, None].expand(4, T, 3, 64, 64).clone()
+    smooth += 0.05 * torch.rand(4, T, 3, 64, 64, generator=g)
+    clips.append(smooth.clamp(0, 1))                                                          # ramps
+    const = torch.rand(4, 1, 3, 1, 1, generator=g).expand(4, T, 3, 64, 64).clone()
+    clips.append(const)                                                                       # flat colour frames
+    sat = (torch.rand(4, T, 3, 64, 64, generator=g) > 0.5).float()
+    clips.append(sat)                                                                         # saturated 0 / 1
+    padded = torch.rand(6, T, 3, 64, 64, generator=g)
+    padded[:, ctx:] = 0
+    clips.append(padded)                                                                      # zero-padded future frames
+    px = torch.cat(clips, 0)
+    assert px.shape[0] == 24
+    want, _ = ora.tokenize(px, ctx)
+    got, _ = m.tokenize(px.to(DEV), ctx)
+    bad = (got.cpu() != want).nonzero()
+    assert len(bad) == 0, f"{len(bad)} of {want.numel()} ids differ, first at {bad[:3].tolist()}"
+    err = (m.detokenize(got, ctx).cpu() - ora.detokenize(want, ctx)).abs().max().item()
+    assert err < 1e-3, f"decoded pixels max abs err {err:.2e}"
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_sampled_rollouts_many_rows_match_oracle(seed):
+    """top-k 100 sampling with explicit uniforms, 8 trajectories x 120 new tokens per seed, action-free and action-conditioned:
+    every token equal to the oracle's (fp32 engine mode)."""
+    from oracle.llama import generate_cached
+    from ivideogpt_amd import HeadModelWithAction, LlamaForCausalLM
+    g = torch.Generator().manual_seed(100 + seed)
+    cfg, sd, fx = llama_fixture("llama_tiny_ctx1_free.npz")
+    prompt = torch.randint(0, 8192, (8, 257), generator=g)
+    prompt[:, -1] = cfg["vocab_size"] - 1
+    u = torch.rand(8, 120, generator=g)
+    out = make_llm(cfg, sd).generate(prompt.to(DEV), do_sample=True, top_k=100, max_new_tokens=120, uniforms=u.to(DEV)).cpu()
+    ref = generate_cached(oracle_llama(cfg, sd), prompt, 120, top_k=100, uniforms=u)
+    assert torch.equal(out, ref), f"action-free: {(out != ref).sum().item()} tokens differ"
+    cfg, sd, fx = llama_fixture("llama_tiny_ctx1_act.npz")
+    ctx, adim = int(fx["ctx"]), int(fx["action_dim"])
+    head = HeadModelWithAction(LlamaForCausalLM(cfg, None, dtype="fp32"), adim, 257 * ctx - 1, 16, ctx, 9)
+    head.load_state_dict(sd, strict=True)
+    head.to(DEV)
+    action = torch.randn(8, 9, adim, generator=g)
+    n_new = 17 * 7 - 1
+    u = torch.rand(8, n_new, generator=g)
+    out = head.generate(prompt.to(DEV), do_sample=True, top_k=100, max_new_tokens=n_new, action=action.to(DEV), uniforms=u.to(DEV)).cpu()
+    ae = torch.nn.functional.linear(action, sd["action_linear.weight"], sd["action_linear.bias"])
+    ref = generate_cached(oracle_llama(cfg, sd, prefix="llm.model."), prompt, n_new, top_k=100, uniforms=u, action_embeds=ae, ctx=ctx,
+                          sdf_token=cfg["vocab_size"] - 1)
+    assert torch.equal(out, ref), f"action-conditioned: {(out != ref).sum().item()} tokens differ"
