@@ -213,13 +213,39 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(const bf16_t* __rest
 #pragma unroll
   for (int d = 0; d < 4; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m = -INFINITY, lsum = 0.f;
+  // The four waves of the workgroup need the same 64-key tile of K and V^T: it is staged once in LDS (rows of 128 + 16
+  // bytes: 16 consecutive rows hit 16 distinct bank groups) instead of being pulled from L2 by every wave, and the next
+  // tile travels from global memory into registers while the current one is consumed.
+  constexpr int PITCH = HD + 8;
+  __shared__ __attribute__((aligned(16))) bf16_t sK[64 * PITCH];
+  __shared__ __attribute__((aligned(16))) bf16_t sV[64 * PITCH];
+  const int srow0 = tid >> 3, scol = (tid & 7) * 8;   // this thread stages chunks (srow0, scol) and (srow0 + 32, scol)
+  Chunk16 pk[2], pv[2];
+  auto fetch = [&](int kt) {
+    const int k0 = kt * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = srow0 + i * 32;
+      const int kr = k0 + row;
+      pk[i] = *(const Chunk16*)(kb + (long)(kr < Lmax ? kr : Lmax - 1) * HD + scol);   // rows past the diagonal are masked below
+      pv[i] = *(const Chunk16*)(vb + (long)row * Lp + k0 + scol);
+    }
+  };
+  fetch(0);
   for (int kt = 0; kt <= qt; ++kt) {
     const int k0 = kt * 64;
+    __syncthreads();   // every wave is done with the previous tile
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *(Chunk16*)(sK + (srow0 + i * 32) * PITCH + scol) = pk[i];
+      *(Chunk16*)(sV + (srow0 + i * 32) * PITCH + scol) = pv[i];
+    }
+    __syncthreads();
+    if (kt < qt) fetch(kt + 1);
     bf16x8 kf[4][2];
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
-      const int kr = k0 + sub * 16 + lr;
-      const bf16_t* krow = kb + (long)(kr < Lmax ? kr : Lmax - 1) * HD;   // rows past the diagonal are masked below
+      const bf16_t* krow = sK + (sub * 16 + lr) * PITCH;
       kf[sub][0] = *(const bf16x8*)(krow + lg * 8);
       kf[sub][1] = *(const bf16x8*)(krow + 32 + lg * 8);
     }
@@ -228,7 +254,7 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(const bf16_t* __rest
     for (int d = 0; d < 4; ++d)
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {
-        const bf16_t* vrow = vb + (long)(d * 16 + lr) * Lp + k0 + pr * 32 + lg * 4;
+        const bf16_t* vrow = sV + (d * 16 + lr) * PITCH + pr * 32 + lg * 4;
         vf[d][pr][0] = *(const bf16x4*)vrow;
         vf[d][pr][1] = *(const bf16x4*)(vrow + 16);
       }
