@@ -526,6 +526,11 @@ int ivg_op_igemm(const ivg_igemm_args* a, int dtype, ivg_stream stream) {
     if (rc == 0) return IVG_OK;
     if (rc > 0) return IVG_ERR_HIP;
   }
+  {  // large dense GEMMs: the 256 x 256-tile kernel first, as the engine does
+    const int rc = launch_gemm256(g, (DType)dtype, (hipStream_t)stream);
+    if (rc == 0) return IVG_OK;
+    if (rc > 0) return IVG_ERR_HIP;
+  }
   return launch_igemm(g, (DType)dtype, (hipStream_t)stream) ? IVG_ERR_HIP : IVG_OK;
 }
 

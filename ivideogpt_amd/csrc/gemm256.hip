@@ -1,0 +1,191 @@
+// Large plain GEMM for gfx950 (bf16):  Y[m][n] = epi( sum_k X[m][k] * W[n][k] ),  M in the tens of thousands.
+// The prompt pass of the transformer (SURVEY.md 2.4 K14 / K17 at L = 514: 32,896 rows) and any dense 1x1 layer large enough.
+//
+// Why a third MFMA kernel: the generic implicit GEMM (igemm.hip, 128 x 128 tiles, 64 FLOP per byte pulled into the CU) sits
+// at the per-CU ingest limit measured on MI355X (~17 B/clk from L2): 510-570 TFLOP/s on these shapes, MFMA pipe 16-23 %
+// busy (profiles/r01_pmc_mfma_lds.txt).  Only a larger tile changes that ratio:
+//   * a workgroup owns a 256 x 256 output tile (128 FLOP/B), 16 waves = 4 (M) x 4 (N), each a 64 x 64 sub-tile of
+//     v_mfma_f32_16x16x32_bf16 fragments with swapped operands (a lane owns 4 consecutive output columns);
+//   * K advances 32 elements (one 64-byte LDS row per matrix row) per step; the A and W slabs of a step (16 KiB each)
+//     arrive by LDS-DMA (global_load_lds, 16 B/lane) into a ring of four stages issued three steps ahead and retired by
+//     COUNTED s_waitcnt vmcnt(n) + raw s_barrier, so the DMA queue never drains inside the loop;
+//   * 64-byte rows with the XOR swizzle on the SOURCE chunk (conflict-free ds_read_b128 of 16 consecutive rows);
+//   * epilogue in registers (bias, residual, SiLU, SiLU(gate) * up on the interleaved weight packing), then staged through
+//     the (now free) ring so that global stores are whole 16-byte runs of an output row;
+//   * XCD-aware block order: the N tiles of one M tile run on one XCD and share its L2 copy of the A slab.
+#include <cstdlib>
+
+#include "igemm.h"
+
+namespace ivg {
+
+struct G256Dev {
+  const bf16_t* X; const bf16_t* W; bf16_t* Y; const bf16_t* R; const float* bias;
+  int M, N, K, ldx, ldw, ldy;
+  int tiles_n;
+  int flags;
+};
+
+__device__ __attribute__((aligned(16))) unsigned char g_zero_chunk_g256[16];
+
+__device__ __forceinline__ void g256_dma16(const void* gsrc, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ int g256_key(int row) { return (row >> 1) & 3; }
+__device__ __forceinline__ int g256_swz(int row, int chunk) { return row * 64 + ((chunk ^ g256_key(row)) << 4); }
+
+constexpr int G256_STAGES = 4;
+constexpr int G256_SLAB = 256 * 64;               // bytes of one 256-row x 32-element slab
+constexpr int G256_STAGE = 2 * G256_SLAB;         // A | W
+constexpr int G256_PITCH = 256 * 2 + 16;          // staged output row (bytes): + 16 spreads the 16 rows of a fragment over banks
+
+__global__ __launch_bounds__(1024) void gemm256_kernel(const G256Dev p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int wm = wave & 3, wn = wave >> 2;
+  const int nwg = gridDim.x;
+  int v;
+  {  // blocks b, b + 8, ... share an XCD: give each XCD a contiguous run of tiles with the N tile fastest (bijective)
+    const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int tile_n = v % p.tiles_n, tile_m = v / p.tiles_n;
+  const int m0 = tile_m * 256, n0 = tile_n * 256;
+  const int steps = p.K >> 5;
+
+  // DMA of one step: thread -> (row = tid / 4, source chunk = (tid % 4) ^ key(row)); a wave fills 16 rows = 1 KiB, lane-linear
+  const int drow = tid >> 2, dslot = tid & 3;
+  const int dchunk = dslot ^ g256_key(drow);
+  const bool a_ok = (m0 + drow) < p.M;
+  const bf16_t* a_src = p.X + (long)(a_ok ? m0 + drow : 0) * p.ldx + dchunk * 8;
+  const bf16_t* w_src = p.W + (long)(n0 + drow) * p.ldw + dchunk * 8;
+  auto issue = [&](int step) {
+    unsigned char* st = smem + (step % G256_STAGES) * G256_STAGE + wave * 1024;
+    g256_dma16(a_ok ? (const void*)(a_src + step * 32) : (const void*)g_zero_chunk_g256, st);
+    g256_dma16((const void*)(w_src + step * 32), st + G256_SLAB);
+  };
+
+  f32x4 acc[4][4];   // [a: N fragment][b: M fragment]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int s = 0; s < G256_STAGES - 1 && s < steps; ++s) issue(s);
+  // step 0 must have landed: at most the (min(steps, STAGES - 1) - 1) younger steps (2 DMA instructions each) stay in flight
+  if (steps >= 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (steps == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  for (int s = 0; s < steps; ++s) {
+    if (s + G256_STAGES - 1 < steps) issue(s + G256_STAGES - 1);   // its stage was read at step s - 1, before the last barrier
+    const unsigned char* sa = smem + (s % G256_STAGES) * G256_STAGE;
+    const unsigned char* sw = sa + G256_SLAB;
+    Chunk16 xa[4], wv[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) xa[b] = *(const Chunk16*)(sa + g256_swz(wm * 64 + b * 16 + lr, lg));
+#pragma unroll
+    for (int a = 0; a < 4; ++a) wv[a] = *(const Chunk16*)(sw + g256_swz(wn * 64 + a * 16 + lr, lg));
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[a]), __builtin_bit_cast(bf16x8, xa[b]),
+                                                            acc[a][b], 0, 0, 0);
+    // step s + 1 must have landed before anyone reads it: everything but the younger steps still allowed in flight
+    const int young = min(G256_STAGES - 2, steps - 2 - s);   // steps s + 2 .. in flight after this wait
+    if (young >= 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else if (young == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+  // ---- epilogue: lane holds 4 consecutive columns n of row (wm*64 + b*16 + lr)
+  const int flags = p.flags;
+  const bool glu = flags & IG_GLU;
+  const int out_cols = glu ? 128 : 256;               // columns this tile writes
+  const int out_n0 = glu ? (n0 >> 1) : n0;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int row = wm * 64 + b * 16 + lr;
+    const int m = m0 + row;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      if (glu && (a & 1)) continue;
+      float v4[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v4[r] = acc[a][b][r];
+      const int ncol = wn * 64 + a * 16 + lg * 4;     // column inside the 256-wide tile (of the PACKED weight rows for GLU)
+      if (flags & IG_BIAS_N) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v4[r] += p.bias[n0 + ncol + r];
+      }
+      int ocol = ncol;
+      if (glu) {  // rows [16 gate | 16 up] per 32 packed weight rows: fragment a = gate, a + 1 = up of the same 16 outputs
+        const int a1 = a + 1 < 4 ? a + 1 : a;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v4[r] = silu_f(v4[r]) * acc[a1][b][r];
+        ocol = (wn * 64 + a * 16) / 2 + lg * 4;
+      }
+      if ((flags & IG_RESIDUAL) && m < p.M) {
+        const bf16x4 rv = *(const bf16x4*)(p.R + (long)m * p.ldy + out_n0 + ocol);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v4[r] += (float)rv[r];
+      }
+      if (flags & IG_SILU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v4[r] = silu_f(v4[r]);
+      }
+      *(bf16x4*)(smem + row * G256_PITCH + ocol * 2) = bf16x4{(bf16_t)v4[0], (bf16_t)v4[1], (bf16_t)v4[2], (bf16_t)v4[3]};
+    }
+  }
+  __syncthreads();
+  const int cpr = out_cols / 8;                        // 16-byte chunks per output row
+  for (int q = tid; q < 256 * cpr; q += 1024) {
+    const int row = q / cpr, ch = q - row * cpr;
+    if (m0 + row >= p.M) continue;
+    const Chunk16 val = *(const Chunk16*)(smem + row * G256_PITCH + ch * 16);
+    *(Chunk16*)(p.Y + (long)(m0 + row) * p.ldy + out_n0 + ch * 8) = val;
+  }
+}
+
+static bool gemm256_enabled() {
+  const char* e = getenv("IVG_GEMM256");   // IVG_GEMM256=0: always the generic implicit GEMM (A/B tests)
+  return !(e && e[0] == '0');
+}
+
+// Returns -1 when the shape is not covered (caller uses launch_igemm).
+int launch_gemm256(const IgemmArgs& a, DType dtype, hipStream_t stream) {
+  if (dtype != BF16 || !gemm256_enabled()) return -1;
+  if (a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0 || a.ups) return -1;
+  if (a.nb0 * a.nb1 * a.nb2 != 1 || a.alpha != 1.0f) return -1;
+  if (a.flags & ~(IG_BIAS_N | IG_RESIDUAL | IG_SILU | IG_GLU)) return -1;
+  const long M = (long)a.Nimg * a.Hout * a.Wout;
+  if (a.Hout != a.Hin || a.Wout != a.Win || a.ldx != a.Cin) return -1;   // dense rows
+  if (a.c_ch != 1 || (a.c_grp > 1)) return -1;
+  if (a.Nimg > 1 && a.c_img != (long)a.Hout * a.Wout * a.c_pix) return -1;
+  const bool glu = a.flags & IG_GLU;
+  if (M < 4096 || M > 0x7fffffffL || a.N % 256 != 0 || a.Cin % 32 != 0 || a.Cin < 64 || a.ldw % 8 != 0 || a.c_pix % 8 != 0) return -1;
+  if (((uintptr_t)a.X & 15) || ((uintptr_t)a.W & 15) || ((uintptr_t)a.Y & 15) || ((a.flags & IG_RESIDUAL) && ((uintptr_t)a.R & 7))) return -1;
+  if (glu && (a.flags & IG_BIAS_N)) return -1;
+  G256Dev d;
+  d.X = (const bf16_t*)a.X; d.W = (const bf16_t*)a.W; d.Y = (bf16_t*)a.Y; d.R = (const bf16_t*)a.R; d.bias = a.bias;
+  d.M = (int)M; d.N = a.N; d.K = a.Cin; d.ldx = a.ldx; d.ldw = a.ldw; d.ldy = (int)a.c_pix;
+  d.tiles_n = a.N / 256;
+  d.flags = a.flags;
+  const int smem = 256 * G256_PITCH > G256_STAGES * G256_STAGE ? 256 * G256_PITCH : G256_STAGES * G256_STAGE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const long tiles = (long)cdiv(M, 256) * d.tiles_n;
+  hipLaunchKernelGGL(gemm256_kernel, dim3((unsigned)tiles), dim3(1024), smem, stream, d);
+  return (int)hipGetLastError();
+}
+
+}  // namespace ivg

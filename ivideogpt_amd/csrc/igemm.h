@@ -42,6 +42,8 @@ struct IgemmArgs {
 
 // dtype = element type of X / W / R (and of Y unless IG_OUT_F32).  Returns hipError_t as int.
 int launch_igemm(const IgemmArgs& a, DType dtype, hipStream_t stream);
+// 256 x 256-tile plain GEMM for tens of thousands of rows, bf16 (gemm256.hip); -1 when the shape is not covered
+int launch_gemm256(const IgemmArgs& a, DType dtype, hipStream_t stream);
 // LDS-halo 3x3 stride-1 kernel (conv3x3.hip); returns -1 when the shape is not covered (use launch_igemm then)
 int launch_conv3x3(const IgemmArgs& a, DType dtype, hipStream_t stream);
 

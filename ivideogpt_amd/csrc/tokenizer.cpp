@@ -59,7 +59,9 @@ int Run::gemm(DType dt, const IgemmArgs& a, double flops, double bytes) {
   Run& R = *this;
   if (planning) return 0;
   prof_begin(dt, flops, bytes);
-  CK(launch_igemm(a, dt, st));
+  int rc = launch_gemm256(a, dt, st);   // large dense GEMMs (prompt pass); -1 = not covered
+  if (rc == -1) rc = launch_igemm(a, dt, st);
+  CK(rc);
   prof_end(dt);
   return 0;
 }
