@@ -111,7 +111,7 @@ def cpu_baseline(res, medium, ctx, T, sample_b, threads, budget_s=150):
 KERNEL_NAMES = {
     "decode_attn": "ivg::decode_attn_kernel (RoPE + KV append + single-query attention over the KV cache)",
     "conv3x3": "ivg::conv3x3_kernel (LDS-halo 3x3 convolution, MFMA)",
-    "igemm": "ivg::igemm_kernel<128,128,64> (implicit-GEMM conv / GEMM, MFMA)",
+    "igemm": "ivg::gemm256_kernel + ivg::igemm_kernel<128,128,64> (dense GEMMs / implicit-GEMM convs other than 3x3, MFMA)",
 }
 
 
