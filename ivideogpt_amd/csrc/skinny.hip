@@ -13,6 +13,9 @@
 //   * epilogues fuse what would otherwise be extra latency-bound launches: RMSNorm of the input rows (row scale
 //     from the activations the wave streams anyway; norm weight pre-folded into W), in-place residual add,
 //     SiLU(gate)*up, and the advance of the device-side step counter.
+#include <cstdio>
+#include <cstdlib>
+
 #include "igemm.h"
 
 namespace ivg {
@@ -240,9 +243,16 @@ static void pick_tile(int M, int N, int K, bool glu, int& MF, int& FN) {
     }
 }
 
+static int g_force_waves = 0;   // tuning override (IVG_SK_FORCE=MF,FN,WAVES; tools/skinny_tune.py), 0 = cost model
+
 template <typename T, int MF, int FN>
 static int launch_sk_w(const SkinnyDev& d, hipStream_t stream) {
-  const int w = pick_waves(d.K, d.splits, Traits<T>::dtype);
+  int w = pick_waves(d.K, d.splits, Traits<T>::dtype);
+  if (g_force_waves) {
+    const int kstep = Traits<T>::dtype == BF16 ? 32 : 16;
+    if ((d.K / d.splits) % (g_force_waves * kstep) != 0) return (int)hipErrorInvalidValue;
+    w = g_force_waves;
+  }
   if constexpr (MF + FN <= 5 && MF * FN <= 4) {  // 1024-thread workgroups only where the 128-VGPR budget holds the burst
     if (w == 16) return launch_sk<T, MF, FN, 16>(d, stream);
   }
@@ -277,6 +287,11 @@ int launch_skinny(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
   if ((a.flags & (SK_NORM | IG_RESIDUAL)) && d.splits != 1) return (int)hipErrorInvalidValue;
   int MF, FN;
   pick_tile(a.M, a.N, a.K, glu, MF, FN);
+  g_force_waves = 0;
+  if (const char* f = getenv("IVG_SK_FORCE")) {   // development: measure a tile shape the cost model would not pick
+    int mf = 0, fn = 0, wv = 0;
+    if (sscanf(f, "%d,%d,%d", &mf, &fn, &wv) == 3) { MF = mf; FN = fn; g_force_waves = wv; }
+  }
   if (MF == 8 && FN == 4) FN = 2;
   return dtype == BF16 ? launch_sk_t<bf16_t>(d, MF, FN, stream) : launch_sk_t<float>(d, MF, FN, stream);
 }
