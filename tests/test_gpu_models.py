@@ -246,3 +246,40 @@ def test_flash_prefill_matches_three_kernel_path(monkeypatch, L):
     msg = f"L={L}: max abs err vs fp32 oracle: three-kernel {e3:.3e}, one-pass {ef:.3e}; between them {d:.3e} (logit scale {ref.abs().max():.1f})"
     print(msg)
     assert torch.isfinite(lgf).all() and ef <= 1.25 * e3 + 1e-2 and d <= 2 * e3 + 1e-2, msg
+
+
+def test_full_width_256_tokenizer_vs_oracle():
+    """ctx_vae256 shapes (310 M parameters, five levels up to 768 channels, 256 x 256 frames), one trajectory with two context
+    frames and one future frame: HIP fp32 vs the CPU oracle run here -- ids bit-exact, decoded pixels within 1e-3."""
+    from ivideogpt_amd import weights as W
+    cfg = W.tokenizer_config(**W.CTX_VAE256)
+    cfg["num_vq_embeddings"] = cfg["num_dyn_embeddings"] = 1024   # keep the CPU oracle's cdist small; shapes otherwise full
+    sd = W.random_tokenizer_state_dict(cfg, 33, codebook_std=0.4)
+    px = torch.randint(0, 256, (1, 3, 3, 256, 256), generator=torch.Generator().manual_seed(4)).float() / 255
+    ora = oracle_tokenizer(cfg, sd, 2)
+    ids_ref, _ = ora.tokenize(px, 2)
+    m = make_tok(cfg, sd, 2)
+    ids, _ = m.tokenize(px.to(DEV), 2)
+    bad = (ids.cpu() != ids_ref).nonzero()
+    assert len(bad) == 0, f"{len(bad)} of {ids_ref.numel()} indices differ from the oracle"
+    err = (m.detokenize(ids, 2).cpu() - ora.detokenize(ids_ref, 2)).abs().max().item()
+    assert err < 1e-3, f"256x256 full-width decode max abs err {err:.2e}"
+    # the benchmarked arithmetic (bf16 decode) at this width: finite and close to the fp32 decode (bf16-sized tolerance)
+    m16 = make_tok(cfg, sd, 2, dec="bf16")
+    d16 = m16.detokenize(ids, 2).cpu()
+    assert torch.isfinite(d16).all()
+    ref = ora.detokenize(ids_ref, 2)
+    rel = (d16 - ref).abs().mean().item() / ref.abs().mean().item()
+    assert rel < 3e-2, f"bf16 decode mean relative deviation {rel:.3e}"
+
+
+def test_full_width_llama_medium_logits_vs_oracle():
+    """config_medium (24 layers, hidden 1024, 16 heads; 436 M parameters): teacher-forced logits vs the CPU oracle."""
+    from ivideogpt_amd import weights as W
+    cfg = dict(W.LLAMA_MEDIUM)
+    sd = W.random_llama_state_dict(cfg, 45)
+    ids = torch.randint(0, cfg["vocab_size"], (1, 160), generator=torch.Generator().manual_seed(7))
+    ref = oracle_llama(cfg, sd).logits(ids)
+    lg = make_llm(cfg, sd).logits(ids.to(DEV)).cpu()
+    err = (lg - ref).abs().max().item()
+    assert err < 1e-3, f"24-layer logits max abs err {err:.2e} (scale {ref.abs().max():.1f})"
