@@ -52,11 +52,16 @@ __device__ __forceinline__ int swz_key(int row) { return (row >> 1) & 3; }   // 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 64 + ((chunk ^ swz_key(row)) << 4); }
 
 // ABL (development ablations, 0 in production): 1 no MFMA, 2 no LDS reads + no MFMA, 4 no halo DMA, 8 no weight DMA
-template <typename T, int BN, bool UPS, int ABL = 0>
-__global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
+// NW = 8: 256-pixel tile, two workgroups per CU.  NW = 16: 512-pixel tile, one 1024-thread workgroup per CU whose 16 waves
+// share ONE weight ring -- half the weight bytes per pixel, for the short-K layers that re-stream the whole weight matrix
+// for every tile (launch_conv3x3 picks).
+template <typename T, int BN, bool UPS, int ABL = 0, int NW = 8>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv3x3_kernel(const Conv3Dev p) {
   constexpr int VEC = Traits<T>::VEC;
+  constexpr int NT = NW * 64;              // threads
+  constexpr int PT = NW * 32;              // output pixels per tile
   constexpr int CK = 4 * VEC;              // channels per chunk: one 64-byte LDS row per halo pixel (one MFMA K-step)
-  constexpr int WN = BN / 2;               // 8 waves = 4 (M) x 2 (N)
+  constexpr int WN = BN / 2;               // NW waves = NW/2 (M) x 2 (N)
   constexpr int FM = 4, FN = WN / 16;
   constexpr int W_BYTES = BN * 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -65,7 +70,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int lr = lane & 15, lg = lane >> 4;
-  const int wm = wave & 3, wn = wave >> 2;
+  const int wm = wave % (NW / 2), wn = wave / (NW / 2);
 
   // ---- XCD-aware block order (blocks b, b+8, ... share an XCD/L2): give each XCD a contiguous run of work items
   // with the N tile fastest, so the N tiles of one spatial tile hit the same L2 (bijective for any grid size)
@@ -87,18 +92,18 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
   const T* Wt = (const T*)p.W;
   const int n_base = tile_n * BN;
   const int halo_rows = p.HTH * p.HTW;
-  const int halo_iters = (halo_rows * 4 + 511) / 512;
+  const int halo_iters = (halo_rows * 4 + NT - 1) / NT;
 
-  // one 8-KiB piece of a halo tile: 512 lanes x 16 B, lane-linear in LDS
+  // one piece of a halo tile: NT lanes x 16 B, lane-linear in LDS
   auto issue_halo_piece = [&](int chunk, int it, unsigned char* hb) {
-    const int q = it * 512 + tid;
+    const int q = it * NT + tid;
     const int row = q >> 2, slot = q & 3;
     const int c = slot ^ swz_key(row);
     const int hy = row / p.HTW, hx = row - hy * p.HTW;
     const int iy = iy0 + hy, ix = ix0 + hx;
     const bool ok = (row < halo_rows) & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.Wd);
     const void* src = ok ? (const void*)(X + ((long)(iy * p.Wd + ix) * p.Cin + chunk * CK + c * VEC)) : (const void*)g_zero_chunk3;
-    glds16b(src, hb + (it * 512 + wave * 64) * 16);
+    glds16b(src, hb + (it * NT + wave * 64) * 16);
   };
   auto issue_w = [&](int step, unsigned char* wb) {
     const int chunk = step / 9, tap = step - chunk * 9;
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
         if (chunk + 1 < nchunks && tap < halo_iters) { issue_halo_piece(chunk + 1, tap, hbuf0 + ((chunk + 1) & 1) * p.hb_bytes); issued += 1; }
       }
     };
-    const bool early = __builtin_amdgcn_readfirstlane(wave) < 4;
+    const bool early = __builtin_amdgcn_readfirstlane(wave) < NW / 2;
     if (early) issue_dma();
     const unsigned char* hb = hbuf0 + (chunk & 1) * p.hb_bytes;
     const unsigned char* wb = wbuf0 + (s % 3) * W_BYTES;
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
 
   // ---- epilogue (same contract as igemm.hip): lane holds 4 consecutive n of pixel (py, px)
   const int flags = p.flags;
-  // dense NHWC output of element type T: stage the 256 x BN tile through LDS (the halo buffers are free now) and store
+  // dense NHWC output of element type T: stage the PT x BN tile through LDS (the halo buffers are free now) and store
   // whole pixel rows, 16 B per lane, instead of 8-byte pieces at a 256-byte stride (store-issue bound otherwise)
   const bool staged = !(flags & IG_OUT_F32) && p.c_ch == 1 && p.c_pix == p.N && (p.N % BN) == 0 && p.stage_ok;
   constexpr int PITCH = BN * (int)sizeof(T) + 16;   // bytes per staged pixel row (+16: spreads the 16 pixel rows of a fragment over banks)
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
     constexpr int CPR = BN * (int)sizeof(T) / 16;   // 16-byte chunks per staged pixel row
     T* Y = (T*)p.Y;
     const long ibase = (long)(img / p.c_grp) * p.c_grp_stride + (long)(img % p.c_grp) * p.c_img;
-    for (int q = tid; q < 256 * CPR; q += 512) {
+    for (int q = tid; q < PT * CPR; q += NT) {
       const int pl = q / CPR, ch = q - pl * CPR;
       const int oy = y0 + (pl >> p.tw_shift), ox = x0 + (pl & (p.TW - 1));
       const Chunk16 val = *(const Chunk16*)(smem + pl * PITCH + ch * 16);
@@ -290,22 +295,22 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
   if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(); p.dbg[63] = dbg_n; }
 }
 
-template <typename T, int BN, bool UPS, int ABL = 0>
+template <typename T, int BN, bool UPS, int ABL = 0, int NW = 8>
 static int launch_c3(const Conv3Dev& d, int nimg, hipStream_t stream) {
   int smem = 2 * d.hb_bytes + 3 * BN * 64;
-  const int stage = 256 * (BN * (int)sizeof(T) + 16);   // LDS-staged epilogue tile
+  const int stage = NW * 32 * (BN * (int)sizeof(T) + 16);   // LDS-staged epilogue tile
   Conv3Dev dd = d;
-  dd.stage_ok = stage <= 80 * 1024;                      // keep two workgroups per CU (fp32 x 128 channels stores directly)
+  dd.stage_ok = stage <= (NW == 8 ? 80 : 160) * 1024;        // NW = 8 keeps two workgroups per CU (fp32 x 128 channels stores directly)
   if (dd.stage_ok && smem < stage) smem = stage;
   static int attr_set = 0;
-  auto kfn = conv3x3_kernel<T, BN, UPS, ABL>;
+  auto kfn = conv3x3_kernel<T, BN, UPS, ABL, NW>;
   if (attr_set < smem) {
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = 160 * 1024;
   }
   const long blocks = (long)nimg * d.tiles_per_img * d.tiles_n;
-  hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(512), smem, stream, dd);
+  hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(NW * 64), smem, stream, dd);
   return (int)hipGetLastError();
 }
 
@@ -313,6 +318,12 @@ bool conv3x3_enabled() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("IVG_CONV3X3"); v = (e && e[0] == '0') ? 0 : 1; }
   return v == 1;
+}
+
+// Measured choice between the two tile sizes (tools/conv_bench.py, IVG_C3_NW): filled in from the sweep.
+static bool conv3x3_prefers_16(int cin, int ho, bool ups) {
+  (void)cin; (void)ho; (void)ups;
+  return false;
 }
 
 // Returns -1 when the shape is not covered (caller falls back to the generic implicit GEMM).
@@ -326,7 +337,13 @@ int launch_conv3x3(const IgemmArgs& a, DType dtype, hipStream_t stream) {
   if (a.ups ? (Ho != 2 * a.Hin || Wo != 2 * a.Win) : (Ho != a.Hin || Wo != a.Win)) return -1;
   int TW = Wo >= 32 ? 32 : Wo;   // 16x16 or 8x32 output tiles: halo <= 10 x 34 pixels = 49 KiB per buffer
   if (TW != 16 && TW != 32) return -1;
-  const int TH = 256 / TW;
+  const int bn = a.N > 64 ? 128 : 64;
+  // 16-wave / 512-pixel (16 x 32) tiles: bf16, 128-channel N tiles, images at least 16 x 32 (IVG_C3_NW=8 / 16 forces)
+  static int nw_env = -1;
+  if (nw_env < 0) { const char* e = getenv("IVG_C3_NW"); nw_env = e ? atoi(e) : 0; }
+  const bool can16 = dtype == BF16 && bn == 128 && TW == 32 && Ho % 16 == 0 && Wo % 32 == 0;
+  const bool nw16 = can16 && (nw_env == 16 || (nw_env == 0 && conv3x3_prefers_16(a.Cin, Ho, a.ups != 0)));
+  const int TH = (nw16 ? 512 : 256) / TW;
   if (Wo % TW != 0 || Ho % TH != 0) return -1;
   Conv3Dev d;
   d.X = a.X; d.W = a.W; d.Y = a.Y; d.R = a.R; d.bias = a.bias;
@@ -336,12 +353,11 @@ int launch_conv3x3(const IgemmArgs& a, DType dtype, hipStream_t stream) {
   else { d.HTH = TH + 2; d.HTW = TW + 2; }
   d.tiles_x = Wo / TW; d.tiles_per_img = d.tiles_x * (Ho / TH); d.n_sp = a.Nimg * d.tiles_per_img;
   d.N = a.N; d.ldw = a.ldw;
-  const int bn = a.N > 64 ? 128 : 64;
   d.tiles_n = cdiv(a.N, bn);
   d.c_img = a.c_img; d.c_pix = a.c_pix; d.c_ch = a.c_ch; d.c_grp = a.c_grp > 0 ? a.c_grp : 1; d.c_grp_stride = a.c_grp_stride;
   if (a.c_grp <= 1 && a.c_grp_stride == 0) d.c_grp_stride = a.c_img;
   d.flags = a.flags;
-  d.hb_bytes = cdiv(d.HTH * d.HTW * 4, 512) * 8192;
+  d.hb_bytes = nw16 ? cdiv(d.HTH * d.HTW * 4, 1024) * 16384 : cdiv(d.HTH * d.HTW * 4, 512) * 8192;
   {
     static long long* dbg_buf = nullptr;
     static int want = -1;
@@ -358,7 +374,7 @@ int launch_conv3x3(const IgemmArgs& a, DType dtype, hipStream_t stream) {
       }
     }
   }
-  if (2 * d.hb_bytes + 3 * bn * 64 > 80 * 1024) return -1;
+  if (2 * d.hb_bytes + 3 * bn * 64 > (nw16 ? 160 : 80) * 1024) return -1;
   if (((uintptr_t)a.X & 15) || ((uintptr_t)a.W & 15)) return -1;
   {  // development ablations of the bf16 / BN = 128 / no-upsample instance (IVG_C3_ABLATE=<mask>)
     static int abl = -1;
@@ -375,6 +391,7 @@ int launch_conv3x3(const IgemmArgs& a, DType dtype, hipStream_t stream) {
       }
     }
   }
+  if (nw16) return a.ups ? launch_c3<bf16_t, 128, true, 0, 16>(d, a.Nimg, stream) : launch_c3<bf16_t, 128, false, 0, 16>(d, a.Nimg, stream);
 #define IVG_C3(T, BNv) (a.ups ? launch_c3<T, BNv, true>(d, a.Nimg, stream) : launch_c3<T, BNv, false>(d, a.Nimg, stream))
   if (dtype == BF16) return bn == 128 ? IVG_C3(bf16_t, 128) : IVG_C3(bf16_t, 64);
   return bn == 128 ? IVG_C3(float, 128) : IVG_C3(float, 64);
