@@ -470,6 +470,7 @@ int ivg_profile_read(ivg_engine* e, int k, ivg_profile_stats* out) {
     // single launches): last ivg_generate call only; bytes = K and V rows read per launch
     out->launches = 0; out->total_ms = 0; out->total_flops = 0; out->total_bytes = 0;
     if (!e->attn_prof) return IVG_OK;
+    if (getenv("IVG_ATTN_DEBUG")) attn_debug_dump();
     const int L = e->Lmax, nl = e->cfg.num_layers, NS = IVG_ATTN_PROF_SLOTS;
     std::vector<unsigned long long> h((size_t)nl * NS * 2 * L);
     API_CK(hipMemcpy(h.data(), e->attn_prof, h.size() * 8, hipMemcpyDeviceToHost));

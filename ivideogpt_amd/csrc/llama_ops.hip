@@ -2,6 +2,7 @@
 // All step-dependent scalars (cache length, index of the token being decided) live in a device-side
 // StepState so the whole per-token kernel sequence has constant arguments and can be captured once
 // into a hipGraph and replayed for every generated token.
+#include <cstdio>
 #include <cstdlib>
 
 #include "ops.h"
@@ -352,6 +353,9 @@ template <typename T> __device__ __forceinline__ void axpy_chunk(float* of, floa
   }
 }
 
+// development (IVG_ATTN_DEBUG): wall-clock (100 MHz) phase stamps of workgroups 0 and last at cache position 640
+__device__ unsigned long long g_attn_dbg[2][8];
+
 template <typename T>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
                                                           T* __restrict__ out, const float* __restrict__ cosT,
@@ -375,6 +379,9 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int sub = tid % lpk, grp = tid / lpk;
   const int pos = state->pos;        // position of the token being fed = number of cached keys
+  const bool dbg = prof && pos == 640 && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1);
+  unsigned long long* dslot = g_attn_dbg[blockIdx.x == 0 ? 0 : 1];
+  if (dbg) { dslot[0] = t_start; dslot[1] = wall_clock64(); }
   const int n_keys = pos + 1;
   const int H = heads * hd, half = hd / 2;
   const float scale = rsqrtf((float)hd);
@@ -405,6 +412,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
     vb[(long)pos * hd + tid] = va; vb[(long)pos * hd + tid + half] = vb2;
   }
   __syncthreads();
+  if (dbg) dslot[2] = wall_clock64();
   float qf[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) qf[j] = sq[sub * VEC + j];
@@ -423,6 +431,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
 #pragma unroll
     for (int u = 0; u < UNR; ++u) cur[u] = nxt[u];
   }
+  if (dbg) dslot[3] = wall_clock64();
   if (grp == 0) {
     float d = 0.f;
 #pragma unroll
@@ -444,6 +453,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   if (lane == 0) sred[4 + wv] = sum;
   __syncthreads();
   sum = (sred[4] + sred[5]) + (sred[6] + sred[7]);
+  if (dbg) dslot[4] = wall_clock64();
   // pass C: weighted V sum; group `grp` takes keys grp, grp+gpb, ... (fixed order), the new token's v from LDS
   float of[VEC];
 #pragma unroll
@@ -458,6 +468,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
 #pragma unroll
     for (int u = 0; u < UNR; ++u) cur[u] = nxt[u];
   }
+  if (dbg) dslot[5] = wall_clock64();
   if (grp == 0) {
     const float pw = sc[pos];
 #pragma unroll
@@ -471,10 +482,21 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
     for (int g = 0; g < gpb; ++g) a += red[g * hd + tid];
     out[(long)b * H + h * hd + tid] = from_f32<T>(a / sum);
   }
+  if (dbg) dslot[6] = wall_clock64();
   if (prof && tid == 0) {
     unsigned long long* slot = prof + (size_t)((blockIdx.x * 7 + blockIdx.y) % IVG_ATTN_PROF_SLOTS) * 2 * Lmax;
     atomicMax(slot + pos, ~t_start);
     atomicMax(slot + Lmax + pos, (unsigned long long)wall_clock64());
+  }
+}
+
+void attn_debug_dump() {
+  unsigned long long h[2][8];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_attn_dbg), sizeof(h)) != hipSuccess) return;
+  for (int b = 0; b < 2; ++b) {
+    fprintf(stderr, "[attn dbg] wg %s (x10 ns since wg0 start): start %lld | pos read +%lld | rope+sync +%lld | K pass +%lld | stats +%lld | V pass +%lld | reduce+store +%lld\n", b ? "last" : "0",
+            (long long)(h[b][0] - h[0][0]), (long long)(h[b][1] - h[b][0]), (long long)(h[b][2] - h[b][1]), (long long)(h[b][3] - h[b][2]),
+            (long long)(h[b][4] - h[b][3]), (long long)(h[b][5] - h[b][4]), (long long)(h[b][6] - h[b][5]));
   }
 }
 

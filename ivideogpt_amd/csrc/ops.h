@@ -62,6 +62,7 @@ int launch_flash_prefill(const void* qkv, const void* kc, const void* vt, void* 
 // prof (nullable): [IVG_ATTN_PROF_SLOTS][Lmax starts | Lmax ends] wall-clock stamps (100 MHz) of the launch at each cache
 // position; workgroups spread over the slots so the atomics do not serialise on one address
 #define IVG_ATTN_PROF_SLOTS 32
+void attn_debug_dump();   // development: prints the phase stamps of the last profiled decode attention at position 640
 int launch_decode_attn(const void* qkv, void* kc, void* vc, void* out, const float* cosT, const float* sinT, int B, int heads, int hd,
                        int Lmax, const StepState* state, unsigned long long* prof, DType dt, hipStream_t st);
 // token decision + embedding of the decided token (+ action embedding on forced sdf slots) + state advance
