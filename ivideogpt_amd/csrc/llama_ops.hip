@@ -353,6 +353,21 @@ template <typename T> __device__ __forceinline__ void axpy_chunk(float* of, floa
   }
 }
 
+// Sum over the lpk (8 or 16) adjacent lanes that share one key row, every lane receiving the total.  DPP lane permutes
+// (VALU latency) instead of __shfl_xor (ds_bpermute: an LDS round trip per step, three or four dependent ones per key row
+// -- that latency, not HBM, was pacing the key pass).  Same pairing tree as the xor butterfly: bitwise the same sums.
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float group_sum(float d, int lpk) {
+  if (lpk >= 2) d = dpp_add<0xB1>(d);    // quad_perm [1,0,3,2]: lane ^ 1
+  if (lpk >= 4) d = dpp_add<0x4E>(d);    // quad_perm [2,3,0,1]: lane ^ 2
+  if (lpk >= 8) d = dpp_add<0x141>(d);   // row_half_mirror: lane i <-> 7 - i of its 8-lane half (the other quad's total)
+  if (lpk >= 16) d = dpp_add<0x140>(d);  // row_mirror: lane i <-> 15 - i (the other half's total)
+  for (int o = 16; o < lpk; o <<= 1) d += __shfl_xor(d, o, 64);   // head_dim > 128 (bf16): beyond a DPP row
+  return d;
+}
+
 // development (IVG_ATTN_DEBUG): wall-clock (100 MHz) phase stamps of workgroups 0 and last at cache position 640
 __device__ unsigned long long g_attn_dbg[2][8];
 
@@ -425,7 +440,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
     for (int u = 0; u < UNR; ++u) {
       const int t = t0 + u * gpb + grp;
       float d = dot_chunk<T>(qf, cur[u]);
-      for (int o = 1; o < lpk; o <<= 1) d += __shfl_xor(d, o, 64);
+      d = group_sum(d, lpk);
       if (t < pos && sub == 0) sc[t] = d * scale;
     }
 #pragma unroll
@@ -436,7 +451,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
     float d = 0.f;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) d = fmaf(qf[j], sk[sub * VEC + j], d);
-    for (int o = 1; o < lpk; o <<= 1) d += __shfl_xor(d, o, 64);
+    d = group_sum(d, lpk);
     if (sub == 0) sc[pos] = d * scale;
   }
   __syncthreads();
