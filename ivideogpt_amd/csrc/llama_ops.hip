@@ -411,15 +411,21 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
     }
   };
   Chunk16 cur[UNR], nxt[UNR];
+  // the few loads of the RoPE step go out BEFORE the first round of key rows: memory returns in order, so issued after them
+  // they (and the barrier behind them) would wait for the whole 32 KiB round
+  float rc = 0.f, rs = 0.f, q1 = 0.f, q2 = 0.f, k1 = 0.f, k2 = 0.f;
+  T va = from_f32<T>(0.f), vb2 = from_f32<T>(0.f);
+  if (tid < half) {
+    const T* row = qkv + (long)b * 3 * H + h * hd;
+    rc = cosT[(long)pos * half + tid]; rs = sinT[(long)pos * half + tid];
+    q1 = to_f32(row[tid]); q2 = to_f32(row[tid + half]);
+    k1 = to_f32(row[H + tid]); k2 = to_f32(row[H + tid + half]);
+    va = row[2 * H + tid]; vb2 = row[2 * H + tid + half];
+  }
   load_rows(cur, kb, 0);  // the first key rows are in flight while q is roped
   if (tid < half) {  // RoPE (HF rotate_half) of q and the new k; append k, v to the cache
-    const T* row = qkv + (long)b * 3 * H + h * hd;
-    const float c = cosT[(long)pos * half + tid], s = sinT[(long)pos * half + tid];
-    const float q1 = to_f32(row[tid]), q2 = to_f32(row[tid + half]);
-    const float k1 = to_f32(row[H + tid]), k2 = to_f32(row[H + tid + half]);
-    const T qa = from_f32<T>(q1 * c - q2 * s), qb = from_f32<T>(q2 * c + q1 * s);
-    const T ka = from_f32<T>(k1 * c - k2 * s), kb2 = from_f32<T>(k2 * c + k1 * s);
-    const T va = row[2 * H + tid], vb2 = row[2 * H + tid + half];
+    const T qa = from_f32<T>(q1 * rc - q2 * rs), qb = from_f32<T>(q2 * rc + q1 * rs);
+    const T ka = from_f32<T>(k1 * rc - k2 * rs), kb2 = from_f32<T>(k2 * rc + k1 * rs);
     sq[tid] = to_f32(qa); sq[tid + half] = to_f32(qb);
     sk[tid] = to_f32(ka); sk[tid + half] = to_f32(kb2);
     sv[tid] = to_f32(va); sv[tid + half] = to_f32(vb2);
