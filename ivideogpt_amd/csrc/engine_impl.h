@@ -36,7 +36,6 @@ struct Run {
   // ---- transformer (transformer.cpp)
   int prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const void* act_emb, int act_T, int ctx, bool all_slots,
               float* logits_all /* [B][L][V] or null */, float* logits_last /* [B][V] or null */, void* hidden_last);
-  int decode_step(int B, const SampleArgs& sa);
   int generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, int n_new, const float* actions, int act_T, int ctx,
                const float* uniforms, int top_k, int64_t* ids_out, float* reward_out, bool reuse_kv = false);
 

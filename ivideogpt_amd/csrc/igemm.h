@@ -61,6 +61,5 @@ struct SkinnyArgs {
   int* bump = nullptr;     // optional pair of device ints incremented once at the end (StepState advance)
 };
 int launch_skinny(const SkinnyArgs& a, DType dtype, hipStream_t stream);
-int skinny_pick_splits(int N, int K, DType dtype);
 
 }  // namespace ivg

@@ -271,11 +271,6 @@ static int launch_sk_t(const SkinnyDev& d, int MF, int FN, hipStream_t stream) {
   return (int)hipErrorInvalidValue;
 }
 
-int skinny_pick_splits(int N, int K, DType dtype) {
-  (void)N; (void)K; (void)dtype;
-  return 1;  // cross-workgroup split-K is no longer used by the engine (kept for the parity tests of the partial path)
-}
-
 int launch_skinny(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
   SkinnyDev d{a.X, a.W, a.Y, a.M, a.N, a.K, a.ldx, a.ldw, a.ldy, a.splits < 1 ? 1 : a.splits, a.flags, a.eps, a.bump, 0};
   const int kstep = (dtype == BF16) ? 32 : 16, vec = (dtype == BF16) ? 8 : 4;

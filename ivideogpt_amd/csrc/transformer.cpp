@@ -309,6 +309,11 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
           const int rc = step_body(e, st, g, Bc, nc, cs, sa, true);
           const hipError_t ce = hipStreamEndCapture(st, &graph);
           if (rc == 0 && ce == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+            if (e->graphs.size() >= 64) {   // bound the cache (a server fed ever new prompt lengths): drop all, recapture on demand
+              CK((int)hipStreamSynchronize(st));
+              for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
+              e->graphs.clear();
+            }
             e->graphs[key] = exec;
           } else {
             exec = nullptr;
