@@ -185,3 +185,27 @@ def test_npz_ingest_and_resize(tmp_path):
     np.savez(tmp_path / "b.npz", image=ep.astype(np.int64), aux1_image=ep[:, :64, :64].astype(np.int64), action=act)
     im2, _ = NPZParser(8, 64).parse(str(tmp_path / "b.npz"), "bair_robot_pushing")
     assert im2.shape == (8, 3, 64, 64)
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """profiles/r01_bench_n1.json is the line bench.py printed on the MI355X: it must carry every key of the driver's contract,
+    the roofline of the kernel with the most time per step (with PMC traffic) and the bounded host-CPU baseline."""
+    import json
+    path = os.path.join(ROOT, "profiles", "r01_bench_n1.json")
+    d = json.load(open(path))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["config"]["global_batch"] * 14 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6   # frames / s of the whole job
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["traffic"] is None or r["traffic"] > 0
+    assert all(o["kernel_ms_per_step"] <= r["kernel_ms_per_step"] for o in d.get("roofline_other", []))
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
