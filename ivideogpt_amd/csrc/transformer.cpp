@@ -6,11 +6,14 @@
 // MI355X-first differences from the reference's op sequence (token-identical):
 //   * ONE prefill + KV-cached single-token steps even in the action-conditioned mode (the reference
 //     re-prefills the whole prefix for every future frame, action_model.py:101-110);
-//   * a decode step is a fixed sequence of ~100 kernels whose step-dependent scalars live in device
-//     memory, captured once into a hipGraph and replayed for every generated token -- no host sync,
-//     no per-step Python;
-//   * decode GEMMs stream each weight matrix once (HBM-bound), split-K partials are folded into the
-//     next fused residual-add + RMSNorm kernel in a fixed order (deterministic).
+//   * a decode step is a fixed sequence of 62 kernels (sampler, 12 x [QKV GEMM with the input RMSNorm folded in, attention,
+//     o-proj + residual, gate/up GEMM with the post-attention norm + SiLU(gate)*up, down-proj + residual], lm_head with the
+//     final norm) whose step-dependent scalars live in device memory, captured once into a hipGraph and replayed for every
+//     generated token -- no host sync, no per-step Python;
+//   * decode GEMMs stream each weight matrix once; their K reduction happens inside the workgroup in a fixed order
+//     (deterministic, no partials in HBM);
+//   * the prompt pass uses the 256 x 256-tile GEMM (gemm256.hip), a vectorised RoPE + cache append and, in bf16, a one-pass
+//     causal attention kernel; step-wise callers (MBRL) keep the KV cache across calls (ivg_generate_continue).
 #include "engine_impl.h"
 
 namespace ivg {
