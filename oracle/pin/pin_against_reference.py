@@ -213,8 +213,17 @@ def pin_llama(HeadModelWithAction, name, cfg, seed, B, ctx, F, action_dim):
         assert torch.equal(out_ref, out_a), "oracle re-prefill algorithm != reference HeadModelWithAction.generate"
         assert torch.equal(out_ref, out_b), "single-prefill cached algorithm != reference"
         print(f"  action-conditioned greedy: {tuple(out_ref.shape)} tokens identical (re-prefill and cached)")
+        # teacher-forced forward of the reference head (action_model.py:154-185): action embeddings on every sdf slot
+        fw_ref = head(input_ids=out_ref, action=action).logits.float()
+        x = oraa.embed(out_ref).clone()
+        start = (L0 - 1) + torch.arange(F) * per                      # start_index, :176-178
+        x[:, start] += ae[:, ctx - 1:-1]
+        fw_ora = oraa.logits(embeds=x)
+        err = (fw_ref - fw_ora).abs().max().item()
+        print(f"  HeadModelWithAction.forward logits: max|reference - oracle| = {err:.2e}")
+        assert err < 2e-4
     save(f"llama_{name}_act.npz", config=json.dumps(cfg), seed=seed + 1, action_dim=action_dim, prompt=prompt,
-         action=action, greedy=out_ref, ctx=ctx)
+         action=action, greedy=out_ref, ctx=ctx, forward_logits_last=fw_ref[:, -2:], forward_logits_sub=fw_ref[:, ::37, ::101])
 
 
 def pin_param_counts():

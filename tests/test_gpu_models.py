@@ -136,6 +136,10 @@ def test_action_conditioned_greedy_matches_reference(name):
     n_new = g["greedy"].shape[1] - prompt.shape[1]
     out = head.generate(prompt, do_sample=False, max_new_tokens=n_new, action=action).cpu().numpy()
     assert np.array_equal(out, g["greedy"]), f"{(out != g['greedy']).sum()} tokens differ from HeadModelWithAction.generate"
+    # teacher-forced logits of the finished sequence vs the reference's HeadModelWithAction.forward (action_model.py:154-185)
+    lg = head.logits(torch.from_numpy(g["greedy"]).to(DEV), action).cpu().numpy()
+    err = max(np.abs(lg[:, -2:] - g["forward_logits_last"]).max(), np.abs(lg[:, ::37, ::101] - g["forward_logits_sub"]).max())
+    assert err < 1e-3, f"forward logits with actions: max abs err {err:.2e}"
 
 
 def test_sampled_rollout_matches_oracle_with_same_uniforms():

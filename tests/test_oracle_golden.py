@@ -64,6 +64,14 @@ def test_action_conditioned_oracle_matches_reference_vectors(name):
     a = generate_reference_algorithm(m, prompt, n_new, action_embeds=ae, ctx=ctx, sdf_token=sdf)
     b = generate_cached(m, prompt, n_new, action_embeds=ae, ctx=ctx, sdf_token=sdf)
     assert np.array_equal(a.numpy(), g["greedy"]) and np.array_equal(b.numpy(), g["greedy"])
+    # teacher-forced logits of the reference's HeadModelWithAction.forward (action_model.py:154-185) on the finished sequence
+    ids = torch.from_numpy(g["greedy"])
+    F = (ids.shape[1] + 1 - 257 * ctx) // 17
+    x = m.embed(ids).clone()
+    x[:, 257 * ctx - 1 + 17 * torch.arange(F)] += ae[:, ctx - 1:-1]
+    lg = m.logits(embeds=x).numpy()
+    err = max(np.abs(lg[:, -2:] - g["forward_logits_last"]).max(), np.abs(lg[:, ::37, ::101] - g["forward_logits_sub"]).max())
+    assert err < 2e-4, f"forward logits: max abs err {err:.2e}"
 
 
 def test_sampler_restatement_properties():
