@@ -226,6 +226,61 @@ def pin_llama(HeadModelWithAction, name, cfg, seed, B, ctx, F, action_dim):
          action=action, greedy=out_ref, ctx=ctx, forward_logits_last=fw_ref[:, -2:], forward_logits_sub=fw_ref[:, ::37, ::101])
 
 
+def pin_mbrl_step(HeadModelWithAction, name, cfg, seed, B, ctx, action_dim, n_steps=2):
+    """The per-step op sequence of the reference's MBRL rollout (mbrl/video_predictor.py:293-317), greedy so that no RNG is
+    involved: action added to the embedding of the last token (an sdf slot), ``llm.generate(inputs_embeds=..., max_new_tokens=17,
+    output_hidden_states=True)``, reward = ``reward_linear`` of the last layer's hidden state of the LAST generation step,
+    16 predicted tokens + a forced sdf appended.  Pins the oracle's ``generate_cached(..., return_last_hidden=True)`` with a
+    growing prompt (``slot0``) and writes the tokens / rewards of every step."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    print(f"[mbrl step] {name}")
+    hf_cfg = LlamaConfig(**{**cfg, "hidden_act": "silu", "tie_word_embeddings": False, "attention_bias": False,
+                            "bos_token_id": 50256, "eos_token_id": 50256})
+    V = cfg["vocab_size"]
+    g = torch.Generator().manual_seed(seed + 20)
+    sd = W.random_llama_state_dict(cfg, seed, action_dim=action_dim, reward_prediction=True)
+    llm = LlamaForCausalLM(hf_cfg).to(torch.float32).eval()
+    head = HeadModelWithAction(llm, action_dim=action_dim, prelude_tokens_num=257 * ctx - 1, tokens_num_per_dyna=16, context=ctx,
+                               segment_length=ctx + n_steps + 1, reward_prediction=True).eval()
+    head.load_state_dict(sd, strict=True)
+    ora = OL.LlamaRef(sd, cfg["num_hidden_layers"], cfg["num_attention_heads"], cfg["rms_norm_eps"], cfg["rope_theta"],
+                      cfg["max_position_embeddings"], prefix="llm.model.")
+    prompt = torch.randint(0, 8192, (B, 257 * ctx), generator=g)
+    prompt[:, -1] = V - 1
+    for c in range(1, ctx):
+        prompt[:, 257 * c - 1] = V - 2
+    actions = torch.randn(n_steps, B, action_dim, generator=g)
+    act_table = torch.zeros(B, ctx - 1 + n_steps + 1, action_dim)
+    tokens = prompt
+    step_tokens, step_rewards = [], []
+    with torch.no_grad():
+        embeds = head.get_input_embeddings(prompt)
+        for t in range(n_steps):
+            embeds = embeds.clone()
+            embeds[:, -1] += head.action_linear(actions[t])                                              # :295-296
+            res = head.llm.generate(inputs_embeds=embeds, do_sample=False, pad_token_id=50256, use_cache=True, max_new_tokens=17,
+                                    return_dict_in_generate=True, output_hidden_states=True)              # :298-308
+            pred = res.sequences[:, :-1]                                                                  # :310
+            reward = head.reward_linear(res.hidden_states[-1][-1]).squeeze(-2)                            # :311-313
+            cat = torch.cat([pred, torch.full((B, 1), V - 1, dtype=pred.dtype)], 1)
+            embeds = torch.cat([embeds, head.get_input_embeddings(cat)], 1)                               # :315-316
+            # oracle: same step on token ids + the action table the engine's callers keep
+            act_table[:, ctx - 1 + t] = actions[t]
+            ae = torch.nn.functional.linear(act_table, sd["action_linear.weight"], sd["action_linear.bias"])
+            out, hid = OL.generate_cached(ora, tokens, 17, uniforms=None, action_embeds=ae, ctx=ctx, sdf_token=V - 1,
+                                          return_last_hidden=True)
+            r_ora = torch.nn.functional.linear(hid, sd["reward_linear.weight"], sd["reward_linear.bias"])
+            assert torch.equal(out[:, tokens.shape[1]:tokens.shape[1] + 16], pred), f"step {t}: tokens differ from the reference"
+            err = (r_ora - reward).abs().max().item()
+            print(f"  step {t}: 16 tokens identical, reward max|reference - oracle| = {err:.2e}")
+            assert err < 1e-4
+            tokens = torch.cat([tokens, pred, torch.full((B, 1), V - 1, dtype=tokens.dtype)], 1)
+            step_tokens.append(pred)
+            step_rewards.append(reward.reshape(B))
+    save(f"llama_{name}_mbrl.npz", config=json.dumps(cfg), seed=seed, action_dim=action_dim, ctx=ctx, prompt=prompt,
+         actions=actions, step_tokens=torch.stack(step_tokens), step_rewards=torch.stack(step_rewards))
+
+
 def pin_param_counts():
     n64 = W.count_params(W.tokenizer_param_shapes(W.CTX_VAE64))
     n256 = W.count_params(W.tokenizer_param_shapes(W.CTX_VAE256))
@@ -253,6 +308,7 @@ def main():
                 vocab_size=16386)
     pin_llama(HeadModelWithAction, "tiny_ctx2", tiny, seed=21, B=2, ctx=2, F=3, action_dim=4)
     pin_llama(HeadModelWithAction, "tiny_ctx1", tiny, seed=23, B=3, ctx=1, F=4, action_dim=7)
+    pin_mbrl_step(HeadModelWithAction, "tiny_ctx2", tiny, seed=31, B=2, ctx=2, action_dim=4, n_steps=3)
     print("all pins passed")
 
 

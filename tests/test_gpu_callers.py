@@ -194,3 +194,31 @@ def test_stepwise_rollout_with_kept_kv_cache_equals_re_prefill():
     with pytest.raises(AssertionError):                            # other batch size
         head.generate(torch.cat([prompt0, b[0][:, 514:530], sdf.cpu()], 1)[:3].to(DEV), do_sample=False, max_new_tokens=17,
                       action=act[:3], reuse_cache=True)
+
+
+@pytest.mark.parametrize("reuse", [False, True])
+def test_mbrl_step_matches_reference_vectors(reuse):
+    """The engine, step by step, against the REFERENCE's own per-step outputs (tests/golden/llama_tiny_ctx2_mbrl.npz: HF
+    ``generate(inputs_embeds, max_new_tokens=17, output_hidden_states=True)`` + ``reward_linear``, mbrl/video_predictor.py:293-317):
+    same 16 tokens per step, reward within 1e-3 -- with the prompt re-prefilled every step and with the KV cache kept."""
+    from helpers import llama_fixture
+    from ivideogpt_amd import HeadModelWithAction, LlamaForCausalLM, weights as W
+    cfg, _, g = llama_fixture("llama_tiny_ctx2_mbrl.npz")
+    adim, ctx, V = int(g["action_dim"]), int(g["ctx"]), cfg["vocab_size"]
+    sd = W.random_llama_state_dict(cfg, int(g["seed"]), action_dim=adim, reward_prediction=True)
+    actions = torch.from_numpy(g["actions"])
+    n_steps, B = actions.shape[0], g["prompt"].shape[0]
+    head = HeadModelWithAction(LlamaForCausalLM(cfg, None, dtype="fp32"), adim, 257 * ctx - 1, 16, ctx, ctx + n_steps + 1,
+                               reward_prediction=True)
+    head.load_state_dict(sd, strict=True)
+    head.to(DEV)
+    tokens = torch.from_numpy(g["prompt"]).to(DEV)
+    table = torch.zeros(B, ctx - 1 + n_steps + 1, adim, device=DEV)
+    sdf = torch.full((B, 1), V - 1, dtype=torch.int64, device=DEV)
+    for t in range(n_steps):
+        table[:, ctx - 1 + t] = actions[t].to(DEV)
+        out, r = head.generate(tokens, do_sample=False, max_new_tokens=17, action=table, return_reward=True, reuse_cache=reuse and t > 0)
+        pred = out[:, tokens.shape[1]:tokens.shape[1] + 16]
+        assert np.array_equal(pred.cpu().numpy(), g["step_tokens"][t]), f"step {t}: tokens differ from the reference"
+        assert np.abs(r.cpu().numpy() - g["step_rewards"][t]).max() < 1e-3, f"step {t}: reward differs from the reference"
+        tokens = torch.cat([tokens, pred, sdf], 1)

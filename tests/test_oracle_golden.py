@@ -74,6 +74,31 @@ def test_action_conditioned_oracle_matches_reference_vectors(name):
     assert err < 2e-4, f"forward logits: max abs err {err:.2e}"
 
 
+def test_mbrl_step_oracle_matches_reference_vectors():
+    """mbrl/video_predictor.py:293-317 run step by step with HF generate(inputs_embeds, output_hidden_states) + reward_linear
+    (oracle/pin/pin_against_reference.py: pin_mbrl_step): the oracle's growing-prompt generate gives the same 16 tokens per step
+    and the same reward (hidden state of the LAST generation step)."""
+    from oracle.llama import generate_cached
+    cfg, _, g = llama_fixture("llama_tiny_ctx2_mbrl.npz")
+    import ivideogpt_amd.weights as W
+    sd = W.random_llama_state_dict(cfg, int(g["seed"]), action_dim=int(g["action_dim"]), reward_prediction=True)
+    m = oracle_llama(cfg, sd, prefix="llm.model.")
+    ctx, V = int(g["ctx"]), cfg["vocab_size"]
+    tokens = torch.from_numpy(g["prompt"])
+    actions = torch.from_numpy(g["actions"])
+    n_steps, B = actions.shape[0], tokens.shape[0]
+    table = torch.zeros(B, ctx - 1 + n_steps + 1, actions.shape[-1])
+    for t in range(n_steps):
+        table[:, ctx - 1 + t] = actions[t]
+        ae = torch.nn.functional.linear(table, sd["action_linear.weight"], sd["action_linear.bias"])
+        out, hid = generate_cached(m, tokens, 17, uniforms=None, action_embeds=ae, ctx=ctx, sdf_token=V - 1, return_last_hidden=True)
+        pred = out[:, tokens.shape[1]:tokens.shape[1] + 16]
+        assert np.array_equal(pred.numpy(), g["step_tokens"][t])
+        r = torch.nn.functional.linear(hid, sd["reward_linear.weight"], sd["reward_linear.bias"]).reshape(B)
+        assert np.abs(r.numpy() - g["step_rewards"][t]).max() < 1e-4
+        tokens = torch.cat([tokens, pred, torch.full((B, 1), V - 1, dtype=tokens.dtype)], 1)
+
+
 def test_sampler_restatement_properties():
     """explicit-uniform top-k sampler: greedy == argmax; u->0 picks the lowest kept id; only kept ids drawn."""
     from oracle.llama import sample_from_logits
