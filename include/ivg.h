@@ -12,7 +12,7 @@
  *   - all data pointers are DEVICE pointers owned by the caller (e.g. torch tensor data_ptr()); the engine borrows
  *     them for the duration of the call; weight tensors passed to ivg_create must stay alive until ivg_destroy;
  *   - work is enqueued on the caller's HIP stream and is asynchronous; no host synchronisation inside, except
- *     ivg_create / ivg_destroy / ivg_profile_read;
+ *     ivg_create / ivg_destroy / ivg_profile_read and the kept-cache verification of ivg_generate_continue / ivg_generate_embeds;
  *   - an engine is bound to one device and is not thread-safe (one engine per process per GPU);
  *   - token ids are int64, pixels are float32 or bfloat16 planar (B, T, 3, H, W) in [0, 1].
  */
@@ -129,9 +129,32 @@ int ivg_generate(ivg_engine* e, const int64_t* prompt, int64_t prompt_stride, in
  * tokens of the previous step): same contract as ivg_generate with actions != NULL, but the engine's KV cache is taken to
  * hold positions [0, L0 - 1) of these B trajectories from the previous ivg_generate / ivg_generate_continue call, so only
  * the prompt's last token (the sdf slot that receives the new action) is fed before the 16 + 1 new tokens -- no prefill.
- * Returns IVG_ERR_INVALID when the cache does not hold exactly that (other batch, other length, cache never filled). */
+ * Returns IVG_ERR_INVALID when the cache does not hold exactly that: other batch, other length, cache never filled, or built from
+ * other tokens / actions (the cached prefix is compared with the prompt on the device: one stream synchronisation). */
 int ivg_generate_continue(ivg_engine* e, const int64_t* prompt, int64_t prompt_stride, int B, int L0, int n_new, const float* actions,
                           int act_T, int ctx, const float* uniforms, int top_k, int64_t* ids_out, float* reward_out, ivg_stream stream);
+
+/* Embeds-level boundary of the step-wise caller (mbrl/video_predictor.py:286-317 runs these five ops per environment step).
+ *
+ * ivg_embed_tokens      HeadModelWithAction.get_input_embeddings (action_model.py:47-54): out[b][l][:] = embed_tokens[ids[b][l]],
+ *                       out (B, L, hidden) in the engine's llm dtype.
+ * ivg_action_linear     action_linear (action_model.py:36): out[r][:] = W a[r] + b, actions float32 (rows, action_dim),
+ *                       out (rows, hidden) llm dtype.
+ * ivg_generate_embeds   llm.generate(inputs_embeds=..., max_new_tokens, return_dict_in_generate=True, output_hidden_states=True)
+ *                       (mbrl/video_predictor.py:298-313): embeds (B, L0, hidden) llm dtype; every new token is sampled (uniforms
+ *                       (B, n_new) or NULL = greedy); new_ids_out int64 (B, n_new) = result.sequences (the inputs_embeds form of HF
+ *                       generate returns only the new tokens); hidden_out (B, hidden) llm dtype or NULL = result.hidden_states[-1][-1],
+ *                       the post-final-norm hidden state of the LAST forward pass (the one that produced the logits of new token n_new).
+ *                       allow_reuse != 0: when the KV cache of the previous call on this engine was built from exactly
+ *                       embeds[:, :L0 - 1] (verified on the device against a kept copy of the fed inputs -- one stream
+ *                       synchronisation), only the last row is fed instead of a prefill of the grown prompt; *reused_out says which.
+ * ivg_reward_linear     reward_linear (action_model.py:41; mbrl/video_predictor.py:313) on post-norm hidden rows (rows, hidden) llm
+ *                       dtype -> float32 (rows). */
+int ivg_embed_tokens(ivg_engine* e, const int64_t* ids, int64_t ids_stride, int B, int L, void* out, ivg_stream stream);
+int ivg_action_linear(ivg_engine* e, const float* actions, int rows, void* out, ivg_stream stream);
+int ivg_generate_embeds(ivg_engine* e, const void* embeds, int B, int L0, int n_new, const float* uniforms, int top_k, int64_t* new_ids_out,
+                        void* hidden_out, int allow_reuse, int* reused_out, ivg_stream stream);
+int ivg_reward_linear(ivg_engine* e, const void* hidden, int rows, float* out, ivg_stream stream);
 
 /* Teacher-forced logits (LlamaForCausalLM.forward / HeadModelWithAction.forward, action_model.py:154-185):
  * ids int64 (B, L); actions as above or NULL (added on every sdf slot 257*ctx - 1 + 17*i < L); logits_out float32 (B, L, vocab). */

@@ -66,6 +66,11 @@ EXPORTS = {
                                C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ivg_generate_continue": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                         C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ivg_embed_tokens": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "ivg_action_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "ivg_generate_embeds": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_int, C.POINTER(C.c_int), C.c_void_p]),
+    "ivg_reward_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "ivg_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ivg_profile_enable": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ivg_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(IvgProfileStats)]),

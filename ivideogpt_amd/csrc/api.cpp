@@ -165,7 +165,9 @@ int build_transformer(ivg_engine* e) {
   if (c.reward_head) {
     e->rew_w = L.f32("llm.reward_linear.weight", H);
     e->rew_b = L.f32("llm.reward_linear.bias", 1);
+    if (e->wmap.count("llm.reward_linear.raw")) e->rew_w_raw = L.f32("llm.reward_linear.raw", H);
   }
+  if (e->wmap.count("llm.norm")) e->final_norm = L.f32("llm.norm", H);   // optional: only the hidden-state outputs need it
   return L.ok ? 0 : IVG_ERR_MISSING;
 }
 
@@ -270,6 +272,8 @@ void ivg_destroy(ivg_engine* e) {
   if (e->gen_buf) (void)hipFree(e->gen_buf);
   if (e->ones) (void)hipFree(e->ones);
   if (e->attn_prof) (void)hipFree(e->attn_prof);
+  if (e->emb_snap) (void)hipFree(e->emb_snap);
+  if (e->h_flag) (void)hipHostFree(e->h_flag);
   delete e;
 }
 
@@ -375,15 +379,27 @@ int ivg_detokenize(ivg_engine* e, const int64_t* ids, int B, int F, float* pixel
 int ivg_cache_create(ivg_engine* e, int B, ivg_cache** out) {
   if (!e || !out || e->cfg.n_levels <= 0) return IVG_ERR_INVALID;
   const ivg_config& c = e->cfg;
+  if (B <= 0 || B > c.max_batch) return e->fail(IVG_ERR_CAPACITY, "cache_create: batch " + std::to_string(B) + " exceeds the engine's max_batch");
   ivg_cache* k = new ivg_cache();
   k->B = B;
   const int ctx = c.context_length, res = c.resolution, nl = c.n_levels;
-  if (hipMalloc((void**)&k->ctx_pixels, (size_t)B * ctx * 3 * res * res * 4) != hipSuccess) { delete k; return e->fail(IVG_ERR_HIP, "hipMalloc failed"); }
+  bool ok = hipMalloc((void**)&k->ctx_pixels, (size_t)B * ctx * 3 * res * res * 4) == hipSuccess;
   // same order as decoder_feature_plan: [1] then every up level whose side <= max_att
-  auto add = [&](int side, int C) { void* p = nullptr; if (hipMalloc(&p, (size_t)B * ctx * side * side * C * dtype_size(e->dec_dt)) == hipSuccess) k->feat.push_back(p); };
+  auto add = [&](int side, int C) {
+    void* p = nullptr;
+    if (ok && hipMalloc(&p, (size_t)B * ctx * side * side * C * dtype_size(e->dec_dt)) == hipSuccess) k->feat.push_back(p);
+    else ok = false;
+  };
   add(16, c.block_out_channels[nl - 1]);
   int s = 16;
   for (int i = 0; i < nl; ++i) { if (i != nl - 1) s *= 2; if (s <= c.max_att_resolution) add(s, c.block_out_channels[nl - 1 - i]); }
+  if (!ok) {   // a partial cache would be overrun by the feature writes of detokenize: release everything
+    (void)hipGetLastError();
+    if (k->ctx_pixels) (void)hipFree(k->ctx_pixels);
+    for (void* p : k->feat) (void)hipFree(p);
+    delete k;
+    return e->fail(IVG_ERR_HIP, "cache_create: hipMalloc failed");
+  }
   *out = k;
   return IVG_OK;
 }
@@ -426,8 +442,55 @@ int ivg_generate_continue(ivg_engine* e, const int64_t* prompt, int64_t prompt_s
   if (e->kv_B != B || e->kv_len != L0 - 1)
     return e->fail(IVG_ERR_INVALID, "generate_continue: the KV cache holds " + std::to_string(e->kv_len) + " positions of " + std::to_string(e->kv_B) +
                                         " trajectories, the call needs " + std::to_string(L0 - 1) + " of " + std::to_string(B));
+  {  // same (batch, length) is not enough: another caller may have used the model in between.  Compare the cached prefix
+     // (token ids + the action rows baked into its sdf slots) with the prompt on the device (one stream synchronisation).
+    bool same = false;
+    IVG_TRY(kv_prefix_matches_ids(e, prompt, prompt_stride, B, L0, actions, act_T, ctx, (hipStream_t)stream, &same));
+    if (!same) return e->fail(IVG_ERR_INVALID, "generate_continue: the KV cache was built from a different prefix (tokens or actions differ)");
+  }
   return plan_then_run(e, (hipStream_t)stream, [&](Run& r) {
     return r.generate(prompt, prompt_stride, B, L0, n_new, actions, act_T, ctx, uniforms, top_k, ids_out, reward_out, true); });
+}
+
+int ivg_generate_embeds(ivg_engine* e, const void* embeds, int B, int L0, int n_new, const float* uniforms, int top_k, int64_t* new_ids_out,
+                        void* hidden_out, int allow_reuse, int* reused_out, ivg_stream stream) {
+  if (!e) return IVG_ERR_INVALID;
+  if (reused_out) *reused_out = 0;
+  if (e->cfg.num_layers <= 0) return e->fail(IVG_ERR_INVALID, "generate: engine was created without a transformer");
+  if (!embeds || !new_ids_out) return e->fail(IVG_ERR_INVALID, "generate_embeds: null argument");
+  if (B <= 0 || B > std::min(e->cfg.max_batch, 128) || n_new < 1 || L0 < 1 || L0 + n_new > e->Lmax)
+    return e->fail(IVG_ERR_CAPACITY, "generate_embeds: batch " + std::to_string(B) + " / sequence of " + std::to_string(L0 + n_new) +
+                                         " tokens exceeds the capacity (" + std::to_string(std::min(e->cfg.max_batch, 128)) + " x " + std::to_string(e->Lmax) + ")");
+  bool reuse = false;
+  if (allow_reuse && L0 >= 2) IVG_TRY(kv_prefix_matches_embeds(e, embeds, B, L0, (hipStream_t)stream, &reuse));
+  if (reused_out) *reused_out = reuse ? 1 : 0;
+  return plan_then_run(e, (hipStream_t)stream, [&](Run& r) {
+    return r.generate(nullptr, 0, B, L0, n_new, nullptr, 0, 1, uniforms, top_k, nullptr, nullptr, reuse, embeds, new_ids_out, hidden_out); });
+}
+
+int ivg_embed_tokens(ivg_engine* e, const int64_t* ids, int64_t ids_stride, int B, int L, void* out, ivg_stream stream) {
+  if (!e) return IVG_ERR_INVALID;
+  if (e->cfg.num_layers <= 0 || !e->embed) return e->fail(IVG_ERR_INVALID, "embed_tokens: engine was created without a transformer");
+  if (B <= 0 || L <= 0) return IVG_OK;
+  if (launch_embed(ids, ids_stride, e->embed, out, e->llm_dt, B, L, e->cfg.hidden_size, e->cfg.vocab_size, (hipStream_t)stream))
+    return e->fail(IVG_ERR_HIP, "embed_tokens: launch failed");
+  return IVG_OK;
+}
+
+int ivg_action_linear(ivg_engine* e, const float* actions, int rows, void* out, ivg_stream stream) {
+  if (!e) return IVG_ERR_INVALID;
+  if (e->cfg.action_dim <= 0 || !e->act_w) return e->fail(IVG_ERR_INVALID, "action_linear: the model is action-free");
+  if (launch_action_embed(actions, e->act_w, e->act_b, out, e->llm_dt, rows, e->cfg.action_dim, e->cfg.hidden_size, (hipStream_t)stream))
+    return e->fail(IVG_ERR_HIP, "action_linear: launch failed");
+  return IVG_OK;
+}
+
+int ivg_reward_linear(ivg_engine* e, const void* hidden, int rows, float* out, ivg_stream stream) {
+  if (!e) return IVG_ERR_INVALID;
+  if (!e->rew_w_raw || !e->rew_b) return e->fail(IVG_ERR_MISSING, "reward_linear: the model has no reward head");
+  if (launch_rowdot(hidden, e->rew_w_raw, e->rew_b, out, rows, e->cfg.hidden_size, -1.0f, e->llm_dt, (hipStream_t)stream))
+    return e->fail(IVG_ERR_HIP, "reward_linear: launch failed");
+  return IVG_OK;
 }
 
 int ivg_logits(ivg_engine* e, const int64_t* ids, int B, int L, const float* actions, int act_T, int ctx, float* logits_out, ivg_stream stream) {

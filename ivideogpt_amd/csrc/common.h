@@ -52,4 +52,15 @@ __device__ __forceinline__ float wave_max(float v) {
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// One-time per-DEVICE guard for hipFuncSetAttribute (the attribute is per device; a process may hold engines on several GPUs):
+// true the first time it is called for `mask` on the current device.
+static inline bool first_time_on_device(unsigned long long& mask) {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  const unsigned long long bit = 1ull << (d & 63);
+  if (mask & bit) return false;
+  mask |= bit;
+  return true;
+}
+
 }  // namespace ivg

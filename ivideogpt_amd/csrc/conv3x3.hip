@@ -302,12 +302,11 @@ static int launch_c3(const Conv3Dev& d, int nimg, hipStream_t stream) {
   Conv3Dev dd = d;
   dd.stage_ok = stage <= (NW == 8 ? 80 : 160) * 1024;        // NW = 8 keeps two workgroups per CU (fp32 x 128 channels stores directly)
   if (dd.stage_ok && smem < stage) smem = stage;
-  static int attr_set = 0;
+  static unsigned long long attr_set = 0;
   auto kfn = conv3x3_kernel<T, BN, UPS, ABL, NW>;
-  if (attr_set < smem) {
+  if (first_time_on_device(attr_set)) {
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    attr_set = 160 * 1024;
   }
   const long blocks = (long)nimg * d.tiles_per_img * d.tiles_n;
   hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(NW * 64), smem, stream, dd);

@@ -1,0 +1,378 @@
+// Decode-step GEMM, second generation (SURVEY.md 2.4 K14/K17 at L = 1):  Y[m][n] = epi( sum_k X[m][k] * W[n][k] ),  M <= 128.
+//
+// What the round-2 micro-benchmarks (tools/ubench/decode_ubench.hip, profiles/r02_decode_ubench.txt) showed about the
+// first-generation kernel (skinny.hip): it pulled the ACTIVATION rows in MFMA-fragment shape -- 16 rows x 64 bytes per
+// wave instruction, half a cache line per row -- and that shape runs at 12-16 B/clk/CU out of L2, while whole 128-byte
+// lines run at 25-49 B/clk/CU (3x).  The activations are 60 % of the bytes a workgroup ingests, so here:
+//   * activations arrive by LDS-DMA (global_load_lds, 16 B per lane) as WHOLE LINES: 8 consecutive lanes fetch the 8 chunks
+//     of one line; the chunk order inside the line is permuted on the SOURCE side (chunk ^ ((row >> 1) & 7)) so that the
+//     lane-linear LDS image [16 rows][8 chunks] is read back as MFMA fragments by conflict-free ds_read_b128;
+//   * the staging area is private to a wave (its K slice of the rows): no workgroup barrier before the MFMAs;
+//   * weights stream once from HBM straight into registers with non-temporal loads (fragment-shaped is fine there: HBM, not
+//     the L2 path, bounds them), every load of a burst in flight before the first wait;
+//   * the residual rows the epilogue updates are requested at kernel start instead of after the K reduction.
+// Waves split K (fixed partition per (K, dtype): a trajectory's result does not depend on its batch-mates), combine
+// through LDS in a fixed order; epilogues as in skinny.hip: RMSNorm row scale (weight folded into W), residual, SiLU(gate)*up,
+// step-counter advance.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+#include "igemm.h"
+
+namespace ivg {
+
+struct DgDev {
+  const void* X; const void* W; void* Y;
+  int M, N, K, ldx, ldw, ldy, flags;
+  float eps;
+  int* bump;
+  int nburst;   // bursts of 8 * LG chunks per wave
+};
+
+__device__ __forceinline__ void dg_dma16(const void* gsrc, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <typename T> struct Vec4T;
+template <> struct Vec4T<bf16_t> { typedef bf16x4 type; };
+template <> struct Vec4T<float> { typedef f32x4 type; };
+
+// MF: 16-row tiles of X per workgroup, FN: 16-row tiles of W, LG: 128-byte lines per row per burst, WMAX: launch bound (waves)
+template <typename T, int MF, int FN, int LG, int WMAX>
+__global__ __launch_bounds__(WMAX * 64) void dgemm_kernel(const DgDev p) {
+  constexpr int KS = 2 * LG;                       // MFMA K-steps per burst (4 chunks = 64 bytes of a row each)
+  constexpr int NFRAG = FN * MF;
+  constexpr bool PREFETCH_RES = NFRAG <= 4;
+  typedef typename Vec4T<T>::type V4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, waves = (int)blockDim.x >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int n_tile = blockIdx.x * 16 * FN, m_tile = blockIdx.y * 16 * MF;
+  unsigned char* stage = smem + (size_t)wave * (LG * MF * 2048);
+  const long cbeg = (long)wave * p.nburst * (8 * LG);   // first 16-byte chunk (along K) of this wave
+  const char* X = (const char*)p.X;
+  const char* W = (const char*)p.W;
+  const bool glu = p.flags & IG_GLU;
+  const bool do_norm = p.flags & SK_NORM;
+
+  // ---- residual rows of the fragments this wave will finalise: requested now, consumed after the K reduction
+  V4 res[PREFETCH_RES ? NFRAG : 1];
+  if constexpr (PREFETCH_RES) {
+    if ((p.flags & IG_RESIDUAL) && !(p.flags & IG_OUT_F32)) {
+#pragma unroll
+      for (int i = 0; i < NFRAG; ++i) {
+        const int f = wave + i * waves;
+        if (f < NFRAG) {
+          const int a = f / MF, b = f - a * MF;
+          const int m = m_tile + b * 16 + lr, n0 = n_tile + a * 16 + lg * 4;
+          if (m < p.M && n0 + 3 < p.N) res[i] = *(const V4*)((const T*)p.Y + (long)m * p.ldy + n0);
+        }
+      }
+    }
+  }
+
+  // ---- per-lane source addresses
+  const int r8 = lane >> 3, jj = lane & 7;
+  long xrow[MF][2];
+  int xsw[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int r = h * 8 + r8;
+    xsw[h] = jj ^ ((r >> 1) & 7);
+#pragma unroll
+    for (int b = 0; b < MF; ++b) {
+      const int m = min(m_tile + b * 16 + r, p.M - 1);
+      xrow[b][h] = (long)m * p.ldx * (long)sizeof(T);
+    }
+  }
+  long wrow[FN];
+#pragma unroll
+  for (int a = 0; a < FN; ++a) {
+    const int n = min(n_tile + a * 16 + lr, p.N - 1);
+    wrow[a] = (long)n * p.ldw * (long)sizeof(T) + lg * 16;
+  }
+
+  f32x4 acc[FN][MF];
+#pragma unroll
+  for (int a = 0; a < FN; ++a)
+#pragma unroll
+    for (int b = 0; b < MF; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float ssq[MF];
+#pragma unroll
+  for (int b = 0; b < MF; ++b) ssq[b] = 0.f;
+
+  for (int burst = 0; burst < p.nburst; ++burst) {
+    const long c0 = cbeg + (long)burst * (8 * LG);
+    if (burst) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the previous burst's fragment reads have left the staging area
+    // activations: whole lines by LDS-DMA (2 instructions per 16 rows x 128 bytes)
+#pragma unroll
+    for (int g = 0; g < LG; ++g)
+#pragma unroll
+      for (int b = 0; b < MF; ++b)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          dg_dma16(X + xrow[b][h] + (c0 + g * 8 + xsw[h]) * 16, stage + ((g * MF + b) * 2 + h) * 1024);
+    asm volatile("" ::: "memory");   // the weight loads below stay BEHIND the DMA issue (the counted wait relies on that order)
+    // weights: every chunk of the burst in flight
+    Chunk16 wv[KS][FN];
+#pragma unroll
+    for (int t = 0; t < KS; ++t)
+#pragma unroll
+      for (int a = 0; a < FN; ++a) wv[t][a] = __builtin_nontemporal_load((const Chunk16*)(W + wrow[a] + (c0 + 4 * t) * 16));
+    // the DMA lines were issued first and memory returns in order: they have landed once at most KS * FN loads are outstanding
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KS * FN) : "memory");
+    Chunk16 xa[KS][MF];
+#pragma unroll
+    for (int t = 0; t < KS; ++t)
+#pragma unroll
+      for (int b = 0; b < MF; ++b) {
+        const int j = (t & 1) * 4 + lg;   // chunk of the line; line g = t >> 1
+        xa[t][b] = *(const Chunk16*)(stage + (((t >> 1) * MF + b) * 128 + lr * 8 + (j ^ ((lr >> 1) & 7))) * 16);
+      }
+    if (do_norm) {
+#pragma unroll
+      for (int t = 0; t < KS; ++t)
+#pragma unroll
+        for (int b = 0; b < MF; ++b) {
+          if constexpr (sizeof(T) == 2) {
+            const bf16x8 xx = __builtin_bit_cast(bf16x8, xa[t][b]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const float f = (float)xx[u]; ssq[b] = fmaf(f, f, ssq[b]); }
+          } else {
+            const f32x4 xx = __builtin_bit_cast(f32x4, xa[t][b]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ssq[b] = fmaf(xx[u], xx[u], ssq[b]);
+          }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < KS; ++t)
+#pragma unroll
+      for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int b = 0; b < MF; ++b) {
+          if constexpr (sizeof(T) == 2) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[t][a]),
+                                                                __builtin_bit_cast(bf16x8, xa[t][b]), acc[a][b], 0, 0, 0);
+          } else {
+            const f32x4 wf = __builtin_bit_cast(f32x4, wv[t][a]), xf = __builtin_bit_cast(f32x4, xa[t][b]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u], xf[u], acc[a][b], 0, 0, 0);
+          }
+        }
+  }
+
+  // ---- combine the waves' K slices (fixed order w = 0 .. waves-1); the combine area aliases the staging areas
+  __syncthreads();
+  f32x4* red = (f32x4*)smem;                                  // [waves][FN][MF][64 lanes]
+  float* s_ss = (float*)(red + (size_t)waves * NFRAG * 64);   // [waves][MF * 16 rows]
+#pragma unroll
+  for (int a = 0; a < FN; ++a)
+#pragma unroll
+    for (int b = 0; b < MF; ++b) red[((wave * FN + a) * MF + b) * 64 + lane] = acc[a][b];
+  if (do_norm) {
+#pragma unroll
+    for (int b = 0; b < MF; ++b) {
+      float v = ssq[b];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lg == 0) s_ss[wave * (MF * 16) + b * 16 + lr] = v;
+    }
+  }
+  __syncthreads();
+
+  const bool f32out = p.flags & IG_OUT_F32;
+#pragma unroll
+  for (int i = 0; i < NFRAG; ++i) {
+    const int f = wave + i * waves;
+    if (f >= NFRAG) break;
+    const int a = f / MF, b = f - a * MF;
+    if (glu && (a & 1)) continue;
+    f32x4 v = red[((0 * FN + a) * MF + b) * 64 + lane];
+    for (int w = 1; w < waves; ++w) v += red[((w * FN + a) * MF + b) * 64 + lane];
+    const int m = m_tile + b * 16 + lr;
+    int n0 = n_tile + a * 16 + lg * 4;
+    if (m >= p.M || n0 >= p.N) continue;
+    int nlim = p.N;
+    float rs = 1.0f;
+    if (do_norm) {
+      float tot = 0.f;
+      for (int w = 0; w < waves; ++w) tot += s_ss[w * (MF * 16) + b * 16 + lr];
+      rs = rsqrtf(tot / (float)p.K + p.eps);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] *= rs;
+    }
+    if (glu) {
+      if constexpr (FN >= 2) {
+        const int a1 = a + 1 < FN ? a + 1 : a;
+        f32x4 u = red[((0 * FN + a1) * MF + b) * 64 + lane];
+        for (int w = 1; w < waves; ++w) u += red[((w * FN + a1) * MF + b) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]) * (u[r] * rs);
+      }
+      n0 = (n_tile >> 1) + (a >> 1) * 16 + lg * 4;
+      nlim = p.N >> 1;
+    }
+    if (f32out) {
+      float* Y = (float*)p.Y + (long)m * p.ldy + n0;
+      if (n0 + 3 < nlim && ((p.ldy & 3) == 0)) *(f32x4*)Y = v;
+      else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (n0 + r < nlim) Y[r] = v[r];
+      }
+    } else {
+      T* Y = (T*)p.Y + (long)m * p.ldy + n0;
+      const bool whole = n0 + 3 < nlim;
+      if (p.flags & IG_RESIDUAL) {  // in-place residual-stream update: each element is read and written by one thread
+        if (whole) {
+          V4 o;
+          if constexpr (PREFETCH_RES) o = res[i]; else o = *(const V4*)Y;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(to_f32(o[r]) + v[r]);
+          *(V4*)Y = o;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (n0 + r < nlim) Y[r] = from_f32<T>(to_f32(Y[r]) + v[r]);
+        }
+      } else {
+        if (whole) {
+          V4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = from_f32<T>(v[r]);
+          *(V4*)Y = o;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (n0 + r < nlim) Y[r] = from_f32<T>(v[r]);
+        }
+      }
+    }
+  }
+  if (p.bump && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { p.bump[0] += 1; p.bump[1] += 1; }
+}
+
+template <typename T, int MF, int FN, int LG, int WMAX>
+static int launch_dg(const DgDev& d, int waves, hipStream_t stream) {
+  const int nfrag = FN * MF;
+  const int stage = waves * LG * MF * 2048;
+  const int comb = waves * nfrag * 64 * 16 + waves * MF * 16 * 4;
+  const int smem = std::max(stage, comb);
+  if (smem > 160 * 1024 || waves > WMAX) return -1;
+  static unsigned long long attr_set = 0;
+  auto kfn = dgemm_kernel<T, MF, FN, LG, WMAX>;
+  if (first_time_on_device(attr_set)) {
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+  }
+  dim3 grid((unsigned)cdiv(d.N, 16 * FN), (unsigned)cdiv(d.M, 16 * MF), 1);
+  hipLaunchKernelGGL(kfn, grid, dim3(waves * 64), smem, stream, d);
+  return (int)hipGetLastError();
+}
+
+// K partition: a function of (K in bytes) only -- never of the batch -- so a row's sum order does not depend on its batch-mates.
+// chunks = K * sizeof(T) / 16;  waves * nburst * 8 * LG = chunks.
+struct DgSplit { int waves, lg, nburst; };
+static bool dg_split(long chunks, DgSplit& s) {
+  if (chunks <= 0 || chunks % 8 != 0) return false;
+  const long lines = chunks / 8;   // 128-byte lines per row
+  // preference: bursts of three lines per wave (24 chunks: all of a wave's operands in flight at once), then two, then one;
+  // as many waves as divide the K range (fewest bursts per wave)
+  for (int lg : {3, 2, 1}) {
+    if (lines % lg != 0) continue;
+    const long units = lines / lg;           // (wave, burst) units
+    for (int waves : {16, 12, 8, 6, 4, 2, 1}) {
+      if (units % waves != 0) continue;
+      const long nb = units / waves;
+      if (nb > 8) continue;
+      s = DgSplit{waves, lg, (int)nb};
+      return true;
+    }
+  }
+  return false;
+}
+
+static int g_dg_force[4] = {0, 0, 0, 0};   // IVG_DG_FORCE=MF,FN,WAVES,LG (tools/dgemm_sweep.py)
+
+// Measured picks (tools/dgemm_sweep.py on MI355X, profiles/r02_dgemm_sweep_*.txt) for the GEMMs of the released transformers,
+// keyed by (K bytes, N) -- never by the batch, so the K partition of a GEMM is fixed.  mf caps the row tiles per workgroup.
+struct DgPick { int kbytes, N, mf, fn, waves, lg; };
+static const DgPick kDgPicks[] = {
+    {1536, 2304, 2, 2, 4, 3},    // small: q/k/v            5.5 us per launch (first generation 6.5)
+    {1536, 768, 1, 1, 4, 3},     // small: o-proj           3.6 (4.8)
+    {1536, 6144, 4, 2, 4, 3},    // small: gate/up          7.1 (9.6)
+    {6144, 768, 1, 1, 4, 3},     // small: down             7.2 (8.9)
+    {1536, 16386, 4, 2, 2, 1},   // small: lm_head         14.3 (19.3)
+};
+
+template <typename T, int LG>
+static int launch_dg_t(const DgDev& d, int MF, int FN, int waves, hipStream_t st) {
+  // launch bound = the smallest class that holds the waves (register budget: 4 waves -> 512, 8 -> 256, 16 -> 128 per lane)
+#define IVG_DG(mf, fn) if (MF == mf && FN == fn) { \
+    if (waves <= 4) return launch_dg<T, mf, fn, LG, 4>(d, waves, st); \
+    if constexpr (mf * fn <= 8) { if (waves <= 8) return launch_dg<T, mf, fn, LG, 8>(d, waves, st); } \
+    if constexpr (mf * fn <= 2) return launch_dg<T, mf, fn, LG, 16>(d, waves, st); \
+    return -1; }
+  IVG_DG(1, 1) IVG_DG(1, 2) IVG_DG(1, 4)
+  IVG_DG(2, 1) IVG_DG(2, 2) IVG_DG(2, 4)
+  IVG_DG(4, 1) IVG_DG(4, 2) IVG_DG(4, 4)
+#undef IVG_DG
+  return -1;
+}
+
+// -1: shape not covered (caller falls back to skinny.hip); otherwise a hipError_t
+int launch_dgemm(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
+  {
+    const char* v = getenv("IVG_DG");   // IVG_DG=0: first-generation kernel only (A/B runs)
+    if ((v && v[0] == '0') || a.splits > 1) return -1;
+  }
+  const int es = dtype == BF16 ? 2 : 4;
+  if (a.M <= 0 || a.N <= 0 || a.M > 128) return -1;
+  if (((long)a.K * es) % 128 != 0 || ((long)a.ldx * es) % 16 != 0 || ((long)a.ldw * es) % 16 != 0) return -1;
+  if (((uintptr_t)a.X & 15) || ((uintptr_t)a.W & 15)) return -1;
+  const bool glu = a.flags & IG_GLU;
+  if (glu && a.N % 32 != 0) return -1;
+  if ((a.flags & IG_RESIDUAL) && !(a.flags & IG_OUT_F32) && ((a.ldy & 3) != 0 || ((uintptr_t)a.Y & (4 * es - 1)))) return -1;
+  DgSplit sp;
+  if (!dg_split((long)a.K * es / 16, sp)) return -1;
+  // tile: all rows of the batch in one workgroup when that still leaves >= ~half the CUs busy, W tiles as narrow as the
+  // epilogue allows -- activations are cheap now (whole lines out of L2), weight bytes per CU are what is left to balance
+  const int mt = cdiv(a.M, 16);
+  int MF = mt >= 4 ? 4 : (mt >= 2 ? 2 : 1);
+  int FN = glu ? 2 : 1;
+  {
+    auto wgs = [&](int mf, int fn) { return (long)cdiv(a.M, 16 * mf) * cdiv(a.N, 16 * fn); };
+    while (MF > 1 && wgs(MF, FN) < 128) MF >>= 1;                 // narrow GEMMs: split the rows to fill the chip
+    while (FN < 4 && wgs(MF, FN) > 512) FN <<= 1;                 // wide GEMMs (lm_head): fatter W tiles, fewer rounds
+    if (sp.waves * sp.lg * MF * 2048 > 160 * 1024) { while (MF > 1 && sp.waves * sp.lg * MF * 2048 > 160 * 1024) MF >>= 1; }
+  }
+  int waves = sp.waves, lgv = sp.lg, nburst = sp.nburst;
+  for (const DgPick& k : kDgPicks) {
+    if (k.kbytes != a.K * es || k.N != a.N) continue;
+    const long chunks = (long)a.K * es / 16;
+    if (chunks % ((long)k.waves * 8 * k.lg) != 0) break;
+    MF = std::min(k.mf, mt >= 4 ? 4 : (mt >= 2 ? 2 : 1));
+    FN = k.fn; waves = k.waves; lgv = k.lg;
+    nburst = (int)(chunks / ((long)waves * 8 * lgv));
+    break;
+  }
+  const char* ff = getenv("IVG_DG_FORCE");   // development: MF,FN,WAVES,LG of every launch (tools/dgemm_sweep.py)
+  const bool forced = ff && sscanf(ff, "%d,%d,%d,%d", &g_dg_force[0], &g_dg_force[1], &g_dg_force[2], &g_dg_force[3]) == 4;
+  if (forced) {
+    const long chunks = (long)a.K * es / 16;
+    MF = g_dg_force[0]; FN = g_dg_force[1]; waves = g_dg_force[2]; lgv = g_dg_force[3];
+    if (waves <= 0 || lgv <= 0 || chunks % ((long)waves * 8 * lgv) != 0) return (int)hipErrorInvalidValue;
+    nburst = (int)(chunks / ((long)waves * 8 * lgv));
+    if (glu && FN < 2) return (int)hipErrorInvalidValue;
+  }
+  DgDev d{a.X, a.W, a.Y, a.M, a.N, a.K, a.ldx, a.ldw, a.ldy, a.flags, a.eps, a.bump, nburst};
+  int rc;
+  if (dtype == BF16) rc = lgv == 3 ? launch_dg_t<bf16_t, 3>(d, MF, FN, waves, stream) : lgv == 2 ? launch_dg_t<bf16_t, 2>(d, MF, FN, waves, stream)
+                                                                                     : launch_dg_t<bf16_t, 1>(d, MF, FN, waves, stream);
+  else rc = lgv == 3 ? launch_dg_t<float, 3>(d, MF, FN, waves, stream) : lgv == 2 ? launch_dg_t<float, 2>(d, MF, FN, waves, stream)
+                                                                                 : launch_dg_t<float, 1>(d, MF, FN, waves, stream);
+  if (rc == -1 && forced) return (int)hipErrorInvalidValue;
+  return rc;
+}
+
+}  // namespace ivg

@@ -95,6 +95,16 @@ struct ivg_engine {
   unsigned long long* attn_prof = nullptr;  // [layers][IVG_ATTN_PROF_SLOTS][2][Lmax] wall-clock stamps of the decode attention
   bool attn_prof_on = false;                // ivg_profile_enable(IVG_K_DECODE_ATTN): part of the step-graph key
   int kv_len = 0, kv_B = 0;                 // the KV cache holds positions [0, kv_len) of kv_B trajectories (last generate call)
+  // what that cache was built from, kept so that a step-wise caller's "same prefix" claim can be VERIFIED on the device:
+  //   token path: the ids are in the persistent id buffer (gen_buf), the action table of the call in last_act;
+  //   embeds path (ivg_generate_embeds): the input embeddings fed so far in emb_snap
+  const float* final_norm = nullptr;        // model.norm.weight (fp32), for the hidden state handed to the caller
+  const float* rew_w_raw = nullptr;         // reward_linear.weight as stored (applies to the post-norm hidden state)
+  char* emb_snap = nullptr;                 // [Bc][Lmax][H] llm dtype, allocated on the first embeds call
+  bool snap_valid = false;                  // emb_snap holds the inputs of positions [0, kv_len)
+  bool ids_valid = false;                   // gen_buf ids hold the tokens of positions [0, kv_len)
+  int last_act_T = 0;                       // rows per trajectory of last_act (0: the cache was built without actions)
+  int* h_flag = nullptr;                    // pinned host word for the verification result
   int attn_prof_B = 0;
   double attn_fit_fixed_us = 0, attn_fit_gbps = 0;   // line fit of the last ivg_profile_read(IVG_K_DECODE_ATTN)
 

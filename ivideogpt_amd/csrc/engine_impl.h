@@ -35,9 +35,14 @@ struct Run {
 
   // ---- transformer (transformer.cpp)
   int prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const void* act_emb, int act_T, int ctx, bool all_slots,
-              float* logits_all /* [B][L][V] or null */, float* logits_last /* [B][V] or null */, void* hidden_last);
+              float* logits_all /* [B][L][V] or null */, float* logits_last /* [B][V] or null */, void* hidden_last,
+              const void* embeds = nullptr /* [B][L][H] llm dtype: used instead of the embedding of ids */,
+              void* hidden_all = nullptr /* [B][L][H] llm dtype: post-final-norm hidden states (eval heads) */);
+  // embeds != null: llm.generate(inputs_embeds=...) -- the prompt is given as input embeddings, only the n_new tokens are
+  // returned (new_ids_out [B][n_new]); hidden_out [B][H]: post-norm hidden state of the last forward pass
   int generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, int n_new, const float* actions, int act_T, int ctx,
-               const float* uniforms, int top_k, int64_t* ids_out, float* reward_out, bool reuse_kv = false);
+               const float* uniforms, int top_k, int64_t* ids_out, float* reward_out, bool reuse_kv = false,
+               const void* embeds = nullptr, int64_t* new_ids_out = nullptr, void* hidden_out = nullptr);
 
   // ---- measurement
   void prof_begin(DType dt, double flops, double bytes, int base = 0);   // base 0: igemm classes, 2: conv3x3 classes
@@ -49,5 +54,9 @@ size_t dtype_size(DType d);
 int build_tokenizer(ivg_engine* e);
 int build_transformer(ivg_engine* e);
 size_t gen_buffer_bytes(const ivg_engine* e);
+// device-side verification (one stream synchronisation) that the kept KV cache was built from this very prefix
+int kv_prefix_matches_ids(ivg_engine* e, const int64_t* prompt, int64_t prompt_stride, int B, int L0, const float* actions, int act_T,
+                          int ctx, hipStream_t st, bool* ok);
+int kv_prefix_matches_embeds(ivg_engine* e, const void* embeds, int B, int L0, hipStream_t st, bool* ok);
 
 }  // namespace ivg

@@ -177,11 +177,10 @@ int launch_gemm256(const IgemmArgs& a, DType dtype, hipStream_t stream) {
   d.tiles_n = a.N / 256;
   d.flags = a.flags;
   const int smem = 256 * G256_PITCH > G256_STAGES * G256_STAGE ? 256 * G256_PITCH : G256_STAGES * G256_STAGE;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0;
+  if (first_time_on_device(attr_set)) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
   const long tiles = (long)cdiv(M, 256) * d.tiles_n;
   hipLaunchKernelGGL(gemm256_kernel, dim3((unsigned)tiles), dim3(1024), smem, stream, d);

@@ -61,5 +61,7 @@ struct SkinnyArgs {
   int* bump = nullptr;     // optional pair of device ints incremented once at the end (StepState advance)
 };
 int launch_skinny(const SkinnyArgs& a, DType dtype, hipStream_t stream);
+// dgemm.hip: the same contract with the activations staged as whole cache lines; -1 when the shape is not covered
+int launch_dgemm(const SkinnyArgs& a, DType dtype, hipStream_t stream);
 
 }  // namespace ivg

@@ -288,12 +288,11 @@ static bool use_glds() {
 template <typename T, int BM, int BN, int WM, int WN, bool GLDS>
 static int launch_cfg2(const IgemmDev& d, int nbatch, hipStream_t stream) {
   constexpr int smem = 2 * (BM + BN) * 128;
-  static bool attr_set = false;
+  static unsigned long long attr_set = 0;
   auto kfn = igemm_kernel<T, BM, BN, WM, WN, GLDS>;
-  if (!attr_set) {
+  if (first_time_on_device(attr_set)) {
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
   const long tiles = (long)cdiv(d.M, BM) * cdiv(d.N, BN);
   dim3 grid((unsigned)tiles, (unsigned)nbatch, 1);

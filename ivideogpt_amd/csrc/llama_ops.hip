@@ -2,6 +2,7 @@
 // All step-dependent scalars (cache length, index of the token being decided) live in a device-side
 // StepState so the whole per-token kernel sequence has constant arguments and can be captured once
 // into a hipGraph and replayed for every generated token.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 
@@ -12,21 +13,23 @@ namespace ivg {
 // ------------------------------------------------------------------------------------------------ embedding
 template <typename T>
 __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ ids, long id_stride, const T* __restrict__ E,
-                                                    T* __restrict__ x, int L, int H, int V) {
+                                                    T* __restrict__ x, long x_bstride, int L, int H, int V) {
   constexpr int VEC = Traits<T>::VEC;
   const int row = blockIdx.x;  // b * L + l
   const int b = row / L, l = row - b * L;
   long id = ids[(long)b * id_stride + l];
   id = id < 0 ? 0 : (id >= V ? V - 1 : id);  // memory safety only: the mirror's callers pass ids < vocab_size
   const T* src = E + id * H;
-  T* dst = x + (long)row * H;
+  T* dst = x + (long)b * x_bstride + (long)l * H;
   for (int c = threadIdx.x * VEC; c < H; c += 256 * VEC) *(Chunk16*)(dst + c) = *(const Chunk16*)(src + c);
 }
 
-int launch_embed(const int64_t* ids, long id_stride, const void* E, void* x, DType dt, int B, int L, int H, int V, hipStream_t st) {
+int launch_embed(const int64_t* ids, long id_stride, const void* E, void* x, DType dt, int B, int L, int H, int V, hipStream_t st,
+                 long x_bstride) {
   if (B * L <= 0) return 0;
-  if (dt == BF16) hipLaunchKernelGGL(embed_kernel<bf16_t>, dim3(B * L), dim3(256), 0, st, ids, id_stride, (const bf16_t*)E, (bf16_t*)x, L, H, V);
-  else hipLaunchKernelGGL(embed_kernel<float>, dim3(B * L), dim3(256), 0, st, ids, id_stride, (const float*)E, (float*)x, L, H, V);
+  if (x_bstride <= 0) x_bstride = (long)L * H;
+  if (dt == BF16) hipLaunchKernelGGL(embed_kernel<bf16_t>, dim3(B * L), dim3(256), 0, st, ids, id_stride, (const bf16_t*)E, (bf16_t*)x, x_bstride, L, H, V);
+  else hipLaunchKernelGGL(embed_kernel<float>, dim3(B * L), dim3(256), 0, st, ids, id_stride, (const float*)E, (float*)x, x_bstride, L, H, V);
   return (int)hipGetLastError();
 }
 
@@ -371,7 +374,7 @@ __device__ __forceinline__ float group_sum(float d, int lpk) {
 // development (IVG_ATTN_DEBUG): wall-clock (100 MHz) phase stamps of workgroups 0 and last at cache position 640
 __device__ unsigned long long g_attn_dbg[2][8];
 
-template <typename T>
+template <typename T, bool NT>   // NT: non-temporal loads of the cache rows (streamed once per step: keep them from evicting the weights)
 __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
                                                           T* __restrict__ out, const float* __restrict__ cosT,
                                                           const float* __restrict__ sinT, int heads, int hd, int Lmax,
@@ -407,7 +410,8 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int t = t0 + u * gpb + grp;
-      dst[u] = t < pos ? *(const Chunk16*)(base + (long)t * hd + sub * VEC) : Chunk16{0u, 0u, 0u, 0u};
+      const Chunk16* src = (const Chunk16*)(base + (long)t * hd + sub * VEC);
+      dst[u] = t < pos ? (NT ? __builtin_nontemporal_load(src) : *src) : Chunk16{0u, 0u, 0u, 0u};
     }
   };
   Chunk16 cur[UNR], nxt[UNR];
@@ -528,11 +532,16 @@ int launch_decode_attn(const void* qkv, void* kc, void* vc, void* out, const flo
   const int gpb = 256 / (hd / vec);
   const size_t smem = (size_t)(3 * hd + Lmax + gpb * hd) * sizeof(float);
   dim3 g(B * heads);
-  if (dt == BF16)
-    hipLaunchKernelGGL(decode_attn_kernel<bf16_t>, g, dim3(256), smem, st, (const bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc, (bf16_t*)out,
+  // non-temporal cache-row loads: 5.57 -> 6.28 TB/s on a pure stream, 203 -> 191 ms per rollout (IVG_ATTN_NT=0: plain loads, A/B)
+  static const bool nt = [] { const char* v = getenv("IVG_ATTN_NT"); return !(v && v[0] == '0'); }();
+  if (dt == BF16 && nt)
+    hipLaunchKernelGGL((decode_attn_kernel<bf16_t, true>), g, dim3(256), smem, st, (const bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc, (bf16_t*)out,
+                       cosT, sinT, heads, hd, Lmax, state, prof);
+  else if (dt == BF16)
+    hipLaunchKernelGGL((decode_attn_kernel<bf16_t, false>), g, dim3(256), smem, st, (const bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc, (bf16_t*)out,
                        cosT, sinT, heads, hd, Lmax, state, prof);
   else
-    hipLaunchKernelGGL(decode_attn_kernel<float>, g, dim3(256), smem, st, (const float*)qkv, (float*)kc, (float*)vc, (float*)out, cosT,
+    hipLaunchKernelGGL((decode_attn_kernel<float, false>), g, dim3(256), smem, st, (const float*)qkv, (float*)kc, (float*)vc, (float*)out, cosT,
                        sinT, heads, hd, Lmax, state, prof);
   return (int)hipGetLastError();
 }
@@ -861,6 +870,9 @@ __global__ __launch_bounds__(256) void sample_embed_kernel(SampleArgs a) {
       }
     }
   }
+  // a row of NaN / -inf logits leaves the arg-max index at its initial value: never let it reach the id buffer or the
+  // embedding gather (out-of-bounds read inside a replayed graph); such a row decides token 0
+  if (tok < 0 || tok >= V) tok = 0;
   if (a.dbg && b == 0 && tid == 0) a.dbg[31] = dbg_n;
   if (tid == 0) a.ids_out[(long)b * a.ids_stride + a.L0 + (j - 1)] = (int64_t)tok;
   // ---- next input embedding
@@ -877,11 +889,9 @@ __global__ __launch_bounds__(256) void sample_embed_kernel(SampleArgs a) {
 
 template <typename T, int KPT>
 static void launch_sample_t(const SampleArgs& a, int B, size_t smem, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0;
+  if (first_time_on_device(attr_set))
     (void)hipFuncSetAttribute((const void*)sample_embed_kernel<T, KPT>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    attr_set = true;
-  }
   hipLaunchKernelGGL((sample_embed_kernel<T, KPT>), dim3(B), dim3(256), smem, st, a);
 }
 
@@ -948,13 +958,63 @@ __global__ __launch_bounds__(64) void rowdot_kernel(const T* __restrict__ h, con
   for (int c = threadIdx.x; c < H; c += 64) { const float v = to_f32(h[(long)b * H + c]); s = fmaf(v, w[c], s); ss = fmaf(v, v, ss); }
   s = wave_sum(s);
   ss = wave_sum(ss);
-  if (threadIdx.x == 0) out[b] = s * rsqrtf(ss / (float)H + eps) + bias[0];
+  if (threadIdx.x == 0) out[b] = (eps >= 0.f ? s * rsqrtf(ss / (float)H + eps) : s) + bias[0];   // eps < 0: h is already normed
 }
 
 int launch_rowdot(const void* h, const float* w, const float* bias, float* out, int B, int H, float eps, DType dt, hipStream_t st) {
   if (B <= 0) return 0;
   if (dt == BF16) hipLaunchKernelGGL(rowdot_kernel<bf16_t>, dim3(B), dim3(64), 0, st, (const bf16_t*)h, w, bias, out, H, eps);
   else hipLaunchKernelGGL(rowdot_kernel<float>, dim3(B), dim3(64), 0, st, (const float*)h, w, bias, out, H, eps);
+  return (int)hipGetLastError();
+}
+
+// out[b][:] = w * T(x[b][:] * rsqrt(mean x^2 + eps))  -- HF LlamaRMSNorm: the normalised row is rounded to the model dtype before
+// the weight multiplies it.  This is `hidden_states[-1]` of the last layer as HF reports it (post final norm).
+template <typename T>
+__global__ __launch_bounds__(256) void final_hidden_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ out,
+                                                           int H, float eps) {
+  __shared__ float red[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float ss = 0.f;
+  for (int c = tid; c < H; c += 256) { const float v = to_f32(x[(long)b * H + c]); ss = fmaf(v, v, ss); }
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) red[tid >> 6] = ss;
+  __syncthreads();
+  const float rs = rsqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)H + eps);
+  for (int c = tid; c < H; c += 256) {
+    const T n = from_f32<T>(to_f32(x[(long)b * H + c]) * rs);
+    out[(long)b * H + c] = from_f32<T>(to_f32(from_f32<T>(w[c])) * to_f32(n));
+  }
+}
+
+int launch_final_hidden(const void* x, const float* w, void* out, int B, int H, float eps, DType dt, hipStream_t st) {
+  if (B <= 0) return 0;
+  if (dt == BF16) hipLaunchKernelGGL(final_hidden_kernel<bf16_t>, dim3(B), dim3(256), 0, st, (const bf16_t*)x, w, (bf16_t*)out, H, eps);
+  else hipLaunchKernelGGL(final_hidden_kernel<float>, dim3(B), dim3(256), 0, st, (const float*)x, w, (float*)out, H, eps);
+  return (int)hipGetLastError();
+}
+
+// flag[0] += number of 4-byte words that differ between rows of a and b (row r at a + r * a_stride bytes; row_bytes % 4 == 0).
+// Used to verify that a kept KV cache was built from exactly the prefix a step-wise caller presents again.
+__global__ __launch_bounds__(256) void compare_rows_kernel(const unsigned* __restrict__ a, long a_stride, const unsigned* __restrict__ b,
+                                                           long b_stride, long row_words, int* __restrict__ flag) {
+  const int r = blockIdx.y;
+  const unsigned* pa = (const unsigned*)((const char*)a + (long)r * a_stride);
+  const unsigned* pb = (const unsigned*)((const char*)b + (long)r * b_stride);
+  int bad = 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < row_words; i += (long)gridDim.x * 256) bad += pa[i] != pb[i] ? 1 : 0;
+  bad = (int)wave_sum((float)bad);
+  if ((threadIdx.x & 63) == 0 && bad) atomicAdd(flag, bad);
+}
+
+int launch_compare_rows(const void* a, long a_stride_bytes, const void* b, long b_stride_bytes, int rows, long row_bytes, int* flag,
+                        hipStream_t st) {
+  if (rows <= 0 || row_bytes <= 0) return 0;
+  if (row_bytes % 4 != 0 || a_stride_bytes % 4 != 0 || b_stride_bytes % 4 != 0) return (int)hipErrorInvalidValue;
+  const long words = row_bytes / 4;
+  const unsigned gx = (unsigned)std::min<long>(64, (words + 255) / 256);
+  hipLaunchKernelGGL(compare_rows_kernel, dim3(gx, (unsigned)rows), dim3(256), 0, st, (const unsigned*)a, a_stride_bytes,
+                     (const unsigned*)b, b_stride_bytes, words, flag);
   return (int)hipGetLastError();
 }
 

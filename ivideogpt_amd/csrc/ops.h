@@ -49,7 +49,9 @@ struct StepState {  // device-resident per-generate state (so one captured step 
   int j;            // 1-based index of the NEW token being decided at this step
 };
 // x[b][:] = E[tok[b]] (+ act[b][slot][:] when add_act), T
-int launch_embed(const int64_t* ids, long id_stride, const void* E, void* x, DType dt, int B, int L, int H, int V, hipStream_t st);
+// (x_bstride: elements between the outputs of consecutive trajectories; 0 = dense [B][L][H])
+int launch_embed(const int64_t* ids, long id_stride, const void* E, void* x, DType dt, int B, int L, int H, int V, hipStream_t st,
+                 long x_bstride = 0);
 // RoPE on q,k of qkv[M][3H] (in place) and append k,v to the cache [B][heads][Lmax][hd]; position of row (b, l) = pos0 + l
 // (pos0 from *state when state != null).  vt (optional): transposed V scratch [B][heads][hd][ldvt] for the prefill P.V GEMM.
 int launch_rope_kv(void* qkv, void* kc, void* vc, void* vt, int ldvt, const float* cosT, const float* sinT, int B, int L,
@@ -85,7 +87,12 @@ int launch_state_set(StepState* state, int pos, int j, hipStream_t st);
 int launch_action_embed(const float* act, const float* W, const float* bias, void* out, DType dt, int BT, int A, int H,
                         hipStream_t st);
 int launch_add_rows(void* x, long x_stride, const void* add, long add_stride, int B, int H, DType dt, hipStream_t st);
-// r[b] = rsqrt(mean(h[b]^2) + eps) * dot(h[b], w) + bias   (reward head on the RMS-normed hidden state)
+// r[b] = rsqrt(mean(h[b]^2) + eps) * dot(h[b], w) + bias   (reward head on the RMS-normed hidden state);  eps < 0: plain dot + bias
 int launch_rowdot(const void* h, const float* w, const float* bias, float* out, int B, int H, float eps, DType dt, hipStream_t st);
+// out[b] = final RMSNorm of the residual rows x[b] as HF reports them in hidden_states[-1] (normalised row rounded to T, times w)
+int launch_final_hidden(const void* x, const float* w, void* out, int B, int H, float eps, DType dt, hipStream_t st);
+// *flag += number of differing 32-bit words between `rows` rows of row_bytes bytes (strides in bytes)
+int launch_compare_rows(const void* a, long a_stride_bytes, const void* b, long b_stride_bytes, int rows, long row_bytes, int* flag,
+                        hipStream_t st);
 
 }  // namespace ivg

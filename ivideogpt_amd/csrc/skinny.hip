@@ -196,12 +196,11 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(const SkinnyDev p) {
 template <typename T, int MF, int FN, int WAVES>
 static int launch_sk(const SkinnyDev& d, hipStream_t stream) {
   constexpr int smem = WAVES * FN * MF * 64 * 16 + WAVES * MF * 16 * 4;
-  static bool attr_set = false;
+  static unsigned long long attr_set = 0;
   auto kfn = skinny_kernel<T, MF, FN, WAVES>;
-  if (!attr_set) {
+  if (first_time_on_device(attr_set)) {
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
   SkinnyDev dd = d;
   dd.tail_split = (MF > 1 && d.M <= 16 * MF && d.splits == 1 && d.N % (16 * FN) != 0 && d.N > 16 * FN && !(d.flags & IG_GLU)) ? 1 : 0;
@@ -280,6 +279,10 @@ int launch_skinny(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
   const bool glu = a.flags & IG_GLU;
   if (glu && (a.N % 32 != 0 || d.splits != 1)) return (int)hipErrorInvalidValue;
   if ((a.flags & (SK_NORM | IG_RESIDUAL)) && d.splits != 1) return (int)hipErrorInvalidValue;
+  {  // second-generation kernel (dgemm.hip: activations as whole lines through LDS) wherever it covers the shape
+    const int rc = launch_dgemm(a, dtype, stream);
+    if (rc != -1) return rc;
+  }
   int MF, FN;
   pick_tile(a.M, a.N, a.K, glu, MF, FN);
   g_force_waves = 0;

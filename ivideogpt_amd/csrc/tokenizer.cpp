@@ -453,6 +453,8 @@ int Run::detokenize(const int64_t* ids, int B, int F, float* out_pixels, ivg_cac
   decoder_feature_plan(c, feats);
   const bool use_cache = cache && cache_mode == 2;
   if (use_cache && (!cache->filled || cache->B != B)) return e->fail(IVG_ERR_INVALID, "detokenize: cache is empty or was made for another batch size");
+  if (cache && cache_mode == 1 && cache->B != B)   // the fill writes B trajectories of features / pixels into buffers sized for cache->B
+    return e->fail(IVG_ERR_INVALID, "detokenize: cache was created for " + std::to_string(cache->B) + " trajectories, this call has " + std::to_string(B));
   {
     size_t fi = 0;
     for (auto& f : feats) {

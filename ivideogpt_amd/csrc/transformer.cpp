@@ -27,6 +27,8 @@ struct GenBuf {  // persistent decode-step buffers (fixed addresses so the captu
   StepState* state;  // [MAX_CHAINS], one per concurrent chain, 256 B apart
   char* x; char* qkv; char* attn; char* act; float* logits;
   int64_t* ids; float* uni; char* act_emb; int Bc, ids_ld;
+  float* last_act;   // [Bc][max_frames][action_dim]: the action table of the call that built the kept KV cache
+  int* flag;         // mismatch counter of the prefix verification
 };
 constexpr int MAX_CHAINS = 8;
 static StepState* chain_state(const GenBuf& g, int c) { return (StepState*)((char*)g.state + 256 * c); }
@@ -50,6 +52,8 @@ static void gen_layout(const ivg_engine* e, GenBuf& g, char* base, size_t* total
   g.ids = (int64_t*)take((size_t)Bc * g.ids_ld * 8);
   g.uni = (float*)take((size_t)Bc * g.ids_ld * 4);
   g.act_emb = take((size_t)Bc * std::max(1, c.max_frames) * H * esz(dt));
+  g.last_act = (float*)take((size_t)Bc * std::max(1, c.max_frames) * std::max(1, c.action_dim) * 4);
+  g.flag = (int*)take(256);
   *total = off;
 }
 
@@ -72,7 +76,7 @@ static bool flash_prefill_covers(DType dt, int hd) {
 }
 
 int Run::prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const void* act_emb, int act_T, int ctx, bool all_slots,
-                 float* logits_all, float* logits_last, void* hidden_last) {
+                 float* logits_all, float* logits_last, void* hidden_last, const void* embeds, void* hidden_all) {
   const ivg_config& c = e->cfg;
   const DType dt = e->llm_dt;
   const int H = c.hidden_size, I = c.intermediate_size, V = c.vocab_size, heads = e->heads, hd = e->hd, Lmax = e->Lmax;
@@ -89,7 +93,8 @@ int Run::prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const voi
   char* Pm = flash ? nullptr : (char*)e->ws.alloc((size_t)B * heads * L * Lp * esz(dt));
   if (!planning) {
     e->kv_len = 0; e->kv_B = 0;   // the cache rows are about to be overwritten (ivg_generate re-validates them at its end)
-    CK(launch_embed(ids, ids_stride, e->embed, x, dt, B, L, H, V, st));
+    if (embeds) CK((int)hipMemcpyAsync(x, embeds, (size_t)M * H * esz(dt), hipMemcpyDeviceToDevice, st));
+    else CK(launch_embed(ids, ids_stride, e->embed, x, dt, B, L, H, V, st));
     if (act_emb) {  // action embedding on the sdf slot(s): slot i (position 257*ctx - 1 + 17*i) gets action i + ctx - 1
       for (int i = 0;; ++i) {
         const int pos = 257 * ctx - 1 + 17 * i;
@@ -147,6 +152,10 @@ int Run::prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const voi
     ConvW wd; wd.w = w.wdown; wd.cin = I; wd.cout = H;
     IVG_TRY(linear(dt, act, M, wd, x, x, 0, 0));
   }
+  if (hidden_all && !planning) {
+    if (!e->final_norm) return e->fail(IVG_ERR_MISSING, "hidden states requested but 'llm.norm' is not in the weight table");
+    CK(launch_final_hidden(x, e->final_norm, hidden_all, (int)M, H, c.rms_norm_eps, dt, st));
+  }
   if (logits_all) {
     if (!planning) CK(launch_add_rmsnorm(x, H, nullptr, 0, e->ones, xn, (int)M, H, c.rms_norm_eps, dt, st));
     ConvW wl; wl.w = e->lm_head; wl.cin = H; wl.cout = V;
@@ -169,7 +178,8 @@ int Run::prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const voi
 // decide token j (sample / forced), embed it, run it through the layers against the KV cache, produce the
 // logits for token j+1, advance the device-side state.
 // One chain = rows [b0, b0 + B) of the generate batch: its own dependency chain, state counters and buffer slices.
-static int step_chain(ivg_engine* e, hipStream_t st, const GenBuf& g, int chain, int b0, int B, const SampleArgs& sa0, bool forward) {
+static int step_chain(ivg_engine* e, hipStream_t st, const GenBuf& g, int chain, int b0, int B, const SampleArgs& sa0, bool forward,
+                      bool skip_sample = false) {
   const ivg_config& c = e->cfg;
   const DType dt = e->llm_dt;
   const int H = c.hidden_size, I = c.intermediate_size, V = c.vocab_size;
@@ -188,7 +198,7 @@ static int step_chain(ivg_engine* e, hipStream_t st, const GenBuf& g, int chain,
   sa.x = x;
   if (sa.act) sa.act = (const char*)sa.act + (size_t)b0 * sa.act_T * H * es;
   sa.state = state;
-  CK(launch_sample_embed(sa, B, dt, st));
+  if (!skip_sample) CK(launch_sample_embed(sa, B, dt, st));   // skip: x already holds the input row (embeds path, kept KV cache)
   if (!forward) return 0;
   // 5 launches per layer: RMSNorms are fused into the consuming GEMMs (weights pre-multiplied by the norm weight,
   // row scale computed from the activations the GEMM streams anyway), residual adds into the producing GEMMs.
@@ -223,14 +233,15 @@ static int step_chain(ivg_engine* e, hipStream_t st, const GenBuf& g, int chain,
 // join by events; under stream capture this becomes one graph with nc parallel branches).  Every kernel of a step is
 // latency- or per-CU-ingest-bound and uses a fraction of the chip, so independent chains overlap almost for free and
 // the HBM-bound attention of one chain hides the launch latencies of the others.
-static int step_body(ivg_engine* e, hipStream_t st, const GenBuf& g, int B, int nc, int cs, const SampleArgs& sa, bool forward) {
-  if (nc <= 1) return step_chain(e, st, g, 0, 0, B, sa, forward);
+static int step_body(ivg_engine* e, hipStream_t st, const GenBuf& g, int B, int nc, int cs, const SampleArgs& sa, bool forward,
+                     bool skip_sample = false) {
+  if (nc <= 1) return step_chain(e, st, g, 0, 0, B, sa, forward, skip_sample);
   CK((int)hipEventRecord(e->fork_ev, st));
   for (int c = 1; c < nc; ++c) CK((int)hipStreamWaitEvent(e->side[c - 1], e->fork_ev, 0));
   for (int c = 0; c < nc; ++c) {
     const int b0 = c * cs, bc = std::min(cs, B - b0);
     if (bc <= 0) continue;
-    IVG_TRY(step_chain(e, c == 0 ? st : e->side[c - 1], g, c, b0, bc, sa, forward));
+    IVG_TRY(step_chain(e, c == 0 ? st : e->side[c - 1], g, c, b0, bc, sa, forward, skip_sample));
   }
   for (int c = 1; c < nc; ++c) {
     CK((int)hipEventRecord(e->join_ev[c - 1], e->side[c - 1]));
@@ -240,7 +251,8 @@ static int step_body(ivg_engine* e, hipStream_t st, const GenBuf& g, int B, int 
 }
 
 int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, int n_new, const float* actions, int act_T, int ctx,
-                  const float* uniforms, int top_k, int64_t* ids_out, float* reward_out, bool reuse_kv) {
+                  const float* uniforms, int top_k, int64_t* ids_out, float* reward_out, bool reuse_kv, const void* embeds,
+                  int64_t* new_ids_out, void* hidden_out) {
   const ivg_config& c = e->cfg;
   const DType dt = e->llm_dt;
   const int H = c.hidden_size, V = c.vocab_size;
@@ -252,20 +264,37 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
     return reuse_kv ? 0 : prefill(nullptr, 0, std::min(B, g.Bc), L0, nullptr, 0, ctx, false, nullptr, nullptr, nullptr);
   }
   e->kv_len = 0; e->kv_B = 0;   // set again once every launch of this call is queued
+  const size_t es = esz(dt);
+  if (embeds && B > g.Bc) return e->fail(IVG_ERR_CAPACITY, "generate (inputs_embeds): batch exceeds the KV-cache chunk");
+  if (embeds && !e->emb_snap) {   // one-time: copy of the inputs the cache is built from (verifies later "same prefix" claims)
+    if (hipMalloc((void**)&e->emb_snap, (size_t)g.Bc * e->Lmax * H * es) != hipSuccess) return e->fail(IVG_ERR_HIP, "hipMalloc of the embeddings snapshot failed");
+  }
+  e->snap_valid = false; e->ids_valid = false;
   for (int b0 = 0; b0 < B; b0 += g.Bc) {
     const int Bc = std::min(g.Bc, B - b0);
     if (e->attn_prof_on) {  // fresh launch windows for this call: every stamp slot back to 0 (= not stamped)
       CK((int)hipMemsetAsync(e->attn_prof, 0, (size_t)c.num_layers * IVG_ATTN_PROF_SLOTS * 2 * e->Lmax * 8, st));
       e->attn_prof_B = Bc;
     }
-    CK((int)hipMemcpy2DAsync(g.ids, (size_t)g.ids_ld * 8, prompt + (long)b0 * prompt_stride, (size_t)prompt_stride * 8, (size_t)L0 * 8, Bc,
-                             hipMemcpyDeviceToDevice, st));
+    if (!embeds)
+      CK((int)hipMemcpy2DAsync(g.ids, (size_t)g.ids_ld * 8, prompt + (long)b0 * prompt_stride, (size_t)prompt_stride * 8, (size_t)L0 * 8, Bc,
+                               hipMemcpyDeviceToDevice, st));
     if (uniforms)
       CK((int)hipMemcpy2DAsync(g.uni, (size_t)g.ids_ld * 4, uniforms + (long)b0 * n_new, (size_t)n_new * 4, (size_t)n_new * 4, Bc,
                                hipMemcpyDeviceToDevice, st));
-    if (actions)
+    if (actions) {
       CK(launch_action_embed(actions + (long)b0 * act_T * c.action_dim, e->act_w, e->act_b, g.act_emb, dt, Bc * act_T, c.action_dim, H, st));
-    if (!reuse_kv) IVG_TRY(prefill(g.ids, g.ids_ld, Bc, L0, actions ? g.act_emb : nullptr, act_T, ctx, true, nullptr, g.logits, g.x));
+      if (B <= g.Bc) CK((int)hipMemcpyAsync(g.last_act, actions, (size_t)B * act_T * c.action_dim * 4, hipMemcpyDeviceToDevice, st));
+    }
+    if (!reuse_kv) IVG_TRY(prefill(g.ids, g.ids_ld, Bc, L0, actions ? g.act_emb : nullptr, act_T, ctx, true, nullptr, g.logits, g.x, embeds));
+    if (embeds) {   // keep what the cache is (being) built from: the whole prompt after a prefill, its last row on the kept-cache path
+      const int p0 = reuse_kv ? L0 - 1 : 0;
+      CK((int)hipMemcpy2DAsync(e->emb_snap + (size_t)p0 * H * es, (size_t)e->Lmax * H * es, (const char*)embeds + (size_t)p0 * H * es,
+                               (size_t)L0 * H * es, (size_t)(L0 - p0) * H * es, Bc, hipMemcpyDeviceToDevice, st));
+      if (reuse_kv)   // the input row of the first forward pass comes straight from the caller
+        CK((int)hipMemcpy2DAsync(g.x, (size_t)H * es, (const char*)embeds + (size_t)(L0 - 1) * H * es, (size_t)L0 * H * es, (size_t)H * es, Bc,
+                                 hipMemcpyDeviceToDevice, st));
+    }
     // chains: rows split into up to e->chains groups of a multiple of 16 rows
     int nc = std::max(1, std::min(e->chains, MAX_CHAINS));
     int cs = ((Bc + nc - 1) / nc + 15) / 16 * 16;
@@ -292,13 +321,17 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
     // reward head: reads the residual stream left by the LAST forward pass, i.e. before the final decide-only step
     // overwrites it with the embedding of the last token (mbrl/video_predictor.py:311-313: hidden state of the last step)
     auto reward = [&]() -> int {
+      if (hidden_out) {   // hidden_states[-1][-1] of HF generate: the last forward pass, after the final norm
+        if (!e->final_norm) return e->fail(IVG_ERR_MISSING, "generate: hidden state requested but 'llm.norm' is not in the weight table");
+        CK(launch_final_hidden(g.x, e->final_norm, (char*)hidden_out + (size_t)b0 * H * es, Bc, H, c.rms_norm_eps, dt, st));
+      }
       if (!reward_out) return 0;
       if (!e->rew_w) return e->fail(IVG_ERR_MISSING, "generate: reward requested but reward_linear is not loaded");
       CK(launch_rowdot(g.x, e->rew_w, e->rew_b, reward_out + b0, Bc, H, c.rms_norm_eps, dt, st));
       return 0;
     };
     int j = 1;
-    if (reuse_kv) IVG_TRY(step_body(e, st, g, Bc, nc, cs, sa, true));   // j = 0: feed the prompt's last token
+    if (reuse_kv) IVG_TRY(step_body(e, st, g, Bc, nc, cs, sa, true, embeds != nullptr));   // j = 0: feed the prompt's last token
     if (n_new == 1) IVG_TRY(reward());
     if (n_new >= 1) { IVG_TRY(step_body(e, st, g, Bc, nc, cs, sa, j < n_new)); ++j; }
     hipGraphExec_t exec = nullptr;
@@ -336,11 +369,64 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
       IVG_TRY(reward());
       IVG_TRY(step_body(e, st, g, Bc, nc, cs, sa, false));  // decide the last token (no forward)
     }
-    CK((int)hipMemcpy2DAsync(ids_out + (long)b0 * Ltot, (size_t)Ltot * 8, g.ids, (size_t)g.ids_ld * 8, (size_t)Ltot * 8, Bc,
-                             hipMemcpyDeviceToDevice, st));
+    if (embeds) {
+      CK((int)hipMemcpy2DAsync(new_ids_out + (long)b0 * n_new, (size_t)n_new * 8, g.ids + L0, (size_t)g.ids_ld * 8, (size_t)n_new * 8, Bc,
+                               hipMemcpyDeviceToDevice, st));
+      if (n_new > 1)   // inputs of the positions the steps appended: the embeddings of the fed new tokens
+        CK(launch_embed(g.ids + L0, g.ids_ld, e->embed, e->emb_snap + (size_t)L0 * H * es, dt, Bc, n_new - 1, H, V, st, (long)e->Lmax * H));
+    } else {
+      CK((int)hipMemcpy2DAsync(ids_out + (long)b0 * Ltot, (size_t)Ltot * 8, g.ids, (size_t)g.ids_ld * 8, (size_t)Ltot * 8, Bc,
+                               hipMemcpyDeviceToDevice, st));
+    }
   }
-  if (B <= g.Bc) { e->kv_len = L0 + n_new - 1; e->kv_B = B; }   // the last new token is decided but never fed
+  if (B <= g.Bc) {   // the last new token is decided but never fed
+    e->kv_len = L0 + n_new - 1; e->kv_B = B;
+    e->snap_valid = embeds != nullptr; e->ids_valid = embeds == nullptr;
+    e->last_act_T = actions ? act_T : 0;
+  }
   return 0;
+}
+
+// ---------------------------------------------------------------------------------------- kept-cache verification
+static int read_flag(ivg_engine* e, const GenBuf& g, hipStream_t st, bool* ok) {
+  if (!e->h_flag && hipHostMalloc((void**)&e->h_flag, sizeof(int), hipHostMallocDefault) != hipSuccess) return e->fail(IVG_ERR_HIP, "hipHostMalloc failed");
+  CK((int)hipMemcpyAsync(e->h_flag, g.flag, sizeof(int), hipMemcpyDeviceToHost, st));
+  CK((int)hipStreamSynchronize(st));
+  *ok = *e->h_flag == 0;
+  return 0;
+}
+
+int kv_prefix_matches_ids(ivg_engine* e, const int64_t* prompt, int64_t prompt_stride, int B, int L0, const float* actions, int act_T,
+                          int ctx, hipStream_t st, bool* ok) {
+  *ok = false;
+  GenBuf g;
+  size_t tot = 0;
+  gen_layout(e, g, e->gen_buf, &tot);
+  if (!e->ids_valid || e->kv_B != B || e->kv_len != L0 - 1 || B > g.Bc) return 0;
+  if (actions && (e->last_act_T != act_T)) return 0;
+  CK((int)hipMemsetAsync(g.flag, 0, sizeof(int), st));
+  CK(launch_compare_rows(prompt, prompt_stride * 8, g.ids, (long)g.ids_ld * 8, B, (long)(L0 - 1) * 8, g.flag, st));
+  if (actions) {   // the action rows already baked into the cached sdf slots: slot i (position 257*ctx - 1 + 17*i < kv_len) used row i + ctx - 1
+    const int A = e->cfg.action_dim;
+    const int slots = std::max(0, (e->kv_len - (257 * ctx - 1) + 16) / 17);
+    if (slots > 0 && ctx - 1 + slots <= act_T)
+      CK(launch_compare_rows(actions + (long)(ctx - 1) * A, (long)act_T * A * 4, g.last_act + (long)(ctx - 1) * A, (long)act_T * A * 4, B,
+                             (long)slots * A * 4, g.flag, st));
+  }
+  return read_flag(e, g, st, ok);
+}
+
+int kv_prefix_matches_embeds(ivg_engine* e, const void* embeds, int B, int L0, hipStream_t st, bool* ok) {
+  *ok = false;
+  GenBuf g;
+  size_t tot = 0;
+  gen_layout(e, g, e->gen_buf, &tot);
+  if (!e->snap_valid || !e->emb_snap || e->kv_B != B || e->kv_len != L0 - 1 || B > g.Bc) return 0;
+  const size_t es = esz(e->llm_dt);
+  const long H = e->cfg.hidden_size;
+  CK((int)hipMemsetAsync(g.flag, 0, sizeof(int), st));
+  CK(launch_compare_rows(embeds, (long)L0 * H * es, e->emb_snap, (long)e->Lmax * H * es, B, (long)(L0 - 1) * H * es, g.flag, st));
+  return read_flag(e, g, st, ok);
 }
 
 }  // namespace ivg

@@ -66,9 +66,13 @@ class Engine:
         self.h = h
         self.max_batch, self.max_frames = int(max_batch), int(max_frames)
         self._stream = torch.cuda.Stream(device=self.device)  # dedicated non-default stream (graph capture needs one)
+        self._caches = set()   # live detokenize caches (device memory owned here: released with the engine)
 
     def close(self):
         if getattr(self, "h", None):
+            for c in list(getattr(self, "_caches", ())):
+                self.lib.ivg_cache_destroy(self.h, C.c_void_p(c))
+            self._caches = set()
             self.lib.ivg_destroy(self.h)
             self.h = None
 
@@ -126,10 +130,13 @@ class Engine:
     def cache_create(self, B):
         h = C.c_void_p()
         self.check(self.lib.ivg_cache_create(self.h, int(B), C.byref(h)), "cache_create")
+        self._caches.add(h.value)
         return h
 
     def cache_destroy(self, h):
-        self.lib.ivg_cache_destroy(self.h, h)
+        if self.h is not None and h.value in self._caches:   # (already released when the engine was closed first)
+            self._caches.discard(h.value)
+            self.lib.ivg_cache_destroy(self.h, h)
 
     def generate(self, prompt, n_new, out, actions=None, ctx=1, uniforms=None, top_k=100, reward=None, reuse_kv=False):
         B, L0 = prompt.shape
@@ -141,6 +148,34 @@ class Engine:
             for t in (prompt, out, actions, uniforms, reward):
                 if t is not None:
                     t.record_stream(self._stream)
+
+    def embed_tokens(self, ids, out):
+        B, L = ids.shape
+        with self.stream() as s:
+            self.check(self.lib.ivg_embed_tokens(self.h, _ptr(ids), ids.stride(0), B, L, _ptr(out), s), "embed_tokens")
+            ids.record_stream(self._stream); out.record_stream(self._stream)
+
+    def action_linear(self, actions, out):
+        with self.stream() as s:
+            self.check(self.lib.ivg_action_linear(self.h, _ptr(actions), actions.numel() // actions.shape[-1], _ptr(out), s), "action_linear")
+            actions.record_stream(self._stream); out.record_stream(self._stream)
+
+    def reward_linear(self, hidden, out):
+        with self.stream() as s:
+            self.check(self.lib.ivg_reward_linear(self.h, _ptr(hidden), hidden.numel() // hidden.shape[-1], _ptr(out), s), "reward_linear")
+            hidden.record_stream(self._stream); out.record_stream(self._stream)
+
+    def generate_embeds(self, embeds, n_new, out, hidden=None, uniforms=None, top_k=100, allow_reuse=True):
+        """-> True when the kept KV cache was reused (only the last row of ``embeds`` was fed)."""
+        B, L0 = embeds.shape[:2]
+        reused = C.c_int(0)
+        with self.stream() as s:
+            self.check(self.lib.ivg_generate_embeds(self.h, _ptr(embeds), B, L0, int(n_new), _ptr(uniforms), int(top_k), _ptr(out),
+                                                    _ptr(hidden), int(bool(allow_reuse)), C.byref(reused), s), "generate_embeds")
+            for t in (embeds, out, hidden, uniforms):
+                if t is not None:
+                    t.record_stream(self._stream)
+        return bool(reused.value)
 
     def logits(self, ids, out, actions=None, ctx=1):
         B, L = ids.shape

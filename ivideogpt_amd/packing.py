@@ -79,6 +79,7 @@ def pack_llama(sd, cfg, device, code, prefix=""):
     out["llm.embed"] = g("model.embed_tokens.weight").to(dt).contiguous()
     fnorm = g("model.norm.weight")
     out["llm.lm_head"] = (g("lm_head.weight") * fnorm[None, :]).to(dt).contiguous()
+    out["llm.norm"] = fnorm.contiguous()                  # raw: the hidden states handed back to callers are post-norm (HF)
     # RoPE tables exactly as HF builds them (fp32 inv_freq, fp32 outer product, cos/sin, cast to the model dtype)
     inv_freq = 1.0 / (cfg.get("rope_theta", 10000.0) ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
     freqs = torch.arange(cfg["max_position_embeddings"], dtype=torch.float32)[:, None] * inv_freq[None, :]
@@ -91,4 +92,5 @@ def pack_llama(sd, cfg, device, code, prefix=""):
         out["llm.reward_linear.weight"] = (sd["reward_linear.weight"].detach().to(device=device, dtype=torch.float32).reshape(-1)
                                            * fnorm).contiguous()   # reward head reads the final-normed hidden state
         out["llm.reward_linear.bias"] = sd["reward_linear.bias"].detach().to(device=device, dtype=torch.float32).contiguous()
+        out["llm.reward_linear.raw"] = sd["reward_linear.weight"].detach().to(device=device, dtype=torch.float32).reshape(-1).contiguous()
     return out

@@ -28,12 +28,11 @@ class DetokenizeCache:
 
     def __init__(self, engine, B):
         self.engine, self.B = engine, B
-        self.handle = engine.cache_create(B)
+        self.handle = engine.cache_create(B)   # the engine owns the device memory: Engine.close releases what is still alive
 
     def __del__(self):
         try:
-            if self.engine.h:
-                self.engine.cache_destroy(self.handle)
+            self.engine.cache_destroy(self.handle)
         except Exception:
             pass
 
@@ -185,9 +184,16 @@ class CompressiveVQModel:
         out = torch.empty(B, context_length + F, 3, res, res, dtype=torch.float32, device=self.device)
         eng = self._ensure(B, context_length + F)
         handle, mode = None, 0
-        if cache is not None:
-            if cache.engine is not eng or cache.B != B:
-                raise AssertionError("detokenize: cache belongs to another engine / batch size")
+        if cache is not None and (cache.engine is not eng or cache.engine.h is None):
+            # the engine was rebuilt since the cache was filled (batch or clip length grew): the cached context features are
+            # gone with it -- decode the context again into a fresh cache instead of failing mid-rollout
+            if cache.B != B:
+                raise AssertionError("detokenize: cache was filled for another batch size")
+            cache = DetokenizeCache(eng, B)
+            handle, mode = cache.handle, 1
+        elif cache is not None:
+            if cache.B != B:
+                raise AssertionError("detokenize: cache was filled for another batch size")
             handle, mode = cache.handle, 2
         elif return_cache:
             cache = DetokenizeCache(eng, B)

@@ -377,6 +377,62 @@ def test_skinny_gemm_lm_head_shape_with_ragged_vocab(M):
     assert rel_err(Yf[:, -2:], ref[:, -2:]) < 2e-5
 
 
+DECODE_SHAPES = [  # (K, N, flags): every decode-step GEMM of the small (768 / 3072) and medium (1024 / 4096) transformers
+    (768, 2304, "norm"), (768, 768, "residual"), (768, 6144, "norm_glu"), (3072, 768, "residual"),
+    (1024, 3072, "norm"), (1024, 1024, "residual"), (1024, 8192, "norm_glu"), (4096, 1024, "residual"),
+    (768, 16386, "norm_f32"), (128, 384, "norm"), (256, 128, "residual"), (1024, 16386, "norm_f32"),
+]
+
+
+@pytest.mark.parametrize("gen", ["gen2", "gen1"])
+@pytest.mark.parametrize("dt", ["bf16", "fp32"])
+@pytest.mark.parametrize("K,N,mode", DECODE_SHAPES)
+def test_decode_gemm_model_shapes(K, N, mode, dt, gen, monkeypatch):
+    """The decode-step GEMMs at the shapes the rollouts run (BASELINE configs 2 and 5), with their fused epilogues -- RMSNorm row
+    scale, in-place residual, SiLU(gate) * up, fp32 logits -- against fp64, for the second-generation kernel (dgemm.hip:
+    activations as whole lines through LDS) and the first-generation one (IVG_DG=0, skinny.hip)."""
+    L, l = lib()
+    if gen == "gen1":
+        monkeypatch.setenv("IVG_DG", "0")
+    else:
+        monkeypatch.delenv("IVG_DG", raising=False)
+    g = torch.Generator().manual_seed(K + N)
+    for M in (64, 37, 128):
+        x = q(torch.randn(M, K, generator=g) * 1.7, dt)
+        w = q(torch.randn(N, K, generator=g) / K ** 0.5, dt)
+        xd = x.to(DEV, tdt(dt))
+        flags, ldy, out_dt = 0, N, tdt(dt)
+        xs = x.double()
+        if "norm" in mode:
+            flags |= 64
+            xs = xs * torch.rsqrt(xs.pow(2).mean(-1, keepdim=True) + 1e-6)
+        if mode == "norm_glu":
+            I = N // 2
+            gate, up = w[:I], w[I:]
+            wd = torch.stack([gate.view(I // 16, 16, K), up.view(I // 16, 16, K)], 1).reshape(N, K).contiguous().to(DEV, tdt(dt))
+            ref = F.silu(xs @ gate.double().T) * (xs @ up.double().T)
+            flags |= 16
+            ldy = I
+        else:
+            wd = w.to(DEV, tdt(dt))
+            ref = xs @ w.double().T
+        if mode == "norm_f32":
+            flags |= 32
+            out_dt = torch.float32
+        if mode == "residual":
+            r0 = q(torch.randn(M, N, generator=g), dt)
+            Y = r0.to(DEV, tdt(dt)).clone()
+            ref = ref + r0.double()
+            flags |= 4
+        else:
+            Y = torch.full((M, ldy), float("nan"), device=DEV, dtype=out_dt)
+        assert l.ivg_op_skinny(P(xd), P(wd), P(Y), M, N, K, K, K, ldy, 1, flags, code(dt), stream()) == 0
+        torch.cuda.synchronize()
+        assert torch.isfinite(Y.float()).all()
+        tol = 2e-5 if (dt == "fp32" or mode == "norm_f32") else TOL[dt]
+        assert rel_err(Y.float(), ref) < tol, (M, K, N, mode, dt, gen)
+
+
 @pytest.mark.parametrize("mode", ["plain", "bias_residual_inplace", "glu", "silu", "k_short", "nimg"])
 def test_gemm256_large_dense(mode, monkeypatch):
     """256 x 256-tile GEMM of the prompt pass (bf16, rows not a multiple of 256): every epilogue against fp64, and bit-for-bit
