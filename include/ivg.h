@@ -161,10 +161,48 @@ int ivg_reward_linear(ivg_engine* e, const void* hidden, int rows, float* out, i
 int ivg_logits(ivg_engine* e, const int64_t* ids, int B, int L, const float* actions, int act_T, int ctx, float* logits_out,
                ivg_stream stream);
 
+/* Eval forward with labels (HeadModelWithAction.forward / LlamaForCausalLM.forward, action_model.py:154-205; train_gpt.py:356-376):
+ * HF shifted cross-entropy, ignore_index -100, WITHOUT materialising the (B, L, vocab) fp32 logits (lm_head runs over row chunks that
+ * are reduced to per-position losses in place).
+ *   ids, labels    int64 (B, L); actions as in ivg_logits (added on every sdf slot) or NULL
+ *   token_nll_out  float32 (B, L): -log p(labels[b][l+1] | ids[b][:l+1]) at position l; 0 where the target is ignored / l = L - 1
+ *   loss_rows_out  float32 (B, 2): per trajectory (sum of token_nll, number of non-ignored targets); the HF loss of the batch is
+ *                  sum(sums) / sum(counts), a trajectory's perplexity exp(sum / count)
+ *   hidden_out     NULL or (B, L, hidden) llm dtype: post-final-norm hidden states (output_hidden_states=True, [-1]) -- what
+ *                  reward_linear (action_model.py:198-204) and action_recon_linear (:187-196) read */
+int ivg_eval_forward(ivg_engine* e, const int64_t* ids, const int64_t* labels, int B, int L, const float* actions, int act_T, int ctx,
+                     float* token_nll_out, float* loss_rows_out, void* hidden_out, ivg_stream stream);
+/* action reconstruction term (action_model.py:187-196): out[b] = sum over positions p >= prelude and action dims of
+ * (action_recon_linear(hidden[b][p]) - actions[b][ctx - 1 + (p - prelude) / 17])^2;  mse_loss = sum(out) / (B * (L - prelude) * action_dim) */
+int ivg_action_recon_sqerr(ivg_engine* e, const void* hidden, const float* actions, int B, int L, int act_T, int ctx, int prelude, float* out,
+                           ivg_stream stream);
+
+/* Clip ingest on the device: NPZParser.preprocess / EvalDataset.data_augmentation of the reference (inference/utils.py:12-16,
+ * ivideogpt/data/simple_dataloader.py:512-516): frames uint8 (T, H, W, 3) as stored in the episode files -> / 255 -> optional centre
+ * crop to the short side -> torchvision resize to (resolution, resolution), whose tensor path is antialiased bilinear interpolation
+ * (ATen upsample_bilinear2d_aa semantics, width first) -> clip_out (T, 3, resolution, resolution) float32 or bfloat16 in [0, 1].
+ * Downscale factors up to 15.  Engine-free. */
+int ivg_ingest_frames(const uint8_t* frames, int T, int H, int W, int center_crop, void* clip_out, int out_dtype, int resolution,
+                      ivg_stream stream);
+
+/* Frame metrics of predicted clips on the device: Evaluator.forward of the reference without LPIPS
+ * (ivideogpt/utils/video_metric.py:63-100; piqa PSNR(epsilon 1e-8, range 1) and SSIM(11 x 11 Gaussian, sigma 1.5, no padding)):
+ * per frame mse / psnr / ssim, mean over the T frames of a trajectory, then the best of its t = n_samples / B samples
+ * (min mse, max psnr, max ssim).  Engine-free (no weights).
+ *   gt    (B, T_gt, 3, H, W) float32 or bfloat16 in [0, 1]; frames [gt_t0, gt_t0 + T) are compared
+ *   pred  float32 (n_samples, T_pr, 3, H, W), frames [pr_t0, pr_t0 + T); sample k of trajectory b is row k * B + b
+ *         (the layout of video_1.repeat([t, 1, 1, 1, 1]), video_metric.py:69-71)
+ *   rows_out float32 (B, 3) = (mse, psnr, ssim): the per-trajectory rows the multi-GPU path all-gathers (train_gpt.py:476-479)
+ *   ws    scratch of at least ivg_frame_metrics_ws_bytes(n_samples, T, H, W) bytes */
+size_t ivg_frame_metrics_ws_bytes(int n_samples, int T, int H, int W);
+int ivg_frame_metrics(const void* gt, int gt_dtype, int B, int T_gt, int gt_t0, const float* pred, int n_samples, int T_pr, int pr_t0, int T, int H,
+                      int W, float* rows_out, void* ws, size_t ws_bytes, ivg_stream stream);
+
 /* ---- measurement hooks (bench.py): time one kernel class with HIP events on the launching stream; the decode attention
  * (which runs inside a replayed hipGraph) stamps its own launch windows with the 100 MHz wall clock instead */
 enum ivg_kernel_class { IVG_K_IGEMM_BF16 = 0, IVG_K_IGEMM_F32 = 1, IVG_K_CONV3X3_BF16 = 2, IVG_K_CONV3X3_F32 = 3, IVG_K_DECODE_ATTN = 4,
-                        IVG_K_COUNT = 5 };
+                        IVG_K_DECODE_GEMM = 5,   /* the decode step's GEMMs (q/k/v, o, gate/up, down, lm_head): HBM-bound, bytes = weights */
+                        IVG_K_COUNT = 6 };
 typedef struct {
   int64_t launches;
   double total_ms;      /* sum of per-launch durations (hipEventElapsedTime) */

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libivg.so")
 
 IVG_F32, IVG_BF16 = 0, 1
-IVG_K_IGEMM_BF16, IVG_K_IGEMM_F32, IVG_K_CONV3X3_BF16, IVG_K_CONV3X3_F32, IVG_K_DECODE_ATTN = 0, 1, 2, 3, 4
+IVG_K_IGEMM_BF16, IVG_K_IGEMM_F32, IVG_K_CONV3X3_BF16, IVG_K_CONV3X3_F32, IVG_K_DECODE_ATTN, IVG_K_DECODE_GEMM = 0, 1, 2, 3, 4, 5
 # igemm epilogue flags (csrc/igemm.h)
 IG_BIAS_N, IG_BIAS_M, IG_RESIDUAL, IG_SILU, IG_GLU, IG_OUT_F32 = 1, 2, 4, 8, 16, 32
 
@@ -72,6 +72,14 @@ EXPORTS = {
                                       C.c_int, C.POINTER(C.c_int), C.c_void_p]),
     "ivg_reward_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "ivg_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "ivg_eval_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ivg_action_recon_sqerr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                         C.c_void_p]),
+    "ivg_ingest_frames": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "ivg_frame_metrics_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ivg_frame_metrics": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ivg_profile_enable": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ivg_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(IvgProfileStats)]),
     "ivg_profile_attn_fit": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -168,6 +168,10 @@ int build_transformer(ivg_engine* e) {
     if (e->wmap.count("llm.reward_linear.raw")) e->rew_w_raw = L.f32("llm.reward_linear.raw", H);
   }
   if (e->wmap.count("llm.norm")) e->final_norm = L.f32("llm.norm", H);   // optional: only the hidden-state outputs need it
+  if (c.action_dim > 0 && e->wmap.count("llm.action_recon_linear.weight")) {
+    e->ar_w = L.f32("llm.action_recon_linear.weight", (int64_t)c.action_dim * H);
+    e->ar_b = L.f32("llm.action_recon_linear.bias", c.action_dim);
+  }
   return L.ok ? 0 : IVG_ERR_MISSING;
 }
 
@@ -273,6 +277,7 @@ void ivg_destroy(ivg_engine* e) {
   if (e->ones) (void)hipFree(e->ones);
   if (e->attn_prof) (void)hipFree(e->attn_prof);
   if (e->emb_snap) (void)hipFree(e->emb_snap);
+  if (e->gemm_prof) (void)hipFree(e->gemm_prof);
   if (e->h_flag) (void)hipHostFree(e->h_flag);
   delete e;
 }
@@ -512,6 +517,58 @@ int ivg_logits(ivg_engine* e, const int64_t* ids, int B, int L, const float* act
   });
 }
 
+int ivg_eval_forward(ivg_engine* e, const int64_t* ids, const int64_t* labels, int B, int L, const float* actions, int act_T, int ctx,
+                     float* token_nll_out, float* loss_rows_out, void* hidden_out, ivg_stream stream) {
+  if (!e) return IVG_ERR_INVALID;
+  if (e->cfg.num_layers <= 0) return e->fail(IVG_ERR_INVALID, "eval_forward: engine was created without a transformer");
+  if (!ids || !labels || !token_nll_out || !loss_rows_out) return e->fail(IVG_ERR_INVALID, "eval_forward: null argument");
+  if (B <= 0 || B > std::min(e->cfg.max_batch, 128) || L < 2 || L > e->Lmax) return e->fail(IVG_ERR_CAPACITY, "eval_forward: batch or length exceeds capacity");
+  if (actions && (e->cfg.action_dim <= 0 || !e->act_w)) return e->fail(IVG_ERR_INVALID, "eval_forward: actions given but the model is action-free");
+  return plan_then_run(e, (hipStream_t)stream, [&](Run& r) {
+    const void* act_emb = nullptr;
+    if (actions) {
+      char* buf = (char*)e->ws.alloc((size_t)B * act_T * e->cfg.hidden_size * dtype_size(e->llm_dt));
+      if (!r.planning && launch_action_embed(actions, e->act_w, e->act_b, buf, e->llm_dt, B * act_T, e->cfg.action_dim, e->cfg.hidden_size, r.st))
+        return e->fail(IVG_ERR_HIP, "action_embed launch failed");
+      act_emb = buf;
+    }
+    int rc = r.prefill(ids, L, B, L, act_emb, act_T, ctx, true, nullptr, nullptr, nullptr, nullptr, hidden_out, labels, token_nll_out);
+    if (rc) return rc;
+    if (!r.planning && launch_ce_reduce(token_nll_out, labels, B, L, e->cfg.vocab_size, loss_rows_out, r.st)) return e->fail(IVG_ERR_HIP, "ce_reduce launch failed");
+    return 0;
+  });
+}
+
+int ivg_action_recon_sqerr(ivg_engine* e, const void* hidden, const float* actions, int B, int L, int act_T, int ctx, int prelude, float* out,
+                           ivg_stream stream) {
+  if (!e) return IVG_ERR_INVALID;
+  if (!e->ar_w || !e->ar_b) return e->fail(IVG_ERR_MISSING, "action_recon: 'action_recon_linear' is not in the weight table");
+  if (!hidden || !actions || !out || B <= 0 || prelude < 0 || prelude >= L) return e->fail(IVG_ERR_INVALID, "action_recon: bad argument");
+  if (ctx - 1 + (L - 1 - prelude) / 17 >= act_T) return e->fail(IVG_ERR_INVALID, "action_recon: action tensor too short");
+  if (launch_action_recon(hidden, e->ar_w, e->ar_b, actions, B, L, e->cfg.hidden_size, e->cfg.action_dim, act_T, ctx, prelude, out, e->llm_dt,
+                          (hipStream_t)stream))
+    return e->fail(IVG_ERR_HIP, "action_recon: launch failed");
+  return IVG_OK;
+}
+
+int ivg_ingest_frames(const uint8_t* frames, int T, int H, int W, int center_crop, void* clip_out, int out_dtype, int resolution, ivg_stream stream) {
+  if (!frames || !clip_out || (out_dtype != IVG_F32 && out_dtype != IVG_BF16)) return IVG_ERR_INVALID;
+  const int rc = launch_ingest(frames, T, H, W, center_crop, clip_out, (DType)out_dtype, resolution, (hipStream_t)stream);
+  return rc == 0 ? IVG_OK : (rc == (int)hipErrorInvalidValue ? IVG_ERR_INVALID : IVG_ERR_HIP);
+}
+
+size_t ivg_frame_metrics_ws_bytes(int n_samples, int T, int H, int W) { return frame_metrics_ws_bytes(n_samples, T, H, W); }
+
+int ivg_frame_metrics(const void* gt, int gt_dtype, int B, int T_gt, int gt_t0, const float* pred, int n_samples, int T_pr, int pr_t0, int T, int H,
+                      int W, float* rows_out, void* ws, size_t ws_bytes, ivg_stream stream) {
+  if (!gt || !pred || !rows_out || !ws) return IVG_ERR_INVALID;
+  if (B <= 0 || n_samples <= 0 || n_samples % B != 0 || T <= 0 || gt_t0 < 0 || pr_t0 < 0 || gt_t0 + T > T_gt || pr_t0 + T > T_pr || H < 11 || W < 11)
+    return IVG_ERR_INVALID;
+  if (ws_bytes < frame_metrics_ws_bytes(n_samples, T, H, W)) return IVG_ERR_CAPACITY;
+  return launch_frame_metrics(gt, (DType)gt_dtype, B, T_gt, gt_t0, pred, n_samples, T_pr, pr_t0, T, H, W, rows_out, ws, (hipStream_t)stream) ? IVG_ERR_HIP
+                                                                                                                                                : IVG_OK;
+}
+
 int ivg_profile_attn_fit(ivg_engine* e, double* fixed_us, double* gbps) {
   if (!e || !fixed_us || !gbps) return IVG_ERR_INVALID;
   *fixed_us = e->attn_fit_fixed_us; *gbps = e->attn_fit_gbps;
@@ -521,6 +578,15 @@ int ivg_profile_attn_fit(ivg_engine* e, double* fixed_us, double* gbps) {
 int ivg_profile_enable(ivg_engine* e, int k, int enable) {
   if (!e || k < 0 || k >= IVG_K_COUNT) return IVG_ERR_INVALID;
   if (k == IVG_K_DECODE_ATTN) { e->attn_prof_on = enable != 0 && e->attn_prof; return IVG_OK; }
+  if (k == IVG_K_DECODE_GEMM) {
+    if (enable && !e->gemm_prof && e->cfg.num_layers > 0) {
+      const size_t n = (size_t)(4 * e->cfg.num_layers + 1) * IVG_GEMM_PROF_SLOTS * 2 * e->Lmax * 8;
+      API_CK(hipMalloc((void**)&e->gemm_prof, n));
+      API_CK(hipMemset(e->gemm_prof, 0, n));
+    }
+    e->gemm_prof_on = enable != 0 && e->gemm_prof;
+    return IVG_OK;
+  }
   e->prof[k].enabled = enable != 0;
   return IVG_OK;
 }
@@ -563,6 +629,32 @@ int ivg_profile_read(ivg_engine* e, int k, ivg_profile_stats* out) {
       e->attn_fit_fixed_us = (sy - slope * sx) / sn * 1e3;
       e->attn_fit_gbps = slope > 0 ? 1e-6 / slope : 0;             // bytes/ms -> GB/s
     }
+    return IVG_OK;
+  }
+  if (k == IVG_K_DECODE_GEMM) {
+    // launch windows stamped by the GEMM kernels of the last ivg_generate call; bytes = the weight matrix a launch streams
+    out->launches = 0; out->total_ms = 0; out->total_flops = 0; out->total_bytes = 0;
+    if (!e->gemm_prof) return IVG_OK;
+    const int L = e->Lmax, nl = e->cfg.num_layers, NS = IVG_GEMM_PROF_SLOTS, ng = 4 * nl + 1;
+    const double H = e->cfg.hidden_size, I = e->cfg.intermediate_size, V = e->cfg.vocab_size, es = (double)dtype_size(e->llm_dt);
+    const double wbytes[5] = {3 * H * H * es, H * H * es, 2 * I * H * es, H * I * es, V * H * es};
+    std::vector<unsigned long long> h((size_t)ng * NS * 2 * L);
+    API_CK(hipMemcpy(h.data(), e->gemm_prof, h.size() * 8, hipMemcpyDeviceToHost));
+    for (int g = 0; g < ng; ++g)
+      for (int p = 0; p < L; ++p) {
+        unsigned long long s = ~0ull, t = 0;
+        for (int q = 0; q < NS; ++q) {
+          const unsigned long long cs = h[((size_t)(g * NS + q) * 2) * L + p], ct = h[((size_t)(g * NS + q) * 2 + 1) * L + p];
+          if (cs) s = std::min(s, ~cs);
+          t = std::max(t, ct);
+        }
+        if (t == 0 || s == ~0ull || t < s) continue;
+        const double wb = g == 4 * nl ? wbytes[4] : wbytes[g & 3];
+        out->launches++;
+        out->total_ms += (double)(t - s) * 1e-5;
+        out->total_bytes += wb;
+        out->total_flops += wb / es * 2.0 * e->gemm_prof_B;
+      }
     return IVG_OK;
   }
   ProfClass& pc = e->prof[k];

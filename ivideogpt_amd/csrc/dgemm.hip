@@ -8,8 +8,10 @@
 //     of one line; the chunk order inside the line is permuted on the SOURCE side (chunk ^ ((row >> 1) & 7)) so that the
 //     lane-linear LDS image [16 rows][8 chunks] is read back as MFMA fragments by conflict-free ds_read_b128;
 //   * the staging area is private to a wave (its K slice of the rows): no workgroup barrier before the MFMAs;
-//   * weights stream once from HBM straight into registers with non-temporal loads (fragment-shaped is fine there: HBM, not
-//     the L2 path, bounds them), every load of a burst in flight before the first wait;
+//   * weights take the same road (whole lines by LDS-DMA, non-temporal: streamed once per step): with NO register-destination
+//     load in flight the compiler has nothing to drain with vmcnt(0) (it does so whenever ordinary loads and LDS-DMA share the
+//     counter), so the hand-counted waits can release the lines group by group and the MFMAs / norm sums of the first
+//     128 bytes of K run while the rest of the wave's slice is still arriving;
 //   * the residual rows the epilogue updates are requested at kernel start instead of after the K reduction.
 // Waves split K (fixed partition per (K, dtype): a trajectory's result does not depend on its batch-mates), combine
 // through LDS in a fixed order; epilogues as in skinny.hip: RMSNorm row scale (weight folded into W), residual, SiLU(gate)*up,
@@ -28,11 +30,16 @@ struct DgDev {
   float eps;
   int* bump;
   int nburst;   // bursts of 8 * LG chunks per wave
+  unsigned long long* prof; const int* pos; int prof_ld;
 };
 
 __device__ __forceinline__ void dg_dma16(const void* gsrc, unsigned char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void dg_dma16_nt(const void* gsrc, unsigned char* lds_wave_base) {   // aux 2 = nt: streamed-once weights
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2);
 }
 
 template <typename T> struct Vec4T;
@@ -46,11 +53,14 @@ __global__ __launch_bounds__(WMAX * 64) void dgemm_kernel(const DgDev p) {
   constexpr int NFRAG = FN * MF;
   constexpr bool PREFETCH_RES = NFRAG <= 4;
   typedef typename Vec4T<T>::type V4;
+  const unsigned long long t_start = p.prof ? (unsigned long long)wall_clock64() : 0ull;
+  const int prof_pos = p.prof ? *p.pos : 0;   // read up front: the lm_head launch advances the counter at its end
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, waves = (int)blockDim.x >> 6;
   const int lr = lane & 15, lg = lane >> 4;
   const int n_tile = blockIdx.x * 16 * FN, m_tile = blockIdx.y * 16 * MF;
-  unsigned char* stage = smem + (size_t)wave * (LG * MF * 2048);
+  unsigned char* stage = smem + (size_t)wave * (LG * (MF + FN) * 2048);   // [LG][MF] activation tiles, then [LG][FN] weight tiles
+  unsigned char* stage_w = stage + LG * MF * 2048;
   const long cbeg = (long)wave * p.nburst * (8 * LG);   // first 16-byte chunk (along K) of this wave
   const char* X = (const char*)p.X;
   const char* W = (const char*)p.W;
@@ -87,12 +97,14 @@ __global__ __launch_bounds__(WMAX * 64) void dgemm_kernel(const DgDev p) {
       xrow[b][h] = (long)m * p.ldx * (long)sizeof(T);
     }
   }
-  long wrow[FN];
+  long wrow[FN][2];
 #pragma unroll
-  for (int a = 0; a < FN; ++a) {
-    const int n = min(n_tile + a * 16 + lr, p.N - 1);
-    wrow[a] = (long)n * p.ldw * (long)sizeof(T) + lg * 16;
-  }
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int a = 0; a < FN; ++a) {
+      const int n = min(n_tile + a * 16 + h * 8 + r8, p.N - 1);
+      wrow[a][h] = (long)n * p.ldw * (long)sizeof(T);
+    }
 
   f32x4 acc[FN][MF];
 #pragma unroll
@@ -106,62 +118,69 @@ __global__ __launch_bounds__(WMAX * 64) void dgemm_kernel(const DgDev p) {
   for (int burst = 0; burst < p.nburst; ++burst) {
     const long c0 = cbeg + (long)burst * (8 * LG);
     if (burst) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the previous burst's fragment reads have left the staging area
-    // activations: whole lines by LDS-DMA (2 instructions per 16 rows x 128 bytes)
+    // Issue order = consumption order: [activation lines | weight lines] of group g (128 bytes of K) for g = 0 .. LG-1; memory
+    // returns in order, so group g has landed once at most (LG - 1 - g) * (2 MF + 2 FN) younger DMA requests are outstanding.
 #pragma unroll
-    for (int g = 0; g < LG; ++g)
+    for (int g = 0; g < LG; ++g) {
 #pragma unroll
       for (int b = 0; b < MF; ++b)
 #pragma unroll
         for (int h = 0; h < 2; ++h)
           dg_dma16(X + xrow[b][h] + (c0 + g * 8 + xsw[h]) * 16, stage + ((g * MF + b) * 2 + h) * 1024);
-    asm volatile("" ::: "memory");   // the weight loads below stay BEHIND the DMA issue (the counted wait relies on that order)
-    // weights: every chunk of the burst in flight
-    Chunk16 wv[KS][FN];
-#pragma unroll
-    for (int t = 0; t < KS; ++t)
-#pragma unroll
-      for (int a = 0; a < FN; ++a) wv[t][a] = __builtin_nontemporal_load((const Chunk16*)(W + wrow[a] + (c0 + 4 * t) * 16));
-    // the DMA lines were issued first and memory returns in order: they have landed once at most KS * FN loads are outstanding
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KS * FN) : "memory");
-    Chunk16 xa[KS][MF];
-#pragma unroll
-    for (int t = 0; t < KS; ++t)
-#pragma unroll
-      for (int b = 0; b < MF; ++b) {
-        const int j = (t & 1) * 4 + lg;   // chunk of the line; line g = t >> 1
-        xa[t][b] = *(const Chunk16*)(stage + (((t >> 1) * MF + b) * 128 + lr * 8 + (j ^ ((lr >> 1) & 7))) * 16);
-      }
-    if (do_norm) {
-#pragma unroll
-      for (int t = 0; t < KS; ++t)
-#pragma unroll
-        for (int b = 0; b < MF; ++b) {
-          if constexpr (sizeof(T) == 2) {
-            const bf16x8 xx = __builtin_bit_cast(bf16x8, xa[t][b]);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { const float f = (float)xx[u]; ssq[b] = fmaf(f, f, ssq[b]); }
-          } else {
-            const f32x4 xx = __builtin_bit_cast(f32x4, xa[t][b]);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) ssq[b] = fmaf(xx[u], xx[u], ssq[b]);
-          }
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < KS; ++t)
 #pragma unroll
       for (int a = 0; a < FN; ++a)
 #pragma unroll
-        for (int b = 0; b < MF; ++b) {
-          if constexpr (sizeof(T) == 2) {
-            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[t][a]),
-                                                                __builtin_bit_cast(bf16x8, xa[t][b]), acc[a][b], 0, 0, 0);
-          } else {
-            const f32x4 wf = __builtin_bit_cast(f32x4, wv[t][a]), xf = __builtin_bit_cast(f32x4, xa[t][b]);
+        for (int h = 0; h < 2; ++h)
+          dg_dma16_nt(W + wrow[a][h] + (c0 + g * 8 + xsw[h]) * 16, stage_w + ((g * FN + a) * 2 + h) * 1024);
+    }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u], xf[u], acc[a][b], 0, 0, 0);
+    for (int g = 0; g < LG; ++g) {
+      constexpr int PER = 2 * MF + 2 * FN;
+      if (g == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LG - 1) * PER) : "memory");
+      else if (g == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LG > 1 ? LG - 2 : 0) * PER) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      Chunk16 xa[2][MF], wa[2][FN];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int j = tt * 4 + lg;   // chunk of the line
+        const int slot = lr * 8 + (j ^ ((lr >> 1) & 7));
+#pragma unroll
+        for (int b = 0; b < MF; ++b) xa[tt][b] = *(const Chunk16*)(stage + ((g * MF + b) * 128 + slot) * 16);
+#pragma unroll
+        for (int a = 0; a < FN; ++a) wa[tt][a] = *(const Chunk16*)(stage_w + ((g * FN + a) * 128 + slot) * 16);
+      }
+      if (do_norm) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int b = 0; b < MF; ++b) {
+            if constexpr (sizeof(T) == 2) {
+              const bf16x8 xx = __builtin_bit_cast(bf16x8, xa[tt][b]);
+#pragma unroll
+              for (int u = 0; u < 8; ++u) { const float f = (float)xx[u]; ssq[b] = fmaf(f, f, ssq[b]); }
+            } else {
+              const f32x4 xx = __builtin_bit_cast(f32x4, xa[tt][b]);
+#pragma unroll
+              for (int u = 0; u < 4; ++u) ssq[b] = fmaf(xx[u], xx[u], ssq[b]);
+            }
           }
-        }
+      }
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int a = 0; a < FN; ++a)
+#pragma unroll
+          for (int b = 0; b < MF; ++b) {
+            if constexpr (sizeof(T) == 2) {
+              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa[tt][a]),
+                                                                  __builtin_bit_cast(bf16x8, xa[tt][b]), acc[a][b], 0, 0, 0);
+            } else {
+              const f32x4 wf = __builtin_bit_cast(f32x4, wa[tt][a]), xf = __builtin_bit_cast(f32x4, xa[tt][b]);
+#pragma unroll
+              for (int u = 0; u < 4; ++u) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u], xf[u], acc[a][b], 0, 0, 0);
+            }
+          }
+    }
   }
 
   // ---- combine the waves' K slices (fixed order w = 0 .. waves-1); the combine area aliases the staging areas
@@ -249,13 +268,18 @@ __global__ __launch_bounds__(WMAX * 64) void dgemm_kernel(const DgDev p) {
       }
     }
   }
+  if (p.prof && tid == 0) {
+    unsigned long long* slot = p.prof + (size_t)((blockIdx.x * 7 + blockIdx.y) % IVG_GEMM_PROF_SLOTS) * 2 * p.prof_ld;
+    atomicMax(slot + prof_pos, ~t_start);
+    atomicMax(slot + p.prof_ld + prof_pos, (unsigned long long)wall_clock64());
+  }
   if (p.bump && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { p.bump[0] += 1; p.bump[1] += 1; }
 }
 
 template <typename T, int MF, int FN, int LG, int WMAX>
 static int launch_dg(const DgDev& d, int waves, hipStream_t stream) {
   const int nfrag = FN * MF;
-  const int stage = waves * LG * MF * 2048;
+  const int stage = waves * LG * (MF + FN) * 2048;
   const int comb = waves * nfrag * 64 * 16 + waves * MF * 16 * 4;
   const int smem = std::max(stage, comb);
   if (smem > 160 * 1024 || waves > WMAX) return -1;
@@ -303,6 +327,11 @@ static const DgPick kDgPicks[] = {
     {1536, 6144, 4, 2, 4, 3},    // small: gate/up          7.1 (9.6)
     {6144, 768, 1, 1, 4, 3},     // small: down             7.2 (8.9)
     {1536, 16386, 4, 2, 2, 1},   // small: lm_head         14.3 (19.3)
+    {2048, 3072, 2, 2, 4, 2},    // medium (hidden 1024, intermediate 4096): q/k/v   6.5 (8.2)
+    {2048, 1024, 1, 1, 4, 2},    // medium: o-proj          4.2 (5.3)
+    {2048, 8192, 4, 2, 4, 2},    // medium: gate/up         8.6 (11.0)
+    {8192, 1024, 1, 1, 4, 2},    // medium: down            8.8 (11.3)
+    {2048, 16386, 4, 2, 2, 1},   // medium: lm_head        16.3 (21.0)
 };
 
 template <typename T, int LG>
@@ -344,7 +373,6 @@ int launch_dgemm(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
     auto wgs = [&](int mf, int fn) { return (long)cdiv(a.M, 16 * mf) * cdiv(a.N, 16 * fn); };
     while (MF > 1 && wgs(MF, FN) < 128) MF >>= 1;                 // narrow GEMMs: split the rows to fill the chip
     while (FN < 4 && wgs(MF, FN) > 512) FN <<= 1;                 // wide GEMMs (lm_head): fatter W tiles, fewer rounds
-    if (sp.waves * sp.lg * MF * 2048 > 160 * 1024) { while (MF > 1 && sp.waves * sp.lg * MF * 2048 > 160 * 1024) MF >>= 1; }
   }
   int waves = sp.waves, lgv = sp.lg, nburst = sp.nburst;
   for (const DgPick& k : kDgPicks) {
@@ -365,7 +393,16 @@ int launch_dgemm(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
     nburst = (int)(chunks / ((long)waves * 8 * lgv));
     if (glu && FN < 2) return (int)hipErrorInvalidValue;
   }
-  DgDev d{a.X, a.W, a.Y, a.M, a.N, a.K, a.ldx, a.ldw, a.ldy, a.flags, a.eps, a.bump, nburst};
+  // staging budget: waves * LG * (MF + FN) * 2 KiB of LDS.  Over budget: first more (shorter) bursts per wave -- the K partition over
+  // the waves, and so every sum order, stays what it is -- then fewer row tiles per workgroup
+  while (lgv > 1 && waves * lgv * (MF + FN) * 2048 > 160 * 1024) {
+    const int total = lgv * nburst;           // lines per wave
+    --lgv;
+    while (total % lgv != 0) --lgv;
+    nburst = total / lgv;
+  }
+  while (MF > 1 && waves * lgv * (MF + FN) * 2048 > 160 * 1024) MF >>= 1;
+  DgDev d{a.X, a.W, a.Y, a.M, a.N, a.K, a.ldx, a.ldw, a.ldy, a.flags, a.eps, a.bump, nburst, a.pos ? a.prof : nullptr, a.pos, a.prof_ld};
   int rc;
   if (dtype == BF16) rc = lgv == 3 ? launch_dg_t<bf16_t, 3>(d, MF, FN, waves, stream) : lgv == 2 ? launch_dg_t<bf16_t, 2>(d, MF, FN, waves, stream)
                                                                                      : launch_dg_t<bf16_t, 1>(d, MF, FN, waves, stream);

@@ -94,12 +94,16 @@ struct ivg_engine {
   ivg::ProfClass prof[IVG_K_COUNT];
   unsigned long long* attn_prof = nullptr;  // [layers][IVG_ATTN_PROF_SLOTS][2][Lmax] wall-clock stamps of the decode attention
   bool attn_prof_on = false;                // ivg_profile_enable(IVG_K_DECODE_ATTN): part of the step-graph key
+  unsigned long long* gemm_prof = nullptr;  // [layers * 4 + 1][IVG_GEMM_PROF_SLOTS][2][Lmax] stamps of the decode-step GEMMs (allocated on first use)
+  bool gemm_prof_on = false;                // ivg_profile_enable(IVG_K_DECODE_GEMM): part of the step-graph key
+  int gemm_prof_B = 0;
   int kv_len = 0, kv_B = 0;                 // the KV cache holds positions [0, kv_len) of kv_B trajectories (last generate call)
   // what that cache was built from, kept so that a step-wise caller's "same prefix" claim can be VERIFIED on the device:
   //   token path: the ids are in the persistent id buffer (gen_buf), the action table of the call in last_act;
   //   embeds path (ivg_generate_embeds): the input embeddings fed so far in emb_snap
   const float* final_norm = nullptr;        // model.norm.weight (fp32), for the hidden state handed to the caller
   const float* rew_w_raw = nullptr;         // reward_linear.weight as stored (applies to the post-norm hidden state)
+  const float* ar_w = nullptr; const float* ar_b = nullptr;   // action_recon_linear (optional, eval loss term only)
   char* emb_snap = nullptr;                 // [Bc][Lmax][H] llm dtype, allocated on the first embeds call
   bool snap_valid = false;                  // emb_snap holds the inputs of positions [0, kv_len)
   bool ids_valid = false;                   // gen_buf ids hold the tokens of positions [0, kv_len)

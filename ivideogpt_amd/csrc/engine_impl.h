@@ -37,7 +37,8 @@ struct Run {
   int prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const void* act_emb, int act_T, int ctx, bool all_slots,
               float* logits_all /* [B][L][V] or null */, float* logits_last /* [B][V] or null */, void* hidden_last,
               const void* embeds = nullptr /* [B][L][H] llm dtype: used instead of the embedding of ids */,
-              void* hidden_all = nullptr /* [B][L][H] llm dtype: post-final-norm hidden states (eval heads) */);
+              void* hidden_all = nullptr /* [B][L][H] llm dtype: post-final-norm hidden states (eval heads) */,
+              const int64_t* labels = nullptr, float* token_nll = nullptr /* [B][L]: shifted cross-entropy per position */);
   // embeds != null: llm.generate(inputs_embeds=...) -- the prompt is given as input embeddings, only the n_new tokens are
   // returned (new_ids_out [B][n_new]); hidden_out [B][H]: post-norm hidden state of the last forward pass
   int generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, int n_new, const float* actions, int act_T, int ctx,

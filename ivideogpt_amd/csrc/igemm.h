@@ -59,7 +59,13 @@ struct SkinnyArgs {
   int flags = 0;           // IG_GLU | IG_OUT_F32 | IG_RESIDUAL (Y += ..., in place) | SK_NORM
   float eps = 1e-6f;       // SK_NORM
   int* bump = nullptr;     // optional pair of device ints incremented once at the end (StepState advance)
+  // measurement hook (bench.py): launch window on the 100 MHz wall clock, [IVG_GEMM_PROF_SLOTS][starts prof_ld | ends prof_ld],
+  // indexed by the decode position *pos (the launch runs inside a replayed graph: HIP events cannot bracket it)
+  unsigned long long* prof = nullptr;
+  const int* pos = nullptr;
+  int prof_ld = 0;
 };
+#define IVG_GEMM_PROF_SLOTS 8
 int launch_skinny(const SkinnyArgs& a, DType dtype, hipStream_t stream);
 // dgemm.hip: the same contract with the activations staged as whole cache lines; -1 when the shape is not covered
 int launch_dgemm(const SkinnyArgs& a, DType dtype, hipStream_t stream);

@@ -994,6 +994,93 @@ int launch_final_hidden(const void* x, const float* w, void* out, int B, int H, 
   return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ eval heads
+// Shifted cross-entropy of teacher-forced logits (HF ForCausalLM loss, train_gpt.py:356-376): row r = (b, l) of a chunk of logits
+// [rows][V] fp32 predicts labels[b][l + 1]; nll[r] = logsumexp(logits[r]) - logits[r][target], 0 where the target is -100 (or l is
+// the last position).  One workgroup per row, fixed-order reductions.
+__global__ __launch_bounds__(256) void ce_rows_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, long row0,
+                                                      int L, int V, float* __restrict__ nll) {
+  __shared__ float red[8];
+  const long r = row0 + blockIdx.x;
+  const int l = (int)(r % L), tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const long tgt = l + 1 < L ? labels[r + 1] : -100;
+  if (tgt < 0 || tgt >= V) { if (tid == 0) nll[r] = 0.f; return; }
+  const float* row = logits + (long)blockIdx.x * V;
+  float mx = -INFINITY;
+  for (int i = tid; i < V; i += 256) mx = fmaxf(mx, row[i]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wv] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int i = tid; i < V; i += 256) sum += expf(row[i] - mx);
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wv] = sum;
+  __syncthreads();
+  if (tid == 0) nll[r] = logf((red[4] + red[5]) + (red[6] + red[7])) + mx - row[tgt];
+}
+
+int launch_ce_rows(const float* logits, const int64_t* labels, long row0, int rows, int L, int V, float* nll, hipStream_t st) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(ce_rows_kernel, dim3((unsigned)rows), dim3(256), 0, st, logits, labels, row0, L, V, nll);
+  return (int)hipGetLastError();
+}
+
+// out[b] = { sum_l nll[b][l], number of positions l whose target labels[b][l + 1] is not ignored }
+__global__ __launch_bounds__(256) void ce_reduce_kernel(const float* __restrict__ nll, const int64_t* __restrict__ labels, int L, int V,
+                                                        float* __restrict__ out) {
+  __shared__ float rs[4], rc[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float s = 0.f, c = 0.f;
+  for (int l = tid; l + 1 < L; l += 256) {
+    const long t = labels[(long)b * L + l + 1];
+    if (t >= 0 && t < V) { s += nll[(long)b * L + l]; c += 1.f; }
+  }
+  s = wave_sum(s); c = wave_sum(c);
+  if ((tid & 63) == 0) { rs[tid >> 6] = s; rc[tid >> 6] = c; }
+  __syncthreads();
+  if (tid == 0) { out[2 * b] = (rs[0] + rs[1]) + (rs[2] + rs[3]); out[2 * b + 1] = (rc[0] + rc[1]) + (rc[2] + rc[3]); }
+}
+
+int launch_ce_reduce(const float* nll, const int64_t* labels, int B, int L, int V, float* out, hipStream_t st) {
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL(ce_reduce_kernel, dim3((unsigned)B), dim3(256), 0, st, nll, labels, L, V, out);
+  return (int)hipGetLastError();
+}
+
+// action reconstruction error (action_model.py:187-196): every position p >= prelude of trajectory b predicts the action of its
+// frame slot i = (p - prelude) / 17, a_hat = W h[b][p] + bias; out[b] = sum over positions and action dims of (a_hat - a)^2.
+template <typename T>
+__global__ __launch_bounds__(256) void action_recon_kernel(const T* __restrict__ hidden, const float* __restrict__ W, const float* __restrict__ bias,
+                                                           const float* __restrict__ act, int L, int H, int A, int act_T, int ctx, int prelude,
+                                                           float* __restrict__ out) {
+  __shared__ float red[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  float err = 0.f;   // lane 0 of every wave accumulates the positions that wave handles (fixed order)
+  for (int p = prelude + wv; p < L; p += 4) {
+    const int slot = (p - prelude) / 17;
+    const T* h = hidden + ((long)b * L + p) * H;
+    for (int a = 0; a < A; ++a) {
+      float s = 0.f;
+      for (int c = lane; c < H; c += 64) s = fmaf(to_f32(h[c]), W[(long)a * H + c], s);
+      s = wave_sum(s);
+      const float d = s + bias[a] - act[((long)b * act_T + ctx - 1 + slot) * A + a];
+      err = fmaf(d, d, err);
+    }
+  }
+  if (lane == 0) red[wv] = err;
+  __syncthreads();
+  if (tid == 0) out[b] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+int launch_action_recon(const void* hidden, const float* W, const float* bias, const float* act, int B, int L, int H, int A, int act_T,
+                        int ctx, int prelude, float* out, DType dt, hipStream_t st) {
+  if (B <= 0) return 0;
+  if (dt == BF16) hipLaunchKernelGGL(action_recon_kernel<bf16_t>, dim3((unsigned)B), dim3(256), 0, st, (const bf16_t*)hidden, W, bias, act, L, H, A, act_T, ctx, prelude, out);
+  else hipLaunchKernelGGL(action_recon_kernel<float>, dim3((unsigned)B), dim3(256), 0, st, (const float*)hidden, W, bias, act, L, H, A, act_T, ctx, prelude, out);
+  return (int)hipGetLastError();
+}
+
 // flag[0] += number of 4-byte words that differ between rows of a and b (row r at a + r * a_stride bytes; row_bytes % 4 == 0).
 // Used to verify that a kept KV cache was built from exactly the prefix a step-wise caller presents again.
 __global__ __launch_bounds__(256) void compare_rows_kernel(const unsigned* __restrict__ a, long a_stride, const unsigned* __restrict__ b,

@@ -91,8 +91,23 @@ int launch_add_rows(void* x, long x_stride, const void* add, long add_stride, in
 int launch_rowdot(const void* h, const float* w, const float* bias, float* out, int B, int H, float eps, DType dt, hipStream_t st);
 // out[b] = final RMSNorm of the residual rows x[b] as HF reports them in hidden_states[-1] (normalised row rounded to T, times w)
 int launch_final_hidden(const void* x, const float* w, void* out, int B, int H, float eps, DType dt, hipStream_t st);
+// eval heads: shifted cross-entropy per row of a logits chunk, per-trajectory (sum, count), action reconstruction squared error
+int launch_ce_rows(const float* logits, const int64_t* labels, long row0, int rows, int L, int V, float* nll, hipStream_t st);
+int launch_ce_reduce(const float* nll, const int64_t* labels, int B, int L, int V, float* out, hipStream_t st);
+int launch_action_recon(const void* hidden, const float* W, const float* bias, const float* act, int B, int L, int H, int A, int act_T,
+                        int ctx, int prelude, float* out, DType dt, hipStream_t st);
 // *flag += number of differing 32-bit words between `rows` rows of row_bytes bytes (strides in bytes)
 int launch_compare_rows(const void* a, long a_stride_bytes, const void* b, long b_stride_bytes, int rows, long row_bytes, int* flag,
                         hipStream_t st);
+
+// ---- ingest.hip
+// uint8 frames [T][H][W][3] -> planar [T][3][R][R] in [0, 1]: / 255, optional centre crop, antialiased bilinear resize (ATen semantics)
+int launch_ingest(const unsigned char* src, int T, int H, int W, int crop, void* dst, DType dst_dt, int R, hipStream_t st);
+
+// ---- metrics.hip
+// per-trajectory (mse, psnr, ssim) of predicted frames, mean over frames, best of the n_samples / B samples per trajectory
+size_t frame_metrics_ws_bytes(int n_samples, int T, int H, int W);
+int launch_frame_metrics(const void* gt, DType gt_dt, int B, int T_gt, int gt_t0, const float* pred, int n_samples, int T_pr, int pr_t0, int T,
+                         int H, int W, float* rows, void* ws, hipStream_t st);
 
 }  // namespace ivg

@@ -76,7 +76,8 @@ static bool flash_prefill_covers(DType dt, int hd) {
 }
 
 int Run::prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const void* act_emb, int act_T, int ctx, bool all_slots,
-                 float* logits_all, float* logits_last, void* hidden_last, const void* embeds, void* hidden_all) {
+                 float* logits_all, float* logits_last, void* hidden_last, const void* embeds, void* hidden_all, const int64_t* labels,
+                 float* token_nll) {
   const ivg_config& c = e->cfg;
   const DType dt = e->llm_dt;
   const int H = c.hidden_size, I = c.intermediate_size, V = c.vocab_size, heads = e->heads, hd = e->hd, Lmax = e->Lmax;
@@ -161,6 +162,19 @@ int Run::prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const voi
     ConvW wl; wl.w = e->lm_head; wl.cin = H; wl.cout = V;
     IVG_TRY(linear(dt, xn, M, wl, logits_all, nullptr, 0, 1));
   }
+  if (token_nll) {
+    // loss without the [B][L][V] fp32 logits tensor (3.1 GB at B = 64, L = 751): lm_head over chunks of rows, each chunk reduced
+    // to its per-position cross-entropy before the next one overwrites it
+    const long Rc = std::min<long>(M, 4096);
+    float* chunk = (float*)e->ws.alloc((size_t)Rc * V * 4);
+    if (!planning && !logits_all) CK(launch_add_rmsnorm(x, H, nullptr, 0, e->ones, xn, (int)M, H, c.rms_norm_eps, dt, st));
+    ConvW wl; wl.w = e->lm_head; wl.cin = H; wl.cout = V;
+    for (long r0 = 0; r0 < M; r0 += Rc) {
+      const long rows = std::min(Rc, M - r0);
+      IVG_TRY(linear(dt, xn + (size_t)r0 * H * esz(dt), rows, wl, chunk, nullptr, 0, 1));
+      if (!planning) CK(launch_ce_rows(chunk, labels, r0, (int)rows, L, V, token_nll, st));
+    }
+  }
   if (logits_last && !planning) {
     // last position of every sequence -> residual rows hidden_last [B][H]; final RMSNorm is fused into the lm_head GEMM
     CK((int)hipMemcpy2DAsync(hidden_last, (size_t)H * esz(dt), x + (size_t)(L - 1) * H * esz(dt), (size_t)L * H * esz(dt),
@@ -202,29 +216,39 @@ static int step_chain(ivg_engine* e, hipStream_t st, const GenBuf& g, int chain,
   if (!forward) return 0;
   // 5 launches per layer: RMSNorms are fused into the consuming GEMMs (weights pre-multiplied by the norm weight,
   // row scale computed from the activations the GEMM streams anyway), residual adds into the producing GEMMs.
+  const size_t gp_ld = (size_t)IVG_GEMM_PROF_SLOTS * 2 * e->Lmax;
+  auto gprof = [&](SkinnyArgs& a, int idx) {
+    if (!e->gemm_prof_on || !e->gemm_prof) return;
+    a.prof = e->gemm_prof + (size_t)idx * gp_ld; a.pos = (const int*)state; a.prof_ld = e->Lmax;
+  };
   for (int l = 0; l < c.num_layers; ++l) {
     const LayerW& w = e->layers[l];
     SkinnyArgs s;
     s.X = x; s.W = w.wqkv; s.Y = qkv; s.M = B; s.N = 3 * H; s.K = H; s.ldx = H; s.ldw = H; s.ldy = 3 * H;
     s.flags = SK_NORM; s.eps = c.rms_norm_eps;
+    gprof(s, 4 * l + 0);
     CK(launch_skinny(s, dt, st));
     CK(launch_decode_attn(qkv, kc_ptr(e, l, 0) + kv_off, kc_ptr(e, l, 1) + kv_off, attn, e->rope_cos, e->rope_sin, B, e->heads, e->hd,
                           e->Lmax, state, e->attn_prof_on ? e->attn_prof + (size_t)l * IVG_ATTN_PROF_SLOTS * 2 * e->Lmax : nullptr, dt, st));
     SkinnyArgs o;
     o.X = attn; o.W = w.wo; o.Y = x; o.M = B; o.N = H; o.K = H; o.ldx = H; o.ldw = H; o.ldy = H; o.flags = IG_RESIDUAL;
+    gprof(o, 4 * l + 1);
     CK(launch_skinny(o, dt, st));
     SkinnyArgs u;
     u.X = x; u.W = w.wgu; u.Y = act; u.M = B; u.N = 2 * I; u.K = H; u.ldx = H; u.ldw = H; u.ldy = I;
     u.flags = IG_GLU | SK_NORM; u.eps = c.rms_norm_eps;
+    gprof(u, 4 * l + 2);
     CK(launch_skinny(u, dt, st));
     SkinnyArgs d;
     d.X = act; d.W = w.wdown; d.Y = x; d.M = B; d.N = H; d.K = I; d.ldx = I; d.ldw = I; d.ldy = H; d.flags = IG_RESIDUAL;
+    gprof(d, 4 * l + 3);
     CK(launch_skinny(d, dt, st));
   }
   SkinnyArgs lm;
   lm.X = x; lm.W = e->lm_head; lm.Y = logits; lm.M = B; lm.N = V; lm.K = H; lm.ldx = H; lm.ldw = H; lm.ldy = V;
   lm.flags = IG_OUT_F32 | SK_NORM; lm.eps = c.rms_norm_eps;
   lm.bump = (int*)state;  // pos += 1, j += 1 once the last reader of this chain's state (its last attention) is done
+  gprof(lm, 4 * c.num_layers);
   CK(launch_skinny(lm, dt, st));
   return 0;
 }
@@ -272,6 +296,10 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
   e->snap_valid = false; e->ids_valid = false;
   for (int b0 = 0; b0 < B; b0 += g.Bc) {
     const int Bc = std::min(g.Bc, B - b0);
+    if (e->gemm_prof_on && e->gemm_prof) {
+      CK((int)hipMemsetAsync(e->gemm_prof, 0, (size_t)(4 * c.num_layers + 1) * IVG_GEMM_PROF_SLOTS * 2 * e->Lmax * 8, st));
+      e->gemm_prof_B = Bc;
+    }
     if (e->attn_prof_on) {  // fresh launch windows for this call: every stamp slot back to 0 (= not stamped)
       CK((int)hipMemsetAsync(e->attn_prof, 0, (size_t)c.num_layers * IVG_ATTN_PROF_SLOTS * 2 * e->Lmax * 8, st));
       e->attn_prof_B = Bc;
@@ -317,7 +345,7 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
     // step 1 eagerly (also performs every kernel's one-time attribute setup), then replay a captured step graph
     const std::string key = std::to_string(Bc) + ":" + std::to_string(nc) + ":" + (uniforms ? "s" : "g") + ":" + std::to_string(top_k) + ":" +
                             std::to_string(sa.forced_period) + ":" + std::to_string(ctx) + ":" + std::to_string(act_T) + ":" +
-                            std::to_string(L0) + (e->attn_prof_on ? ":p" : "");   // (the same step graph serves both entry modes)
+                            std::to_string(L0) + (e->attn_prof_on ? ":p" : "") + (e->gemm_prof_on ? ":q" : "");   // (the same step graph serves both entry modes)
     // reward head: reads the residual stream left by the LAST forward pass, i.e. before the final decide-only step
     // overwrites it with the embedding of the last token (mbrl/video_predictor.py:311-313: hidden state of the last step)
     auto reward = [&]() -> int {

@@ -186,6 +186,24 @@ class Engine:
                 if t is not None:
                     t.record_stream(self._stream)
 
+    def eval_forward(self, ids, labels, token_nll, loss_rows, actions=None, ctx=1, hidden=None):
+        B, L = ids.shape
+        act_T = actions.shape[1] if actions is not None else 0
+        with self.stream() as s:
+            self.check(self.lib.ivg_eval_forward(self.h, _ptr(ids), _ptr(labels), B, L, _ptr(actions), act_T, int(ctx), _ptr(token_nll),
+                                                 _ptr(loss_rows), _ptr(hidden), s), "eval_forward")
+            for t in (ids, labels, token_nll, loss_rows, actions, hidden):
+                if t is not None:
+                    t.record_stream(self._stream)
+
+    def action_recon_sqerr(self, hidden, actions, ctx, prelude, out):
+        B, L = hidden.shape[:2]
+        with self.stream() as s:
+            self.check(self.lib.ivg_action_recon_sqerr(self.h, _ptr(hidden), _ptr(actions), B, L, actions.shape[1], int(ctx), int(prelude),
+                                                       _ptr(out), s), "action_recon_sqerr")
+            for t in (hidden, actions, out):
+                t.record_stream(self._stream)
+
     def profile_enable(self, kclass, on=True):
         self.check(self.lib.ivg_profile_enable(self.h, kclass, int(on)), "profile_enable")
 

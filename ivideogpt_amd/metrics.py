@@ -1,0 +1,41 @@
+"""Frame metrics of predicted clips on the MI355X (libivg ``ivg_frame_metrics``): the reference's ``Evaluator.forward``
+(/root/reference/ivideogpt/utils/video_metric.py:63-100) without LPIPS / FVD (external network weights): per-frame MSE,
+PSNR and SSIM (piqa semantics), mean over a trajectory's frames, best of the ``t`` samples drawn per trajectory."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .packing import dtype_code
+
+
+@torch.no_grad()
+def frame_metric_rows(video_gt, video_pred, gt_t0=0, pred_t0=0, frames=None):
+    """video_gt (B, T, 3, H, W) float32 / bfloat16 on the GPU; video_pred float32 (t * B, T', 3, H, W), sample k of trajectory b
+    at row k * B + b.  Frames [gt_t0, gt_t0 + frames) of the ground truth are compared with [pred_t0, pred_t0 + frames) of the
+    prediction (default: everything after the offsets).  -> float32 (B, 3) rows (mse, psnr, ssim), best of t per trajectory."""
+    lib = _lib.load()
+    if not video_gt.is_cuda:
+        raise RuntimeError("frame metrics run on the MI355X only (no CPU path)")
+    gt = video_gt if video_gt.dtype in (torch.float32, torch.bfloat16) else video_gt.float()
+    gt, pred = gt.contiguous(), video_pred.float().contiguous()
+    B, Tg, _, H, W = gt.shape
+    n, Tp = pred.shape[:2]
+    T = frames if frames is not None else min(Tg - gt_t0, Tp - pred_t0)
+    rows = torch.empty(B, 3, dtype=torch.float32, device=gt.device)
+    nbytes = lib.ivg_frame_metrics_ws_bytes(n, T, H, W)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=gt.device)
+    st = C.c_void_p(torch.cuda.current_stream(gt.device).cuda_stream)
+    _lib.check(lib.ivg_frame_metrics(C.c_void_p(gt.data_ptr()), dtype_code(gt.dtype), B, Tg, gt_t0, C.c_void_p(pred.data_ptr()), n, Tp, pred_t0,
+                                     T, H, W, C.c_void_p(rows.data_ptr()), C.c_void_p(ws.data_ptr()), nbytes, st), None, "frame_metrics")
+    return rows
+
+
+class Evaluator:
+    """``Evaluator(video_1, video_2)`` of the reference's eval loop (train_gpt.py:469-472) -> (mse, psnr, ssim) scalars: the mean
+    over trajectories of the best-of-t rows (LPIPS and FVD need network weights that do not ship: not provided)."""
+
+    def __call__(self, video_1, video_2):
+        rows = frame_metric_rows(video_1, video_2)
+        m = rows.mean(0)
+        return m[0], m[1], m[2]

@@ -88,6 +88,9 @@ def pack_llama(sd, cfg, device, code, prefix=""):
     if prefix and "action_linear.weight" in sd:
         out["llm.action_linear.weight"] = sd["action_linear.weight"].detach().to(device=device, dtype=torch.float32).contiguous()
         out["llm.action_linear.bias"] = sd["action_linear.bias"].detach().to(device=device, dtype=torch.float32).contiguous()
+    if prefix and "action_recon_linear.weight" in sd:
+        out["llm.action_recon_linear.weight"] = sd["action_recon_linear.weight"].detach().to(device=device, dtype=torch.float32).contiguous()
+        out["llm.action_recon_linear.bias"] = sd["action_recon_linear.bias"].detach().to(device=device, dtype=torch.float32).contiguous()
     if "reward_linear.weight" in sd:
         out["llm.reward_linear.weight"] = (sd["reward_linear.weight"].detach().to(device=device, dtype=torch.float32).reshape(-1)
                                            * fnorm).contiguous()   # reward head reads the final-normed hidden state

@@ -23,10 +23,10 @@ def predict_frames(tokenizer, model, pixel_values, context_length, future_length
 
 
 @torch.no_grad()
-def frame_metrics(pred, target):
-    """Per-trajectory rows [B, 4]: (mse, psnr, mean abs err, max abs err) over the predicted frames -- the payload of the
-    one collective of the multi-GPU path (the reference gathers mse/psnr/ssim/lpips, train_gpt.py:476-479)."""
-    d = (pred.float() - target.float())
-    mse = d.pow(2).flatten(1).mean(1)
-    psnr = -10.0 * torch.log10(mse.clamp_min(1e-12))
-    return torch.stack([mse, psnr, d.abs().flatten(1).mean(1), d.abs().flatten(1).amax(1)], 1)
+def frame_metrics(pred, target, first_frame=0):
+    """Per-trajectory rows [B, 3] = (mse, psnr, ssim) over the frames from ``first_frame`` on, best of the t = pred.shape[0] /
+    target.shape[0] samples per trajectory -- the reference's Evaluator semantics (ivideogpt/utils/video_metric.py:63-100, piqa
+    PSNR / SSIM) computed by libivg ``ivg_frame_metrics``; the payload of the one collective of the multi-GPU path
+    (the reference gathers mse / psnr / ssim / lpips, train_gpt.py:476-479)."""
+    from .metrics import frame_metric_rows
+    return frame_metric_rows(target, pred, gt_t0=first_frame, pred_t0=first_frame)

@@ -18,7 +18,58 @@ import torch
 
 from . import weights as W
 from .engine import Engine
-from .packing import dtype_code, pack_llama
+from .packing import dtype_code, pack_llama, torch_dtype
+
+
+class _Embedding:
+    """What ``llm.get_input_embeddings()`` returns (an ``nn.Embedding`` in HF): callable on int64 ids -> (…, hidden) rows of
+    ``model.embed_tokens.weight`` in the engine's transformer dtype (libivg ``ivg_embed_tokens``)."""
+
+    def __init__(self, llm):
+        self._llm = llm
+
+    def __call__(self, input_ids):
+        llm = self._llm
+        ids = input_ids.to(device=llm.device, dtype=torch.int64)
+        shape = ids.shape
+        ids2 = ids.reshape(-1, shape[-1]).contiguous() if ids.dim() > 1 else ids.reshape(1, -1).contiguous()
+        out = torch.empty(*ids2.shape, llm._cfg["hidden_size"], dtype=llm.torch_dtype, device=llm.device)
+        llm._ensure(ids2.shape[0]).embed_tokens(ids2, out)
+        return out.reshape(*shape, -1)
+
+    forward = __call__
+
+
+class _ActionLinear:
+    """``HeadModelWithAction.action_linear`` (action_model.py:36): float (…, action_dim) -> (…, hidden), transformer dtype."""
+
+    def __init__(self, llm):
+        self._llm = llm
+
+    def __call__(self, action):
+        llm = self._llm
+        a = action.to(device=llm.device, dtype=torch.float32).contiguous()
+        out = torch.empty(*a.shape[:-1], llm._cfg["hidden_size"], dtype=llm.torch_dtype, device=llm.device)
+        llm._ensure(max(1, a.shape[0] if a.dim() > 1 else 1)).action_linear(a, out)
+        return out
+
+    forward = __call__
+
+
+class _RewardLinear:
+    """``HeadModelWithAction.reward_linear`` (action_model.py:41): post-norm hidden states (…, hidden) -> float32 (…, 1)."""
+
+    def __init__(self, llm):
+        self._llm = llm
+
+    def __call__(self, hidden):
+        llm = self._llm
+        h = hidden.to(device=llm.device, dtype=llm.torch_dtype).contiguous()
+        out = torch.empty(*h.shape[:-1], 1, dtype=torch.float32, device=llm.device)
+        llm._ensure(max(1, h.shape[0] if h.dim() > 1 else 1)).reward_linear(h, out)
+        return out
+
+    forward = __call__
 
 
 class LlamaForCausalLM:
@@ -30,6 +81,7 @@ class LlamaForCausalLM:
         self._sd, self._prefix = state_dict, prefix
         self._action_dim, self._reward = action_dim, reward_prediction
         self.dtype = dtype
+        self.torch_dtype = torch_dtype(dtype_code(dtype))
         self.device = torch.device("cpu")
         self._engine = None
 
@@ -102,11 +154,32 @@ class LlamaForCausalLM:
             return None
         return torch.rand(B, n, device=self.device, dtype=torch.float32, generator=generator)
 
+    def get_input_embeddings(self):
+        return _Embedding(self)
+
     @torch.no_grad()
     def generate(self, input_ids=None, do_sample=True, temperature=1.0, top_k=100, max_new_tokens=None, pad_token_id=None,
-                 generator=None, uniforms=None, **unused):
-        """-> int64 (B, L0 + max_new_tokens), prompt included (HF convention for ``input_ids`` prompts)."""
+                 generator=None, uniforms=None, inputs_embeds=None, return_dict_in_generate=False, output_hidden_states=False,
+                 use_cache=True, **unused):
+        """``input_ids`` prompt -> int64 (B, L0 + max_new_tokens), prompt included (HF convention).
+        ``inputs_embeds`` prompt (B, L0, hidden) -> only the new tokens (B, max_new_tokens), as HF does for embeddings prompts
+        (action_model.py:101-110, mbrl/video_predictor.py:298-313).  With ``return_dict_in_generate`` the result has
+        ``.sequences`` and, with ``output_hidden_states``, ``.hidden_states`` of which only what the callers read exists:
+        ``hidden_states[-1][-1]`` = last layer (post final norm) of the LAST forward pass, (B, 1, hidden).
+        When the engine's KV cache was built from exactly ``inputs_embeds[:, :-1]`` (the step-wise rollout: previous prompt +
+        the embeddings of the tokens it generated), only the last row is fed -- verified on the device, never assumed."""
         assert temperature == 1.0, "the reference always samples at temperature 1.0"
+        if inputs_embeds is not None:
+            emb = inputs_embeds.to(device=self.device, dtype=self.torch_dtype).contiguous()
+            B, L0, _ = emb.shape
+            out = torch.empty(B, max_new_tokens, dtype=torch.int64, device=self.device)
+            hidden = torch.empty(B, 1, emb.shape[-1], dtype=self.torch_dtype, device=self.device) if output_hidden_states else None
+            u = uniforms if uniforms is not None else self._uniforms(B, max_new_tokens, do_sample, generator)
+            self.last_generate_reused_cache = self._ensure(B).generate_embeds(
+                emb, max_new_tokens, out, hidden=hidden, uniforms=u, top_k=top_k or self._cfg["vocab_size"], allow_reuse=use_cache)
+            if not return_dict_in_generate:
+                return out
+            return SimpleNamespace(sequences=out, hidden_states=((hidden,),) if output_hidden_states else None)
         ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
         B, L0 = ids.shape
         out = torch.empty(B, L0 + max_new_tokens, dtype=torch.int64, device=self.device)
@@ -123,13 +196,32 @@ class LlamaForCausalLM:
         self._ensure(B).logits(ids, out)
         return out
 
-    def __call__(self, input_ids=None, labels=None, **unused):
-        lg = self.logits(input_ids)
-        loss = None
-        if labels is not None:  # HF shifted cross-entropy, ignore_index -100 (train_gpt.py:364-376)
-            loss = torch.nn.functional.cross_entropy(lg[:, :-1].reshape(-1, lg.shape[-1]), labels[:, 1:].reshape(-1).to(lg.device),
-                                                     ignore_index=-100)
-        return SimpleNamespace(logits=lg, loss=loss)
+    @torch.no_grad()
+    def _eval_forward(self, input_ids, labels, action=None, ctx=1, want_hidden=False, frames=32):
+        """-> namespace(loss, token_nll (B, L), sample_loss (B), sample_perplexity (B), hidden_states or None): HF shifted
+        cross-entropy (ignore_index -100; mean over the batch's valid targets) computed by libivg ``ivg_eval_forward`` without the
+        (B, L, vocab) logits tensor."""
+        ids = input_ids.to(device=self.device, dtype=torch.int64).contiguous()
+        lab = labels.to(device=self.device, dtype=torch.int64).contiguous()
+        B, L = ids.shape
+        nll = torch.empty(B, L, dtype=torch.float32, device=self.device)
+        rows = torch.empty(B, 2, dtype=torch.float32, device=self.device)
+        hidden = torch.empty(B, L, self._cfg["hidden_size"], dtype=self.torch_dtype, device=self.device) if want_hidden else None
+        act = action.to(device=self.device, dtype=torch.float32).contiguous() if action is not None else None
+        self._ensure(B, frames).eval_forward(ids, lab, nll, rows, actions=act, ctx=ctx, hidden=hidden)
+        sums, counts = rows[:, 0], rows[:, 1]
+        per = sums / counts.clamp_min(1.0)
+        return SimpleNamespace(loss=sums.sum() / counts.sum().clamp_min(1.0), token_nll=nll, sample_loss=per,
+                               sample_perplexity=torch.exp(per), hidden_states=(hidden,) if want_hidden else None, logits=None)
+
+    def __call__(self, input_ids=None, labels=None, output_hidden_states=False, **unused):
+        """``model(input_ids=tokens, labels=labels)`` of the eval loop (train_gpt.py:356-376): ``.loss`` (+ per-sample loss /
+        perplexity); without labels: ``.logits`` (B, L, vocab) fp32."""
+        if labels is None:
+            return SimpleNamespace(logits=self.logits(input_ids), loss=None)
+        return self._eval_forward(input_ids, labels, want_hidden=output_hidden_states)
+
+    forward = __call__
 
 
 class HeadModelWithAction:
@@ -150,7 +242,15 @@ class HeadModelWithAction:
         self.reward_prediction = reward_prediction
         self.action_recon = action_recon
         llm._action_dim, llm._reward, llm._prefix = action_dim, reward_prediction, "llm."
+        llm._drop_engine()   # an engine built for the bare llm has no action / reward head
         self.device = llm.device
+        self.action_linear = _ActionLinear(llm)
+        if reward_prediction:
+            self.reward_linear = _RewardLinear(llm)
+
+    def get_input_embeddings(self, input_ids):
+        """action_model.py:47-54."""
+        return self.llm.get_input_embeddings()(input_ids)
 
     def load_state_dict(self, sd, strict=True):
         if strict:
@@ -189,6 +289,36 @@ class HeadModelWithAction:
         llm._ensure(B, act.shape[1]).generate(ids, max_new_tokens, out, actions=act, ctx=self.context, uniforms=u,
                                               top_k=top_k or llm._cfg["vocab_size"], reward=reward, reuse_kv=reuse_cache)
         return (out, reward) if return_reward else out
+
+    @torch.no_grad()
+    def __call__(self, input_ids=None, attention_mask=None, labels=None, position_ids=None, action=None):
+        """``HeadModelWithAction.forward`` (action_model.py:154-205) as the eval loop calls it (train_gpt.py:356-376):
+        ``x.loss`` = HF shifted cross-entropy (+ ``action_recon`` * MSE of the reconstructed actions, :187-196); with
+        ``reward_prediction`` returns ``(x, reward_pred)`` with ``reward_pred`` (B, segment - context, 1) read from the hidden
+        state of the last token of every predicted frame (:198-204).  No logits tensor is materialised (``x.logits`` is None;
+        ``self.logits(ids, action)`` returns them when needed)."""
+        assert attention_mask is None and position_ids is None, "the reference's callers never pass masks / position ids"
+        llm = self.llm
+        F = self.segment_length - self.context
+        need_hidden = bool(self.reward_prediction or self.action_recon)
+        if labels is None:
+            return SimpleNamespace(logits=self.logits(input_ids, action), loss=None)
+        x = llm._eval_forward(input_ids, labels, action=action, ctx=self.context, want_hidden=need_hidden, frames=action.shape[1])
+        hidden = x.hidden_states[-1] if need_hidden else None
+        if self.action_recon:
+            B, L = hidden.shape[:2]
+            act = action.to(device=llm.device, dtype=torch.float32).contiguous()
+            err = torch.empty(B, dtype=torch.float32, device=llm.device)
+            llm._engine.action_recon_sqerr(hidden, act, self.context, self.prelude_tokens_num, err)
+            self.action_recon_loss = err.sum() / (B * (L - self.prelude_tokens_num) * self.action_dim)
+            x.loss = x.loss + self.action_recon * self.action_recon_loss
+        if self.reward_prediction:
+            start = self.prelude_tokens_num + torch.arange(F, device=llm.device) * (self.tokens_num_per_dyna + 1)
+            reward_pred = self.reward_linear(hidden[:, start + self.tokens_num_per_dyna])   # (B, F, 1)
+            return x, reward_pred
+        return x
+
+    forward = __call__
 
     @torch.no_grad()
     def logits(self, input_ids, action):

@@ -207,8 +207,8 @@ def random_tokenizer_state_dict(cfg, seed=0, codebook_std=None):
     return random_state_dict(tokenizer_param_shapes(cfg), seed, codebook_std)
 
 
-def random_llama_state_dict(cfg, seed=0, action_dim=None, reward_prediction=False):
-    return random_state_dict(llama_param_shapes(cfg, action_dim, reward_prediction), seed)
+def random_llama_state_dict(cfg, seed=0, action_dim=None, reward_prediction=False, action_recon=False):
+    return random_state_dict(llama_param_shapes(cfg, action_dim, reward_prediction, action_recon), seed)
 
 
 def validate_state_dict(sd, shapes, what):

@@ -185,3 +185,24 @@ def generate_reference_algorithm(model, input_ids, n_new, top_k=100, uniforms=No
         embeds = torch.cat([embeds, model.embed(new)], 1)
         tokens = torch.cat([tokens, new], 1)
     return tokens[:, :-1]
+
+
+@torch.no_grad()
+def eval_forward(model, input_ids, labels, action_embeds=None, ctx=None, n_future=None, tokens_per_dyn=16):
+    """Teacher-forced eval forward with labels: ``LlamaForCausalLM.forward(labels=...)`` (HF shifted cross-entropy, ignore_index
+    -100, mean over the batch's valid targets) and ``HeadModelWithAction.forward`` (action embeddings
+    ``action_embeds[:, ctx-1:-1]`` added on the sdf slots, ivideogpt/transformer/action_model.py:170-178).
+    -> dict(loss, token_nll [B, L] (0 where ignored), sample_loss [B], hidden [B, L, H] post final norm)."""
+    x = model.embed(input_ids)
+    if action_embeds is not None:
+        x = x.clone()
+        start = (257 * ctx - 1) + torch.arange(n_future) * (tokens_per_dyn + 1)
+        x[:, start] += action_embeds[:, ctx - 1:-1]
+    logits, _, hid = model.forward_embeds(x, return_hidden=True)
+    B, L, V = logits.shape
+    tgt = labels[:, 1:]
+    nll = F.cross_entropy(logits[:, :-1].reshape(-1, V), tgt.reshape(-1), ignore_index=-100, reduction="none").view(B, L - 1)
+    valid = (tgt != -100)
+    token_nll = torch.cat([nll * valid, torch.zeros(B, 1)], 1)
+    counts = valid.sum(1).clamp_min(1)
+    return dict(loss=token_nll.sum() / valid.sum().clamp_min(1), token_nll=token_nll, sample_loss=token_nll.sum(1) / counts, hidden=hid)

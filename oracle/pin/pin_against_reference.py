@@ -78,6 +78,18 @@ def write_shim():
         "diffusers/models/autoencoders/vae.py": "from oracle.df_blocks import VectorQuantizer\n",
         "torchvision_stub/torchvision/__init__.py": "",
         "torchvision_stub/torchvision/models.py": "",
+        "torchvision_stub/torchvision/transforms/__init__.py": "",
+        # torchvision 0.17 tensor path of resize / center_crop (functional.py: interpolate(..., antialias=True); crop by slicing)
+        "torchvision_stub/torchvision/transforms/functional.py": """
+            import torch
+            def resize(img, size, *a, **k):
+                return torch.nn.functional.interpolate(img, size=list(size), mode='bilinear', align_corners=False, antialias=True)
+            def center_crop(img, output_size):
+                s = output_size if isinstance(output_size, int) else output_size[0]
+                h, w = img.shape[-2:]
+                top, left = int(round((h - s) / 2.0)), int(round((w - s) / 2.0))
+                return img[..., top:top + s, left:left + s]
+        """,
     }
     for rel, body in files.items():
         p = os.path.join(SHIM, rel)
@@ -281,6 +293,138 @@ def pin_mbrl_step(HeadModelWithAction, name, cfg, seed, B, ctx, action_dim, n_st
          actions=actions, step_tokens=torch.stack(step_tokens), step_rewards=torch.stack(step_rewards))
 
 
+def pin_eval_forward(HeadModelWithAction, name, cfg, seed, B, ctx, F, action_dim):
+    """The eval forward (train_gpt.py:356-376): ``LlamaForCausalLM(input_ids, labels).loss`` and the reference's
+    ``HeadModelWithAction(reward_prediction=True, action_recon=0.5).forward(input_ids, labels, action)`` -> loss (cross-entropy
+    + action-reconstruction term, action_model.py:187-196) and ``reward_pred`` (:198-204)."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    print(f"[eval forward] {name}")
+    hf_cfg = LlamaConfig(**{**cfg, "hidden_act": "silu", "tie_word_embeddings": False, "attention_bias": False,
+                            "bos_token_id": 50256, "eos_token_id": 50256})
+    V, per = cfg["vocab_size"], 17
+    g = torch.Generator().manual_seed(seed + 30)
+    L = 257 * ctx - 1 + per * F
+    ids = torch.randint(0, V - 2, (B, L), generator=g)
+    for i in range(F):
+        ids[:, 257 * ctx - 1 + per * i] = V - 1
+    for c in range(1, ctx):
+        ids[:, 257 * c - 1] = V - 2
+    labels = ids.clone()
+    labels[:, :257 * ctx] = -100                       # context tokens carry no loss (compressive_vq_model.py:216-218)
+    labels[0, 257 * ctx + 5] = -100                    # an ignored target in the middle
+    args = dict(num_layers=cfg["num_hidden_layers"], heads=cfg["num_attention_heads"])
+    # ---- action-free
+    sd = W.random_llama_state_dict(cfg, seed)
+    hf = LlamaForCausalLM(hf_cfg).to(torch.float32).eval()
+    hf.load_state_dict(sd, strict=True)
+    ora = OL.LlamaRef(sd, args["num_layers"], args["heads"], cfg["rms_norm_eps"], cfg["rope_theta"], cfg["max_position_embeddings"])
+    with torch.no_grad():
+        loss_ref = hf(input_ids=ids, labels=labels).loss.float()
+        o = OL.eval_forward(ora, ids, labels)
+        print(f"  LlamaForCausalLM loss: reference {loss_ref.item():.6f}, oracle {o['loss'].item():.6f}")
+        assert abs(loss_ref.item() - o["loss"].item()) < 1e-4
+    # ---- HeadModelWithAction with reward head and action reconstruction
+    T = ctx + F
+    sda = W.random_llama_state_dict(cfg, seed + 1, action_dim=action_dim, reward_prediction=True, action_recon=True)
+    llm = LlamaForCausalLM(hf_cfg).to(torch.float32).eval()
+    head = HeadModelWithAction(llm, action_dim=action_dim, prelude_tokens_num=257 * ctx - 1, tokens_num_per_dyna=16, context=ctx,
+                               segment_length=T, reward_prediction=True, action_recon=0.5).eval()
+    head.load_state_dict(sda, strict=True)
+    action = torch.randn(B, T, action_dim, generator=g)
+    oraa = OL.LlamaRef(sda, args["num_layers"], args["heads"], cfg["rms_norm_eps"], cfg["rope_theta"], cfg["max_position_embeddings"],
+                       prefix="llm.model.")
+    with torch.no_grad():
+        x, reward_pred = head(input_ids=ids, labels=labels, action=action)
+        loss_a = x.loss.float()
+        ar = head.action_recon_loss.float()
+        ae = torch.nn.functional.linear(action, sda["action_linear.weight"], sda["action_linear.bias"])
+        o = OL.eval_forward(oraa, ids, labels, action_embeds=ae, ctx=ctx, n_future=F)
+        hid = o["hidden"]
+        rec = torch.nn.functional.linear(hid[:, 257 * ctx - 1:], sda["action_recon_linear.weight"], sda["action_recon_linear.bias"])
+        tgt = action[:, ctx - 1:-1].unsqueeze(-2).repeat(1, 1, per, 1)
+        ar_o = torch.nn.functional.mse_loss(rec.reshape(-1, F, per, action_dim), tgt)
+        start = (257 * ctx - 1) + torch.arange(F) * per
+        rp_o = torch.nn.functional.linear(hid[:, start + 16], sda["reward_linear.weight"], sda["reward_linear.bias"])
+        loss_o = o["loss"] + 0.5 * ar_o
+        print(f"  HeadModelWithAction loss: reference {loss_a.item():.6f} (action_recon {ar.item():.6f}), oracle {loss_o.item():.6f}; "
+              f"reward_pred max diff {(rp_o - reward_pred).abs().max().item():.2e}")
+        assert abs(loss_a.item() - loss_o.item()) < 1e-4 and abs(ar.item() - ar_o.item()) < 1e-5
+        assert (rp_o - reward_pred).abs().max().item() < 1e-4
+    save(f"llama_{name}_eval.npz", config=json.dumps(cfg), seed=seed, action_dim=action_dim, ctx=ctx, n_future=F, ids=ids, labels=labels,
+         action=action, loss_free=loss_ref, loss_act=loss_a, action_recon_loss=ar, action_recon_weight=0.5, reward_pred=reward_pred.float())
+
+
+def pin_bf16(CompressiveVQModel, name, tcfg, tseed, lcfg, lseed, codebook_std):
+    """The reference's OWN bf16 path (``torch.autocast(dtype=bfloat16)``, vp/ivideogpt_interface.py:180, mbrl/video_predictor.py:269)
+    run here on the CPU: tokenizer decode of the fp32 fixture's tokens and HF Llama teacher-forced logits under autocast, plus the
+    same Llama with bf16 weights (``model.to(bfloat16)``).  These are the vectors the engine's bf16 mode is tested against."""
+    from transformers import LlamaConfig, LlamaForCausalLM
+    print(f"[bf16] {name}")
+    g0 = np.load(os.path.join(GOLD, f"tok_{name}.npz"))
+    cfg = W.tokenizer_config(**tcfg)
+    kw = {k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()}
+    nlev = len(cfg["block_out_channels"])
+    kw["down_block_types"], kw["up_block_types"] = ["DownEncoderBlock2D"] * nlev, ["UpDecoderBlock2D"] * nlev
+    kw["vq_embed_dim"] = None if tcfg.get("vq_embed_dim") is None else tcfg["vq_embed_dim"]
+    ref = CompressiveVQModel(**kw).eval()
+    ref.load_state_dict(W.random_tokenizer_state_dict(cfg, tseed, codebook_std), strict=True)
+    ids = torch.from_numpy(g0["indices"])
+    ctx = int(g0["context_length"])
+    with torch.no_grad():
+        rec32 = ref.detokenize(ids, ctx).float()
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            rec16 = ref.detokenize(ids, ctx).float()
+    d = (rec16 - rec32).abs()
+    print(f"  detokenize under autocast vs fp32: max {d.max().item():.3e} mean {d.mean().item():.3e}")
+    hf_cfg = LlamaConfig(**{**lcfg, "hidden_act": "silu", "tie_word_embeddings": False, "attention_bias": False,
+                            "bos_token_id": 50256, "eos_token_id": 50256})
+    sd = W.random_llama_state_dict(lcfg, lseed)
+    hf = LlamaForCausalLM(hf_cfg).to(torch.float32).eval()
+    hf.load_state_dict(sd, strict=True)
+    gl = np.load(os.path.join(GOLD, "llama_tiny_ctx2_free.npz"))
+    full = torch.from_numpy(gl["teacher_ids"])
+    with torch.no_grad():
+        lg32 = hf(input_ids=full).logits.float()
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            lg_ac = hf(input_ids=full).logits.float()
+        lg_bf = hf.to(torch.bfloat16)(input_ids=full).logits.float()
+    print(f"  logits: autocast vs fp32 max {(lg_ac - lg32).abs().max().item():.3e}; bf16 weights vs fp32 max {(lg_bf - lg32).abs().max().item():.3e} "
+          f"(scale {lg32.abs().max().item():.2f})")
+    save(f"bf16_{name}.npz", pixels_autocast=rec16, pixels_fp32_sub=rec32[:, :, :, ::4, ::4], logits_autocast_last=lg_ac[:, -2:],
+         logits_autocast_sub=lg_ac[:, ::37, ::101], logits_bf16_last=lg_bf[:, -2:], logits_bf16_sub=lg_bf[:, ::37, ::101],
+         autocast_pixel_dev=np.array([d.max().item(), d.mean().item()]),
+         logits_dev=np.array([(lg_ac - lg32).abs().max().item(), (lg_bf - lg32).abs().max().item()]))
+
+
+def pin_fractal_clip():
+    """BASELINE config 1: the reference's clip ingest (inference/utils.py:12-39, executed unmodified; torchvision's tensor
+    ``resize`` is supplied by the shim as ``interpolate(mode='bilinear', antialias=True)``, its definition in torchvision 0.17)
+    on inference/samples/fractal_sample.npz, seed 0 -> the [16, 3, 64, 64] clip the CLI feeds the tokenizer.  Pins
+    ivideogpt_amd.data.NPZParser and is the input of the config-1 GPU test.  The episode itself (a data file of the reference)
+    is committed next to it so the CLI test can run on the real file."""
+    import importlib.util
+    import shutil
+    print("[fractal clip]")
+    spec = importlib.util.spec_from_file_location("ref_inference_utils", os.path.join(REF, "inference", "utils.py"))
+    ru = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ru)
+    src = os.path.join(REF, "inference", "samples", "fractal_sample.npz")
+    np.random.seed(0)
+    clip_ref, _ = ru.NPZParser(16, 64).parse(src, "fractal20220817_data")
+    from ivideogpt_amd.data import NPZParser, DATASETS
+    np.random.seed(0)
+    clip_own, _ = NPZParser(16, 64).parse(src, "fractal20220817_data")
+    assert clip_ref.shape == (16, 3, 64, 64) and torch.equal(clip_ref, clip_own), "NPZParser restatement differs from the reference"
+    for k, v in ru.BASE_STEPSIZE.items():
+        assert DATASETS[k][0] == v, f"stride table differs for {k}"
+    for k, v in ru.DISPLAY_KEY.items():
+        assert DATASETS[k][1] == v, f"display key differs for {k}"
+    for k in DATASETS:
+        assert k in ru.BASE_STEPSIZE or k in ru.DISPLAY_KEY, f"unknown dataset {k}"
+    shutil.copyfile(src, os.path.join(GOLD, "fractal_sample.npz"))
+    save("fractal_clip_seed0.npz", clip=clip_ref, seed=0, dataset_name="fractal20220817_data", segment_length=16, resolution=64)
+
+
 def pin_param_counts():
     n64 = W.count_params(W.tokenizer_param_shapes(W.CTX_VAE64))
     n256 = W.count_params(W.tokenizer_param_shapes(W.CTX_VAE256))
@@ -309,6 +453,9 @@ def main():
     pin_llama(HeadModelWithAction, "tiny_ctx2", tiny, seed=21, B=2, ctx=2, F=3, action_dim=4)
     pin_llama(HeadModelWithAction, "tiny_ctx1", tiny, seed=23, B=3, ctx=1, F=4, action_dim=7)
     pin_mbrl_step(HeadModelWithAction, "tiny_ctx2", tiny, seed=31, B=2, ctx=2, action_dim=4, n_steps=3)
+    pin_eval_forward(HeadModelWithAction, "tiny_ctx2", tiny, seed=41, B=3, ctx=2, F=3, action_dim=4)
+    pin_bf16(CompressiveVQModel, "mini64_ctx2", mini64, 11, tiny, 21, 0.4)
+    pin_fractal_clip()
     print("all pins passed")
 
 

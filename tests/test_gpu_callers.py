@@ -222,3 +222,136 @@ def test_mbrl_step_matches_reference_vectors(reuse):
         assert np.array_equal(pred.cpu().numpy(), g["step_tokens"][t]), f"step {t}: tokens differ from the reference"
         assert np.abs(r.cpu().numpy() - g["step_rewards"][t]).max() < 1e-3, f"step {t}: reward differs from the reference"
         tokens = torch.cat([tokens, pred, sdf], 1)
+
+
+@pytest.mark.parametrize("use_cache", [True, False])
+def test_mbrl_embeds_level_op_sequence_matches_reference_vectors(use_cache):
+    """The op sequence of /root/reference/mbrl/video_predictor.py:286-317, line for line, against the mirror objects:
+    ``get_input_embeddings`` -> ``action_linear`` added to the last embedding -> ``llm.generate(inputs_embeds=...,
+    return_dict_in_generate=True, output_hidden_states=True)`` -> ``.sequences[:, :-1]`` / ``reward_linear(.hidden_states[-1][-1])``
+    -> embeddings of the predicted tokens + sdf appended.  Tokens and rewards of every step must equal what the REFERENCE produced
+    for the same weights and actions (tests/golden/llama_tiny_ctx2_mbrl.npz), with and without the kept KV cache; with it, every
+    step after the first must actually have reused the cache."""
+    from helpers import llama_fixture
+    from ivideogpt_amd import HeadModelWithAction, LlamaForCausalLM, weights as W
+    cfg, _, g = llama_fixture("llama_tiny_ctx2_mbrl.npz")
+    adim, ctx, V = int(g["action_dim"]), int(g["ctx"]), cfg["vocab_size"]
+    sd = W.random_llama_state_dict(cfg, int(g["seed"]), action_dim=adim, reward_prediction=True)
+    actions = torch.from_numpy(g["actions"])
+    n_steps, B = actions.shape[0], g["prompt"].shape[0]
+    model = HeadModelWithAction(LlamaForCausalLM(cfg, None, dtype="fp32"), adim, 257 * ctx - 1, 16, ctx, ctx + n_steps + 1,
+                                reward_prediction=True)
+    model.load_state_dict(sd, strict=True)
+    model.to(DEV)
+    tokens = torch.from_numpy(g["prompt"]).to(DEV)
+    embeds = model.get_input_embeddings(tokens)                                           # :285
+    assert embeds.shape == (B, tokens.shape[1], cfg["hidden_size"]) and embeds.dtype == torch.float32
+    reused = []
+    for t in range(n_steps):
+        action = actions[t].to(DEV)
+        action_embeds = model.action_linear(action)                                        # :295
+        embeds[:, -1] += action_embeds                                                     # :296
+        result = model.llm.generate(inputs_embeds=embeds, do_sample=False, temperature=1.0, pad_token_id=50256, top_k=100,
+                                    use_cache=use_cache, max_new_tokens=16 + 1, return_dict_in_generate=True,
+                                    output_hidden_states=True)                             # :298-308
+        reused.append(model.llm.last_generate_reused_cache)
+        predicted_token = result.sequences[:, :-1]                                         # :310
+        last_layer_hidden_states = result.hidden_states[-1]                                # :311
+        last_token_states = last_layer_hidden_states[-1]                                   # :312
+        reward = model.reward_linear(last_token_states).squeeze(-2)                        # :313
+        assert result.sequences.shape == (B, 17) and last_token_states.shape == (B, 1, cfg["hidden_size"]) and reward.shape == (B, 1)
+        cat_predicted_token = torch.concat([predicted_token, (torch.ones(B) * model.token_for_sdf).unsqueeze(1).to(DEV)],
+                                           dim=1).to(predicted_token.dtype)               # :315
+        embeds = torch.concat([embeds, model.get_input_embeddings(cat_predicted_token)], dim=1)   # :316
+        assert np.array_equal(predicted_token.cpu().numpy(), g["step_tokens"][t]), f"step {t}: tokens differ from the reference"
+        assert np.abs(reward[:, 0].cpu().numpy() - g["step_rewards"][t]).max() < 1e-3, f"step {t}: reward differs from the reference"
+    assert reused == ([False] + [True] * (n_steps - 1) if use_cache else [False] * n_steps), reused
+
+
+def test_kept_cache_is_verified_not_assumed():
+    """A kept KV cache is reused only when it was built from exactly the presented prefix: an embedding changed in the middle
+    of the prompt (same shapes) makes the embeds path fall back to a prefill -- with the same tokens as a fresh engine gives --
+    and a token-level ``generate(reuse_cache=True)`` whose prefix was not what the cache holds is refused."""
+    from ivideogpt_amd import HeadModelWithAction, LlamaForCausalLM, weights as W
+    lsd = W.random_llama_state_dict(LLM_CFG, 91, action_dim=4, reward_prediction=True)
+
+    def fresh():
+        m = HeadModelWithAction(LlamaForCausalLM(LLM_CFG, None, dtype="fp32"), 4, 513, 16, 2, 16, reward_prediction=True)
+        m.load_state_dict(lsd, strict=True)
+        return m.to(DEV)
+    g = torch.Generator().manual_seed(12)
+    B = 3
+    prompt = torch.randint(0, 1024, (B, 514), generator=g).to(DEV)
+    prompt[:, -1] = 1025
+    model = fresh()
+    e0 = model.get_input_embeddings(prompt)
+    r0 = model.llm.generate(inputs_embeds=e0, do_sample=False, max_new_tokens=17, return_dict_in_generate=True, output_hidden_states=True)
+    sdf = torch.full((B, 1), 1025, dtype=torch.int64, device=DEV)
+    e1 = torch.cat([e0, model.get_input_embeddings(torch.cat([r0.sequences[:, :-1], sdf], 1))], 1)
+    tampered = e1.clone()
+    tampered[1, 100] += 0.25                                   # same shape, one cached row differs
+    r_t = model.llm.generate(inputs_embeds=tampered, do_sample=False, max_new_tokens=17, return_dict_in_generate=True)
+    assert model.llm.last_generate_reused_cache is False
+    r_ref = fresh().llm.generate(inputs_embeds=tampered, do_sample=False, max_new_tokens=17, return_dict_in_generate=True)
+    assert torch.equal(r_t.sequences, r_ref.sequences)
+    # ... and the untouched continuation right after a call that rebuilt the cache from something else is not reused either
+    r1 = model.llm.generate(inputs_embeds=e1, do_sample=False, max_new_tokens=17, return_dict_in_generate=True)
+    assert model.llm.last_generate_reused_cache is False
+    assert torch.equal(r1.sequences, fresh().llm.generate(inputs_embeds=e1, do_sample=False, max_new_tokens=17))
+    # token level: the cache now holds e1's 530 positions + 16; a 548-token prompt with another prefix must be refused
+    act = torch.randn(B, 6, 4, generator=g).to(DEV)
+    out = model.generate(prompt, do_sample=False, max_new_tokens=17, action=act)
+    other = torch.randint(0, 1024, (B, 514), generator=g).to(DEV)
+    other[:, -1] = 1025
+    grown = torch.cat([other, out[:, 514:530], sdf], 1)
+    with pytest.raises(AssertionError):
+        model.generate(grown, do_sample=False, max_new_tokens=17, action=act, reuse_cache=True)
+    good = torch.cat([prompt, out[:, 514:530], sdf], 1)
+    act2 = act.clone()
+    act2[:, 1] += 1.0                                          # the action of the cached first slot changed: refuse as well
+    with pytest.raises(AssertionError):
+        model.generate(good, do_sample=False, max_new_tokens=17, action=act2, reuse_cache=True)
+    cont = model.generate(good, do_sample=False, max_new_tokens=17, action=act, reuse_cache=True)
+    full = fresh().generate(good, do_sample=False, max_new_tokens=17, action=act)
+    assert torch.equal(cont, full)
+
+
+def test_config1_predict_cli_on_fractal_sample_full_width(tmp_path):
+    """BASELINE config 1: ``predict.py`` on the reference's own sample episode (tests/golden/fractal_sample.npz, a data file
+    of the reference: inference/samples/fractal_sample.npz) with ivideogpt-oxe-64-act-free shapes at FULL width (114 M tokenizer,
+    138 M transformer; seeded random weights, codebooks cut to 1024 entries to keep the CPU oracle's cdist quick), repeat_times 5,
+    2 context + 14 predicted frames, fp32 -- tokens identical to the oracle fed the same uniforms, pixels within 1e-3; the clip
+    the CLI fed the tokenizer is the one the REFERENCE's NPZParser produces (tests/golden/fractal_clip_seed0.npz)."""
+    sys.path.insert(0, os.path.join(ROOT, "inference"))
+    import importlib
+    predict = importlib.import_module("predict")
+    from oracle.llama import generate_cached
+    from ivideogpt_amd import weights as W
+    tcfg = W.tokenizer_config(**W.CTX_VAE64)
+    tcfg["num_vq_embeddings"] = tcfg["num_dyn_embeddings"] = 1024
+    lcfg = dict(W.LLAMA_SMALL, vocab_size=2050)
+    tsd = W.random_tokenizer_state_dict(tcfg, 71, codebook_std=0.4)
+    lsd = W.random_llama_state_dict(lcfg, 72)
+    ck = str(tmp_path / "ckpt")
+    W.save_tokenizer_checkpoint(ck, tcfg, tsd, "tokenizer")
+    W.save_transformer_checkpoint(ck, lcfg, lsd, "transformer")
+    sample = os.path.join(ROOT, "tests", "golden", "fractal_sample.npz")
+    out_dir = str(tmp_path / "out")
+    argv = ["--pretrained_model_name_or_path", ck, "--input_path", sample, "--dataset_name", "fractal20220817_data", "--output_path", out_dir,
+            "--context_length", "2", "--segment_length", "16", "--repeat_times", "5", "--seed", "0", "--dtype", "fp32"]
+    rec = predict.main(argv).cpu()
+    saved = np.load(os.path.join(out_dir, "pred-samples.npz"))
+    assert rec.shape == (5, 16, 3, 64, 64)
+    clip = torch.from_numpy(np.load(os.path.join(ROOT, "tests", "golden", "fractal_clip_seed0.npz"))["clip"])
+    predict.set_seed(0)                                    # same seed -> the same uniforms from the GPU generator
+    u = torch.rand(5, 17 * 14 - 1, device=DEV).cpu()
+    tok, llm = oracle_tokenizer(tcfg, tsd, 2), oracle_llama(lcfg, lsd)
+    ids_ref, _ = tok.tokenize(clip[None], 2)
+    out_ref = generate_cached(llm, ids_ref[:, :514].repeat(5, 1), 17 * 14 - 1, top_k=100, uniforms=u)
+    from helpers import assert_sampled_rollout_matches
+    toks = torch.from_numpy(saved["tokens"])
+    n_tie = assert_sampled_rollout_matches(toks, out_ref, llm, u, 100, 514, what="predict CLI on fractal_sample.npz")
+    assert n_tie <= 1, f"{n_tie} of 5 rows diverged at a sampling near-tie"
+    # pixels: the oracle decodes the tokens the engine produced (rows that left the oracle's path at a near-tie included)
+    rec_ref = tok.detokenize(toks, 2).clamp(0, 1)
+    assert (rec - rec_ref).abs().max().item() < 1e-3

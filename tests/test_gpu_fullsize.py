@@ -172,3 +172,75 @@ def test_predict_frames_equals_three_calls(models):
     want = tok.detokenize(toks, CTX).clamp(0.0, 1.0)
     assert frames.shape == (B, T, 3, RES, RES) and torch.equal(frames, want)
     assert frames.min() >= 0 and frames.max() <= 1
+
+
+def test_config4_256px_full_batch_properties():
+    """BASELINE config 4 at its full size: ivideogpt-oxe-256-act-free tokenizer (310 M parameters, 256 x 256), batch 16,
+    2 context + 14 predicted frames, bf16 decode: token layout, batch invariance of tokenize / detokenize, the context-only
+    path, the context cache and the three-call composition (the oracle checks this tokenizer bit-exactly at B = 1, T = 3 in
+    test_gpu_models.py; the CPU cannot finish 16 x 16 frames of 256 x 256 in seconds)."""
+    from ivideogpt_amd import CompressiveVQModel, LlamaForCausalLM
+    from ivideogpt_amd import weights as W
+    from ivideogpt_amd.pipeline import predict_frames
+    Bq, Tq, res = 16, 16, 256
+    tcfg = W.tokenizer_config(**dict(W.CTX_VAE256, resolution=256, max_att_resolution=32))
+    tok = CompressiveVQModel(tcfg, W.random_tokenizer_state_dict(tcfg, 15, codebook_std=0.4), encode_dtype="fp32", decode_dtype="bf16").to(DEV)
+    g = torch.Generator().manual_seed(27)
+    base = torch.rand(Bq, 1, 3, res, res, generator=g)
+    px = (base + 0.15 * torch.rand(Bq, Tq, 3, res, res, generator=g)).clamp(0, 1).to(torch.bfloat16).to(DEV)
+    ids, labels = tok.tokenize(px, CTX)
+    F = Tq - CTX
+    assert ids.shape == (Bq, 257 * CTX - 1 + 17 * F)
+    n_vq, n_dyn = tcfg["num_vq_embeddings"], tcfg["num_dyn_embeddings"]
+    host = ids.cpu()
+    pos = torch.arange(host.shape[1])
+    in_ctx = pos < 257 * CTX - 1
+    is_sep = torch.where(in_ctx, (pos % 257) == 256, ((pos - (257 * CTX - 1)) % 17) == 0)
+    assert (host[:, in_ctx & is_sep] == n_vq + n_dyn).all() and (host[:, ~in_ctx & is_sep] == n_vq + n_dyn + 1).all()
+    assert (host[:, in_ctx & ~is_sep] < n_vq).all() and (host[:, ~in_ctx & ~is_sep] >= n_vq).all()
+    for b in (0, 9, 15):
+        one, _ = tok.tokenize(px[b:b + 1], CTX)
+        assert torch.equal(one[0], ids[b]), f"row {b} depends on its batch"
+    assert torch.equal(tok.tokenize(px[8:], CTX)[0], ids[8:])                     # a rank's shard
+    assert torch.equal(tok.encode_context(px, CTX), ids[:, :257 * CTX])
+    rec = tok.detokenize(ids, CTX)
+    assert rec.shape == (Bq, Tq, 3, res, res) and torch.isfinite(rec).all()
+    assert torch.equal(tok.detokenize(ids[5:6], CTX)[0], rec[5]) and torch.equal(tok.detokenize(ids[8:], CTX), rec[8:])
+    rec3, cache = tok.detokenize(ids[:, :257 * CTX - 1 + 17 * 2], CTX, return_cache=True)
+    assert torch.equal(rec3, rec[:, :CTX + 2]) and torch.equal(tok.detokenize(ids, CTX, cache=cache), rec)
+    # the whole prediction path at this size (138 M transformer, sampled)
+    lcfg = dict(W.LLAMA_SMALL)
+    llm = LlamaForCausalLM(lcfg, W.random_llama_state_dict(lcfg, 16), dtype="bf16").to(DEV)
+    g1 = torch.Generator(device=DEV).manual_seed(6)
+    frames, toks = predict_frames(tok, llm, px, CTX, F, do_sample=True, top_k=100, generator=g1, return_tokens=True)
+    assert frames.shape == (Bq, Tq, 3, res, res) and torch.isfinite(frames).all() and frames.min() >= 0 and frames.max() <= 1
+    assert torch.equal(tok.detokenize(toks, CTX).clamp(0, 1), frames)
+    from ivideogpt_amd.pipeline import frame_metrics
+    rows = frame_metrics(frames, px, first_frame=CTX)
+    assert rows.shape == (Bq, 3) and torch.isfinite(rows).all()
+
+
+def test_config5_medium_30_frame_rollout_properties():
+    """BASELINE config 5 per-GPU shape: 436 M transformer (24 layers, hidden 1024, 16 heads), 64 trajectories, 2 context + 28
+    predicted frames = 989-token sequences, bf16: the decode path at its longest cache -- determinism, batch invariance
+    (a 2-rank shard equals the whole), prefix property, graph replay == eager; the fp32 decode path of this model is checked
+    token-for-token against the oracle in test_gpu_models.py::test_medium_llama_decode_path_vs_oracle."""
+    from ivideogpt_amd import LlamaForCausalLM
+    from ivideogpt_amd import weights as W
+    lcfg = dict(W.LLAMA_MEDIUM)
+    sd = W.random_llama_state_dict(lcfg, 26)
+    llm = LlamaForCausalLM(lcfg, sd, dtype="bf16").to(DEV)
+    g = torch.Generator().manual_seed(31)
+    Bm, F = 64, 28
+    prompt = torch.randint(0, 8192, (Bm, 514), generator=g)
+    prompt[:, 256] = lcfg["vocab_size"] - 2
+    prompt[:, -1] = lcfg["vocab_size"] - 1
+    prompt = prompt.to(DEV)
+    n_new = 17 * F - 1
+    u = torch.rand(Bm, n_new, generator=g).to(DEV)
+    out = llm.generate(prompt, do_sample=True, top_k=100, max_new_tokens=n_new, uniforms=u)
+    assert out.shape == (Bm, 989) and (out >= 0).all() and (out < lcfg["vocab_size"]).all()
+    assert torch.equal(llm.generate(prompt, do_sample=True, top_k=100, max_new_tokens=n_new, uniforms=u), out)
+    assert torch.equal(llm.generate(prompt[32:], do_sample=True, top_k=100, max_new_tokens=n_new, uniforms=u[32:]), out[32:])
+    short = llm.generate(prompt[:16], do_sample=True, top_k=100, max_new_tokens=60, uniforms=u[:16, :60].contiguous())
+    assert torch.equal(short, out[:16, :514 + 60])

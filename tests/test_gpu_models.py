@@ -287,3 +287,130 @@ def test_full_width_llama_medium_logits_vs_oracle():
     lg = make_llm(cfg, sd).logits(ids.to(DEV)).cpu()
     err = (lg - ref).abs().max().item()
     assert err < 1e-3, f"24-layer logits max abs err {err:.2e} (scale {ref.abs().max():.1f})"
+
+
+# ------------------------------------------------------------------------------------------------ the reference's own bf16 path
+def test_bf16_mode_against_reference_autocast_vectors():
+    """tests/golden/bf16_mini64_ctx2.npz holds what the REFERENCE classes produce under ``torch.autocast(dtype=bfloat16)`` -- the
+    way vp/ivideogpt_interface.py:180 and mbrl/video_predictor.py:269 run them -- for the tokens / ids of the fp32 fixtures.  The
+    engine's bf16 mode (the benchmarked arithmetic) against those vectors, absolute tolerances:
+      decoded pixels  max |d| < 0.15, mean |d| < 0.012   (the reference's autocast path itself sits 7.7e-2 / 7.9e-3 from its fp32 path)
+      logits          max |d| < 0.30 at a logit scale of 12  (autocast is 0.17 from fp32, HF with bf16 weights 0.98)
+    and the engine may not be further from the fp32 reference than the reference's own bf16 paths are."""
+    from helpers import load_golden
+    gb = load_golden("bf16_mini64_ctx2.npz")
+    cfg, sd, ctx, px, g = tokenizer_fixture("tok_mini64_ctx2.npz")
+    m = make_tok(cfg, sd, ctx, dec="bf16")
+    rec = m.detokenize(torch.from_numpy(g["indices"]).to(DEV), ctx).cpu().numpy()
+    d = np.abs(rec - gb["pixels_autocast"])
+    d32 = np.abs(rec - g["recon"])
+    ref_dev = gb["autocast_pixel_dev"]
+    msg = (f"bf16 decode vs reference autocast: max {d.max():.3e} mean {d.mean():.3e}; vs reference fp32: max {d32.max():.3e} mean "
+           f"{d32.mean():.3e} (reference autocast vs its fp32: max {ref_dev[0]:.3e} mean {ref_dev[1]:.3e})")
+    print(msg)
+    assert d.max() < 0.15 and d.mean() < 0.012, msg
+    assert d32.max() <= 1.25 * ref_dev[0] and d32.mean() <= 1.25 * ref_dev[1], msg
+    lcfg, lsd, gl = llama_fixture("llama_tiny_ctx2_free.npz")
+    lg = make_llm(lcfg, lsd, "bf16").logits(torch.from_numpy(gl["teacher_ids"]).to(DEV)).cpu().numpy()
+    e_ac = max(np.abs(lg[:, -2:] - gb["logits_autocast_last"]).max(), np.abs(lg[:, ::37, ::101] - gb["logits_autocast_sub"]).max())
+    e_32 = max(np.abs(lg[:, -2:] - gl["teacher_logits_last"]).max(), np.abs(lg[:, ::37, ::101] - gl["teacher_logits_sub"]).max())
+    msg = (f"bf16 logits vs reference autocast: max {e_ac:.3e}; vs reference fp32: {e_32:.3e} (reference autocast vs fp32 {gb['logits_dev'][0]:.3e}, "
+           f"HF bf16 weights vs fp32 {gb['logits_dev'][1]:.3e})")
+    print(msg)
+    assert e_ac < 0.30 and e_32 <= 1.25 * gb["logits_dev"][0], msg
+
+
+# ------------------------------------------------------------------------------------------------ eval forward (labels -> loss)
+def test_eval_forward_matches_reference_loss():
+    """``model(input_ids, labels[, action])`` of the eval loop (train_gpt.py:356-376) against the REFERENCE's numbers
+    (tests/golden/llama_tiny_ctx2_eval.npz): HF shifted cross-entropy of LlamaForCausalLM; HeadModelWithAction.forward with
+    reward head and action reconstruction (loss = CE + 0.5 * MSE, reward_pred (B, F, 1)) -- computed without a logits tensor."""
+    from helpers import load_golden
+    from ivideogpt_amd import HeadModelWithAction, LlamaForCausalLM, weights as W
+    g = load_golden("llama_tiny_ctx2_eval.npz")
+    cfg = json.loads(str(g["config"]))
+    seed, adim, ctx, F = int(g["seed"]), int(g["action_dim"]), int(g["ctx"]), int(g["n_future"])
+    ids, labels = torch.from_numpy(g["ids"]).to(DEV), torch.from_numpy(g["labels"]).to(DEV)
+    free = LlamaForCausalLM(cfg, W.random_llama_state_dict(cfg, seed), dtype="fp32").to(DEV)
+    out = free(input_ids=ids, labels=labels)
+    assert abs(out.loss.item() - float(g["loss_free"])) < 1e-3, (out.loss.item(), float(g["loss_free"]))
+    # per-position losses against the logits path of the same engine
+    lg = free.logits(ids)
+    nll = torch.nn.functional.cross_entropy(lg[:, :-1].reshape(-1, lg.shape[-1]), labels[:, 1:].reshape(-1), ignore_index=-100,
+                                            reduction="none").view(ids.shape[0], -1)
+    assert (out.token_nll[:, :-1] - nll).abs().max().item() < 1e-4 and out.token_nll[:, -1].abs().max().item() == 0
+    assert (out.sample_perplexity - torch.exp(out.sample_loss)).abs().max().item() < 1e-3
+    sda = W.random_llama_state_dict(cfg, seed + 1, action_dim=adim, reward_prediction=True, action_recon=True)
+    head = HeadModelWithAction(LlamaForCausalLM(cfg, None, dtype="fp32"), adim, 257 * ctx - 1, 16, ctx, ctx + F, reward_prediction=True,
+                               action_recon=float(g["action_recon_weight"]))
+    head.load_state_dict(sda, strict=True)
+    head.to(DEV)
+    action = torch.from_numpy(g["action"]).to(DEV)
+    x, reward_pred = head(input_ids=ids, labels=labels, action=action)
+    assert abs(x.loss.item() - float(g["loss_act"])) < 1e-3, (x.loss.item(), float(g["loss_act"]))
+    assert abs(head.action_recon_loss.item() - float(g["action_recon_loss"])) < 1e-4
+    assert reward_pred.shape == g["reward_pred"].shape and np.abs(reward_pred.cpu().numpy() - g["reward_pred"]).max() < 1e-3
+
+
+def test_eval_forward_full_width_loss_vs_oracle():
+    """12-layer small Llama, L = 751 (2 context + 14 future frames), 3 trajectories: loss / per-sample loss vs the oracle's
+    eval_forward (the row chunking of the fused cross-entropy is exercised: 2253 rows)."""
+    from oracle.llama import eval_forward
+    from ivideogpt_amd import weights as W
+    cfg = dict(W.LLAMA_SMALL)
+    sd = W.random_llama_state_dict(cfg, 47)
+    g = torch.Generator().manual_seed(11)
+    ids = torch.randint(0, cfg["vocab_size"], (3, 751), generator=g)
+    labels = ids.clone()
+    labels[:, :514] = -100
+    ref = eval_forward(oracle_llama(cfg, sd), ids, labels)
+    out = make_llm(cfg, sd)(input_ids=ids.to(DEV), labels=labels.to(DEV))
+    assert abs(out.loss.item() - ref["loss"].item()) < 1e-3
+    assert (out.sample_loss.cpu() - ref["sample_loss"]).abs().max().item() < 1e-3
+    assert (out.token_nll.cpu() - ref["token_nll"]).abs().max().item() < 2e-3
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE config 5: medium decode path
+def test_medium_llama_decode_path_vs_oracle():
+    """ivideogpt-oxe-64-act-free-medium (24 layers, hidden 1024, 16 heads, intermediate 4096): the DECODE path -- skinny / decode
+    GEMMs at K = 1024 / 4096, decode attention with 16 heads -- through ``generate`` from a 514-token prompt, 2 rows, 48 new
+    tokens, greedy and sampled with explicit uniforms, fp32 mode: token-identical to oracle.llama.generate_cached."""
+    from oracle.llama import generate_cached
+    from ivideogpt_amd import weights as W
+    cfg = dict(W.LLAMA_MEDIUM)
+    sd = W.random_llama_state_dict(cfg, 49)
+    g = torch.Generator().manual_seed(13)
+    prompt = torch.randint(0, 8192, (2, 514), generator=g)
+    prompt[:, 256] = cfg["vocab_size"] - 2
+    prompt[:, -1] = cfg["vocab_size"] - 1
+    n_new = 48
+    u = torch.rand(2, n_new, generator=g)
+    ora = oracle_llama(cfg, sd)
+    m = make_llm(cfg, sd)
+    out_g = m.generate(prompt.to(DEV), do_sample=False, max_new_tokens=n_new).cpu()
+    ref_g = generate_cached(ora, prompt, n_new)
+    assert torch.equal(out_g, ref_g), f"greedy: {(out_g != ref_g).sum().item()} of {2 * n_new} tokens differ from the oracle"
+    out_s = m.generate(prompt.to(DEV), do_sample=True, top_k=100, max_new_tokens=n_new, uniforms=u.to(DEV)).cpu()
+    ref_s = generate_cached(ora, prompt, n_new, top_k=100, uniforms=u)
+    assert torch.equal(out_s, ref_s), f"sampled: {(out_s != ref_s).sum().item()} of {2 * n_new} tokens differ from the oracle"
+
+
+def test_sampler_survives_nan_logits():
+    """A row of NaN (or -inf) logits must decide an in-range token (0) instead of writing a garbage id / gathering an embedding
+    out of bounds inside a replayed graph."""
+    import ctypes as C
+    from ivideogpt_amd import _lib
+    l = _lib.load()
+    B, V = 4, 16386
+    lg = torch.randn(B, V, device=DEV)
+    lg[1] = float("nan")
+    lg[2] = float("-inf")
+    u = torch.rand(B, device=DEV)
+    out = torch.full((B,), -7, dtype=torch.int64, device=DEV)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for uni in (u, None):
+        assert l.ivg_op_sample(C.c_void_p(lg.data_ptr()), B, V, 100, C.c_void_p(uni.data_ptr()) if uni is not None else None,
+                               C.c_void_p(out.data_ptr()), st) == 0
+        o = out.cpu()
+        assert ((o >= 0) & (o < V)).all(), o.tolist()
+        assert o[1].item() == 0 and o[2].item() == 0

@@ -209,3 +209,19 @@ def test_committed_bench_line_keeps_the_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
+
+
+def test_bench_launch_line_and_config_presets():
+    """bench.py --gpus N without a torchrun environment re-executes itself under torch.distributed.run on 127.0.0.1, one rank per
+    GPU; --config presets carry the per-GPU shapes of BASELINE.json's configs."""
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.torchrun_command(8, ["--gpus", "8", "--steps", "3", "--config", "5"], port=29511)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "3", "--config", "5"] and cmd[-7].endswith("bench.py")
+    c = bench.CONFIGS
+    assert c[2] == dict(batch=64, frames=16, res=64, medium=False, action_dim=0, ctx=0)
+    assert c[3]["batch"] * 8 == 256 and c[3]["action_dim"] == 4 and c[3]["ctx"] == 1            # bair-64-act-cond, 256 over 8 GPUs
+    assert c[4]["res"] == 256 and c[4]["batch"] == 16
+    assert c[5]["medium"] and c[5]["batch"] * 8 == 512 and 257 * 2 - 1 + 17 * (c[5]["frames"] - 2) + 1 == 990   # 989-token sequences

@@ -117,3 +117,64 @@ def test_sampler_restatement_properties():
     p = torch.softmax(lg[0].masked_fill(lg[0] < kth[0], float("-inf")), -1)
     top = p.argmax()
     assert abs((t == top).float().mean().item() - p[top].item()) < 0.03
+
+
+def test_eval_forward_oracle_matches_reference_vectors():
+    """oracle.llama.eval_forward against the REFERENCE's losses (tests/golden/llama_tiny_ctx2_eval.npz: HF
+    ``LlamaForCausalLM(input_ids, labels).loss`` and ``HeadModelWithAction(reward_prediction, action_recon=0.5).forward``)."""
+    import json
+    from helpers import load_golden
+    from oracle.llama import eval_forward
+    import ivideogpt_amd.weights as W
+    g = load_golden("llama_tiny_ctx2_eval.npz")
+    cfg = json.loads(str(g["config"]))
+    seed, adim, ctx, F = int(g["seed"]), int(g["action_dim"]), int(g["ctx"]), int(g["n_future"])
+    ids, labels, action = torch.from_numpy(g["ids"]), torch.from_numpy(g["labels"]), torch.from_numpy(g["action"])
+    o = eval_forward(oracle_llama(cfg, W.random_llama_state_dict(cfg, seed)), ids, labels)
+    assert abs(o["loss"].item() - float(g["loss_free"])) < 1e-4
+    sda = W.random_llama_state_dict(cfg, seed + 1, action_dim=adim, reward_prediction=True, action_recon=True)
+    ae = torch.nn.functional.linear(action, sda["action_linear.weight"], sda["action_linear.bias"])
+    o = eval_forward(oracle_llama(cfg, sda, prefix="llm.model."), ids, labels, action_embeds=ae, ctx=ctx, n_future=F)
+    hid = o["hidden"]
+    rec = torch.nn.functional.linear(hid[:, 257 * ctx - 1:], sda["action_recon_linear.weight"], sda["action_recon_linear.bias"])
+    tgt = action[:, ctx - 1:-1].unsqueeze(-2).repeat(1, 1, 17, 1)
+    ar = torch.nn.functional.mse_loss(rec.reshape(-1, F, 17, adim), tgt)
+    assert abs(ar.item() - float(g["action_recon_loss"])) < 1e-5
+    assert abs((o["loss"] + float(g["action_recon_weight"]) * ar).item() - float(g["loss_act"])) < 1e-4
+    start = (257 * ctx - 1) + torch.arange(F) * 17
+    rp = torch.nn.functional.linear(hid[:, start + 16], sda["reward_linear.weight"], sda["reward_linear.bias"])
+    assert np.abs(rp.numpy() - g["reward_pred"]).max() < 1e-4
+
+
+def test_clip_ingest_matches_reference_parser_output():
+    """ivideogpt_amd.data.NPZParser (host path) on the reference's sample episode, seed 0, == the clip the REFERENCE's own
+    inference/utils.py NPZParser produced (tests/golden/fractal_clip_seed0.npz), bit for bit."""
+    import os
+    from helpers import GOLDEN
+    from ivideogpt_amd.data import NPZParser, frame_stride
+    ref = torch.from_numpy(np.load(os.path.join(GOLDEN, "fractal_clip_seed0.npz"))["clip"])
+    np.random.seed(0)
+    clip, actions = NPZParser(16, 64).parse(os.path.join(GOLDEN, "fractal_sample.npz"), "fractal20220817_data")
+    assert actions is None and clip.shape == (16, 3, 64, 64) and torch.equal(clip, ref)
+    assert frame_stride("fractal20220817_data") == 1 and frame_stride("kuka") == 3 and frame_stride("toto") == 10
+    assert frame_stride("asu_table_top_converted_externally_to_rlds") == 4 and frame_stride("unknown_dataset") == 1
+
+
+def test_frame_metric_oracle_known_answers():
+    """oracle/metrics.py (restatement of Evaluator.forward, ivideogpt/utils/video_metric.py:63-100): closed-form cases.
+    Constant frames x = a, y = b: every filtered moment is the constant itself, all variances vanish, so
+    ssim = (2ab + c1) / (a^2 + b^2 + c1); mse = (a - b)^2; psnr = 10 log10(1 / (mse + 1e-8)); best-of-t keeps the closest sample."""
+    from oracle.metrics import frame_metric_rows, gaussian_window
+    w = gaussian_window()
+    assert abs(w.sum().item() - 1) < 1e-6 and torch.allclose(w, w.flip(0)) and w.argmax().item() == 5
+    a, b1, b2 = 0.6, 0.5, 0.2
+    gt = torch.full((2, 3, 3, 32, 32), a)
+    pred = torch.cat([torch.full((2, 3, 3, 32, 32), b2), torch.full((2, 3, 3, 32, 32), b1)], 0)   # sample 0: far, sample 1: close
+    rows = frame_metric_rows(gt, pred)
+    c1 = 0.01 ** 2
+    assert rows.shape == (2, 3)
+    assert torch.allclose(rows[:, 0], torch.tensor((a - b1) ** 2), atol=1e-7)
+    assert torch.allclose(rows[:, 1], torch.tensor(10 * np.log10(1 / ((a - b1) ** 2 + 1e-8)), dtype=torch.float32), atol=1e-3)
+    assert torch.allclose(rows[:, 2], torch.tensor((2 * a * b1 + c1) / (a * a + b1 * b1 + c1), dtype=torch.float32), atol=2e-4)
+    same = frame_metric_rows(gt, gt.clone())
+    assert same[:, 0].abs().max().item() == 0 and torch.allclose(same[:, 1], torch.tensor(80.0), atol=1e-3) and torch.allclose(same[:, 2], torch.tensor(1.0))
