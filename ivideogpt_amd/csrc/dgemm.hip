@@ -322,11 +322,11 @@ static int g_dg_force[4] = {0, 0, 0, 0};   // IVG_DG_FORCE=MF,FN,WAVES,LG (tools
 // keyed by (K bytes, N) -- never by the batch, so the K partition of a GEMM is fixed.  mf caps the row tiles per workgroup.
 struct DgPick { int kbytes, N, mf, fn, waves, lg; };
 static const DgPick kDgPicks[] = {
-    {1536, 2304, 2, 2, 4, 3},    // small: q/k/v            5.5 us per launch (first generation 6.5)
-    {1536, 768, 1, 1, 4, 3},     // small: o-proj           3.6 (4.8)
-    {1536, 6144, 4, 2, 4, 3},    // small: gate/up          7.1 (9.6)
-    {6144, 768, 1, 1, 4, 3},     // small: down             7.2 (8.9)
-    {1536, 16386, 4, 2, 2, 1},   // small: lm_head         14.3 (19.3)
+    {1536, 2304, 2, 2, 4, 3},    // small: q/k/v            5.0 us per launch incl. the boundary (first generation 6.5)
+    {1536, 768, 1, 1, 4, 3},     // small: o-proj           3.4 (4.8)
+    {1536, 6144, 4, 2, 4, 3},    // small: gate/up          7.0 (9.6)
+    {6144, 768, 1, 1, 8, 3},     // small: down             5.8 (8.9)
+    {1536, 16386, 4, 2, 2, 2},   // small: lm_head         12.9 (19.2)
     {2048, 3072, 2, 2, 4, 2},    // medium (hidden 1024, intermediate 4096): q/k/v   6.5 (8.2)
     {2048, 1024, 1, 1, 4, 2},    // medium: o-proj          4.2 (5.3)
     {2048, 8192, 4, 2, 4, 2},    // medium: gate/up         8.6 (11.0)

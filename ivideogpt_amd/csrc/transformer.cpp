@@ -362,36 +362,46 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
     if (reuse_kv) IVG_TRY(step_body(e, st, g, Bc, nc, cs, sa, true, embeds != nullptr));   // j = 0: feed the prompt's last token
     if (n_new == 1) IVG_TRY(reward());
     if (n_new >= 1) { IVG_TRY(step_body(e, st, g, Bc, nc, cs, sa, j < n_new)); ++j; }
-    hipGraphExec_t exec = nullptr;
-    if (e->use_graph && st != nullptr && j < n_new) {
-      auto it = e->graphs.find(key);
-      if (it != e->graphs.end()) {
-        exec = it->second;
-      } else {
-        hipGraph_t graph = nullptr;
-        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-          const int rc = step_body(e, st, g, Bc, nc, cs, sa, true);
-          const hipError_t ce = hipStreamEndCapture(st, &graph);
-          if (rc == 0 && ce == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-            if (e->graphs.size() >= 64) {   // bound the cache (a server fed ever new prompt lengths): drop all, recapture on demand
-              CK((int)hipStreamSynchronize(st));
-              for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
-              e->graphs.clear();
-            }
-            e->graphs[key] = exec;
-          } else {
-            exec = nullptr;
-            (void)hipGetLastError();
+    // the step sequence is position-independent (all step-dependent scalars live in StepState): it is captured once as a graph of
+    // ONE step and once as a graph of `multi` consecutive steps -- the long rollouts replay the multi-step graph (a graph launch
+    // costs the host ~10-16 us and leaves a bubble on the device; 8 steps per launch amortise it), the tail the single-step one
+    auto get_graph = [&](int n_steps, hipGraphExec_t* out) -> int {
+      *out = nullptr;
+      if (!(e->use_graph && st != nullptr)) return 0;
+      const std::string k = key + (n_steps > 1 ? ":x" + std::to_string(n_steps) : "");
+      auto it = e->graphs.find(k);
+      if (it != e->graphs.end()) { *out = it->second; return 0; }
+      hipGraph_t graph = nullptr;
+      hipGraphExec_t ex = nullptr;
+      if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        int rc = 0;
+        for (int i = 0; i < n_steps && rc == 0; ++i) rc = step_body(e, st, g, Bc, nc, cs, sa, true);
+        const hipError_t ce = hipStreamEndCapture(st, &graph);
+        if (rc == 0 && ce == hipSuccess && graph && hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0) == hipSuccess) {
+          if (e->graphs.size() >= 64) {   // bound the cache (a server fed ever new prompt lengths): drop all, recapture on demand
+            CK((int)hipStreamSynchronize(st));
+            for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
+            e->graphs.clear();
           }
-          if (graph) (void)hipGraphDestroy(graph);
+          e->graphs[k] = ex;
+          *out = ex;
         } else {
           (void)hipGetLastError();
         }
+        if (graph) (void)hipGraphDestroy(graph);
+      } else {
+        (void)hipGetLastError();
       }
-    }
-    for (; j < n_new; ++j) {
-      if (exec) CK((int)hipGraphLaunch(exec, st));
-      else IVG_TRY(step_body(e, st, g, Bc, nc, cs, sa, true));
+      return 0;
+    };
+    static const int multi = [] { const char* v = getenv("IVG_GRAPH_STEPS"); const int n = v ? atoi(v) : 8; return n < 1 ? 1 : (n > 32 ? 32 : n); }();
+    hipGraphExec_t exec = nullptr, exec_multi = nullptr;
+    if (j < n_new) IVG_TRY(get_graph(1, &exec));
+    if (exec && multi > 1 && n_new - j >= 2 * multi) IVG_TRY(get_graph(multi, &exec_multi));
+    while (j < n_new) {
+      if (exec_multi && n_new - j >= multi) { CK((int)hipGraphLaunch(exec_multi, st)); j += multi; }
+      else if (exec) { CK((int)hipGraphLaunch(exec, st)); ++j; }
+      else { IVG_TRY(step_body(e, st, g, Bc, nc, cs, sa, true)); ++j; }
     }
     if (j == n_new && n_new > 1) {
       IVG_TRY(reward());

@@ -47,12 +47,13 @@ def oracle_llama(cfg, sd, prefix="model."):
                     cfg["rope_theta"], cfg["max_position_embeddings"], prefix=prefix)
 
 
-def assert_sampled_rollout_matches(out, ref, oracle_model, uniforms, top_k, L0, what="rollout", tie=2e-5):
+def assert_sampled_rollout_matches(out, ref, oracle_model, uniforms, top_k, L0, what="rollout", tie=3e-3):
     """Sampled rollouts of two fp32 implementations agree token for token EXCEPT where a uniform lands on a boundary of the
-    inverse CDF closer than fp32 summation-order noise: there the draw may fall to the neighbouring kept token, and the rest of
-    that row legitimately diverges.  Every row must therefore equal the oracle's up to its first mismatch, and that mismatch
-    must be such a near-tie under the ORACLE's own logits (|u * total - cdf boundary| / total < `tie`, engine token = the
-    adjacent kept token).  Returns the number of rows that diverged at a near-tie."""
+    inverse CDF closer than what the logits bar allows: logits within 1e-3 (the parity bar) move every kept probability by up to
+    0.1 % and a CDF boundary by up to ~0.2 % of the mass; a draw closer than that to a boundary may fall to the neighbouring kept
+    token, and the rest of that row then legitimately diverges.  Every row must therefore equal the oracle's up to its first
+    mismatch, and that mismatch must be such a near-tie under the ORACLE's own logits (|u * total - cdf boundary| / total < `tie`,
+    engine token = the adjacent kept token).  Returns the number of rows that diverged at a near-tie."""
     out, ref = out.cpu(), ref.cpu()
     assert out.shape == ref.shape
     diverged = 0
