@@ -226,6 +226,11 @@ typedef struct {
   int64_t sa[3], sw[3], sy[3];
 } ivg_igemm_args;
 int ivg_op_igemm(const ivg_igemm_args* a, int dtype, ivg_stream stream);
+/* 3x3 convolution whose epilogue also reduces the GroupNorm statistics of its output into gn_part (double2 [Nimg][chunks][groups],
+ * at least Nimg * ceil(Hout*Wout/256) * ceil(N/64) * groups entries), then GroupNorm(+SiLU) of that output from those statistics
+ * into gn_out.  Returns the number of chunks per image (> 0) or a negative ivg_status. */
+int ivg_op_conv_gn(const ivg_igemm_args* a, int dtype, void* gn_part, int groups, const float* gamma, const float* beta, void* gn_out, float eps,
+                   int silu, ivg_stream stream);
 int ivg_op_skinny(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy, int splits, int flags,
                   int dtype, ivg_stream stream);
 int ivg_op_groupnorm(const void* X, void* Y, void* ws /* >= N*chunks*groups*16 B */, const float* gamma, const float* beta,

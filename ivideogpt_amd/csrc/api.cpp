@@ -288,8 +288,13 @@ int ivg_create(const ivg_config* cfg, const ivg_tensor* weights, int n_weights, 
   e->cfg = *cfg; e->device = device;
   auto bail = [&](int code) { g_create_err = e->err; ivg_destroy(e); return code; };
   if (hipSetDevice(device) != hipSuccess) { e->err = "hipSetDevice failed (no MI355X visible?)"; return bail(IVG_ERR_HIP); }
+  // Decode steps are launched eagerly by default: on ROCm 7.2 a replayed hipGraph leaves ~1 us MORE between two dependent kernel
+  // nodes than the same kernels launched one by one on the stream (config-2 rollout: 166 ms replayed, 149 ms eager; the host
+  // issues a launch in ~4 us against ~10 us of device time per kernel, so it stays ahead).  IVG_GRAPH=1 captures the step into
+  // a hipGraph (8 steps per launch) for callers that need the host thread back early; IVG_NO_GRAPH=1 wins over it.
   const char* ng = getenv("IVG_NO_GRAPH");
-  e->use_graph = !(ng && ng[0] == '1');
+  const char* yg = getenv("IVG_GRAPH");
+  e->use_graph = (yg && yg[0] == '1') && !(ng && ng[0] == '1');
   e->enc_dt = (DType)cfg->encode_dtype; e->dec_dt = (DType)cfg->decode_dtype; e->llm_dt = (DType)cfg->llm_dtype;
   e->ctx = cfg->context_length > 0 ? cfg->context_length : 1;
   for (int i = 0; i < n_weights; ++i) e->wmap[weights[i].name] = weights[i];
@@ -688,6 +693,25 @@ int ivg_op_igemm(const ivg_igemm_args* a, int dtype, ivg_stream stream) {
     if (rc > 0) return IVG_ERR_HIP;
   }
   return launch_igemm(g, (DType)dtype, (hipStream_t)stream) ? IVG_ERR_HIP : IVG_OK;
+}
+
+int ivg_op_conv_gn(const ivg_igemm_args* a, int dtype, void* gn_part, int groups, const float* gamma, const float* beta, void* gn_out, float eps,
+                   int silu, ivg_stream stream) {
+  // unit-test hook of the fused path: 3x3 convolution whose epilogue reduces the GroupNorm statistics of its output, followed by
+  // the apply-only GroupNorm that consumes them.  Returns the number of statistics chunks per image (> 0) or a negative status.
+  IgemmArgs g;
+  g.X = a->X; g.W = a->W; g.Y = a->Y; g.R = a->R; g.bias = a->bias;
+  g.Nimg = a->Nimg; g.Hin = a->Hin; g.Win = a->Win; g.Cin = a->Cin; g.ldx = a->ldx; g.Hout = a->Hout; g.Wout = a->Wout;
+  g.KH = a->KH; g.KW = a->KW; g.stride = a->stride; g.pad = a->pad; g.ups = a->ups; g.N = a->N; g.ldw = a->ldw;
+  g.c_img = a->c_img; g.c_pix = a->c_pix; g.c_ch = a->c_ch; g.c_grp = a->c_grp; g.c_grp_stride = a->c_grp_stride;
+  g.flags = a->flags; g.alpha = a->alpha;
+  g.gn_part = gn_part; g.gn_groups = groups;
+  const int rc = launch_conv3x3(g, (DType)dtype, (hipStream_t)stream);
+  if (rc != 0 || g.gn_chunks <= 0) return rc > 0 ? IVG_ERR_HIP : IVG_ERR_INVALID;
+  if (launch_groupnorm_apply(a->Y, gn_out, gn_part, g.gn_chunks, gamma, beta, nullptr, a->Nimg, a->Hout * a->Wout, a->N, groups, eps, silu,
+                             (DType)dtype, (hipStream_t)stream))
+    return IVG_ERR_HIP;
+  return g.gn_chunks;
 }
 
 int ivg_op_skinny(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy, int splits, int flags, int dtype, ivg_stream stream) {

@@ -50,6 +50,19 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Sum over the 16 lanes of a DPP row (lanes with equal lane >> 4), every lane receiving the total: DPP lane permutes run on the
+// VALU -- no LDS round trip as __shfl_xor (ds_bpermute) costs.
+template <int CTRL> __device__ __forceinline__ float dpp_add_f32(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float d) {
+  d = dpp_add_f32<0xB1>(d);    // quad_perm [1,0,3,2]: lane ^ 1
+  d = dpp_add_f32<0x4E>(d);    // quad_perm [2,3,0,1]: lane ^ 2
+  d = dpp_add_f32<0x141>(d);   // row_half_mirror: the other quad of the 8-lane half
+  d = dpp_add_f32<0x140>(d);   // row_mirror: the other half of the row
+  return d;
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // One-time per-DEVICE guard for hipFuncSetAttribute (the attribute is per device; a process may hold engines on several GPUs):

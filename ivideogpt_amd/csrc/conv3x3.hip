@@ -36,6 +36,8 @@ struct Conv3Dev {
   int c_grp, flags;
   int hb_bytes;                      // one halo buffer
   int stage_ok;                      // the 256 x BN staging tile of the epilogue fits in the workgroup's LDS
+  double2* gn_part;                  // GroupNorm statistics of the output (null: off): [img][chunk = spatial tile x N tile][group]
+  int gn_groups, gn_off;             // gn_off: byte offset of the per-channel partial sums in LDS (behind everything else)
   long long* dbg;                    // development: cycle stamps of workgroup 0 / wave 0 (null in production)
 };
 
@@ -219,6 +221,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv3x3_kernel(const
   // whole pixel rows, 16 B per lane, instead of 8-byte pieces at a 256-byte stride (store-issue bound otherwise)
   const bool staged = !(flags & IG_OUT_F32) && p.c_ch == 1 && p.c_pix == p.N && (p.N % BN) == 0 && p.stage_ok;
   constexpr int PITCH = BN * (int)sizeof(T) + 16;   // bytes per staged pixel row (+16: spreads the 16 pixel rows of a fragment over banks)
+  // GroupNorm statistics of what this workgroup stores (the consumer's GroupNorm then needs no pass of its own over the tensor):
+  // per lane the sums over its FM pixels of every channel it owns, reduced over the 16 pixel lanes, the NW / 2 pixel waves and
+  // finally the channels of a group -- all in a fixed order
+  const bool gn = p.gn_part != nullptr;
+  float gs[FN][4], gq[FN][4];
+#pragma unroll
+  for (int a = 0; a < FN; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { gs[a][r] = 0.f; gq[a][r] = 0.f; }
 #pragma unroll
   for (int b = 0; b < FM; ++b) {
     const int pix = (y0 + py[b]) * p.Wo + (x0 + px[b]);
@@ -257,6 +268,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv3x3_kernel(const
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
       }
+      if (gn) {   // statistics of the STORED values (rounded to the output type, as a separate pass over the tensor would see them)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float f = (flags & IG_OUT_F32) ? v[r] : to_f32(from_f32<T>(v[r]));
+          if (n0 + r < p.N) { gs[a][r] += f; gq[a][r] = fmaf(f, f, gq[a][r]); }
+        }
+      }
       if (staged) {
         unsigned char* dst = smem + (wm * 64 + b * 16 + lr) * PITCH + (wn * WN + a * 16 + lg * 4) * (int)sizeof(T);
         if constexpr (sizeof(T) == 2) *(bf16x4*)dst = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
@@ -280,8 +298,30 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv3x3_kernel(const
       }
     }
   }
+  if (gn) {
+    float* ch_s = (float*)(smem + p.gn_off);          // [NW / 2 pixel waves][BN channels]
+    float* ch_q = ch_s + (NW / 2) * BN;
+#pragma unroll
+    for (int a = 0; a < FN; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s1 = row16_sum(gs[a][r]), s2 = row16_sum(gq[a][r]);   // over the 16 pixel lanes (DPP: no LDS traffic)
+        if (lr == 0) { ch_s[wm * BN + wn * WN + a * 16 + lg * 4 + r] = s1; ch_q[wm * BN + wn * WN + a * 16 + lg * 4 + r] = s2; }
+      }
+  }
+  if (staged || gn) __syncthreads();
+  if (gn && tid < p.gn_groups) {
+    const float* ch_s = (const float*)(smem + p.gn_off);
+    const float* ch_q = ch_s + (NW / 2) * BN;
+    const int cpg = p.N / p.gn_groups;
+    const int c0 = max(tid * cpg, n_base), c1 = min(min((tid + 1) * cpg, n_base + BN), p.N);
+    double a1 = 0.0, a2 = 0.0;
+    for (int c = c0; c < c1; ++c)
+      for (int w = 0; w < NW / 2; ++w) { a1 += (double)ch_s[w * BN + c - n_base]; a2 += (double)ch_q[w * BN + c - n_base]; }
+    const long chunk = (long)t_in * p.tiles_n + tile_n;
+    p.gn_part[((long)img * p.tiles_per_img * p.tiles_n + chunk) * p.gn_groups + tid] = double2{a1, a2};
+  }
   if (staged) {
-    __syncthreads();
     constexpr int CPR = BN * (int)sizeof(T) / 16;   // 16-byte chunks per staged pixel row
     T* Y = (T*)p.Y;
     const long ibase = (long)(img / p.c_grp) * p.c_grp_stride + (long)(img % p.c_grp) * p.c_img;
@@ -302,6 +342,7 @@ static int launch_c3(const Conv3Dev& d, int nimg, hipStream_t stream) {
   Conv3Dev dd = d;
   dd.stage_ok = stage <= (NW == 8 ? 80 : 160) * 1024;        // NW = 8 keeps two workgroups per CU (fp32 x 128 channels stores directly)
   if (dd.stage_ok && smem < stage) smem = stage;
+  if (d.gn_part) { dd.gn_off = (smem + 15) & ~15; smem = dd.gn_off + 2 * (NW / 2) * BN * 4; }
   static unsigned long long attr_set = 0;
   auto kfn = conv3x3_kernel<T, BN, UPS, ABL, NW>;
   if (first_time_on_device(attr_set)) {
@@ -312,6 +353,8 @@ static int launch_c3(const Conv3Dev& d, int nimg, hipStream_t stream) {
   hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(NW * 64), smem, stream, dd);
   return (int)hipGetLastError();
 }
+
+int conv3x3_gn_chunks_bound(int Hout, int Wout, int N) { return cdiv((long)Hout * Wout, 256) * cdiv(N, 64); }
 
 bool conv3x3_enabled() {
   static int v = -1;
@@ -356,6 +399,13 @@ int launch_conv3x3(const IgemmArgs& a, DType dtype, hipStream_t stream) {
   d.c_img = a.c_img; d.c_pix = a.c_pix; d.c_ch = a.c_ch; d.c_grp = a.c_grp > 0 ? a.c_grp : 1; d.c_grp_stride = a.c_grp_stride;
   if (a.c_grp <= 1 && a.c_grp_stride == 0) d.c_grp_stride = a.c_img;
   d.flags = a.flags;
+  d.gn_part = nullptr; d.gn_groups = 0; d.gn_off = 0;
+  if (a.gn_part && a.gn_groups > 0 && a.gn_groups <= 64 && a.N % a.gn_groups == 0 && !nw16 && (a.c_grp <= 1)) {
+    d.gn_part = (double2*)a.gn_part; d.gn_groups = a.gn_groups;
+    a.gn_chunks = d.tiles_per_img * d.tiles_n;
+  } else {
+    a.gn_chunks = 0;
+  }
   d.hb_bytes = nw16 ? cdiv(d.HTH * d.HTW * 4, 1024) * 16384 : cdiv(d.HTH * d.HTW * 4, 512) * 8192;
   {
     static long long* dbg_buf = nullptr;
@@ -373,8 +423,8 @@ int launch_conv3x3(const IgemmArgs& a, DType dtype, hipStream_t stream) {
       }
     }
   }
-  if (2 * d.hb_bytes + 3 * bn * 64 > (nw16 ? 160 : 80) * 1024) return -1;
-  if (((uintptr_t)a.X & 15) || ((uintptr_t)a.W & 15)) return -1;
+  if (2 * d.hb_bytes + 3 * bn * 64 > (nw16 ? 160 : 80) * 1024) { a.gn_chunks = 0; return -1; }
+  if (((uintptr_t)a.X & 15) || ((uintptr_t)a.W & 15)) { a.gn_chunks = 0; return -1; }
   {  // development ablations of the bf16 / BN = 128 / no-upsample instance (IVG_C3_ABLATE=<mask>)
     static int abl = -1;
     if (abl < 0) { const char* e = getenv("IVG_C3_ABLATE"); abl = e ? atoi(e) : 0; }

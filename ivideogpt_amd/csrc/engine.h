@@ -85,7 +85,7 @@ struct ivg_engine {
   char* gen_buf = nullptr;   // persistent decode-step buffers (fixed addresses -> graph replay)
   size_t gen_bytes = 0;
   std::unordered_map<std::string, hipGraphExec_t> graphs;
-  bool use_graph = true;
+  bool use_graph = false;     // IVG_GRAPH=1 (see ivg_create)
   int chains = 1;            // concurrent dependency chains (measured: no gain on MI355X, graph branches serialise; IVG_CHAINS=n to try)
                              // of a decode step of a decode step (batch rows split across side streams)
   hipStream_t side[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -11,6 +11,9 @@ namespace ivg {
 
 #define IVG_TRY(x) do { int _r = (x); if (_r != 0) return _r; } while (0)
 
+// GroupNorm statistics of an activation tensor that its PRODUCER (a conv3x3 epilogue) already reduced: [N][chunks][groups] double2
+struct GnStats { void* part = nullptr; int chunks = 0; };
+
 struct Run {
   ivg_engine* e;
   hipStream_t st;
@@ -18,11 +21,14 @@ struct Run {
 
   // ---- primitives (tokenizer.cpp)
   int conv(DType dt, const void* X, int N, int H, int W, const ConvW& c, void* Y, int stride, int ups, const void* Rres, int flags,
-           int out_f32);
+           int out_f32, GnStats* out_stats = nullptr /* in: .part = buffer; out: .chunks (0: the statistics were not produced) */);
   int gemm(DType dt, const IgemmArgs& a, double flops, double bytes);
   int linear(DType dt, const void* X, long rows, const ConvW& c, void* Y, const void* Rres, int flags, int out_f32);
-  int gnorm(DType dt, const void* X, void* Y, int N, int P, int C, const NormW& n, float eps, int silu, const float* pos);
-  int resnet(DType dt, const void* x, int N, int H, int W, const ResnetW& r, void* out);
+  int gnorm(DType dt, const void* X, void* Y, int N, int P, int C, const NormW& n, float eps, int silu, const float* pos,
+            const GnStats* stats = nullptr /* statistics of X from its producer: skips the statistics pass */);
+  int resnet(DType dt, const void* x, int N, int H, int W, const ResnetW& r, void* out, const GnStats* x_stats = nullptr,
+             GnStats* out_stats = nullptr);
+  size_t gn_stats_bytes(int N, int H, int W, int C) const;
   int self_attention(DType dt, const void* x, int N, int P, int C, const AttnW& a, void* out);
   int xatt_project_kv(DType dt, const void* feat, int B, const XAttW& x, void* Kp, void* VpT);
   int cross_attention(DType dt, const void* z, int B, int F, const XAttW& x, const void* Kp, const void* VpT, void* out);

@@ -35,6 +35,12 @@ struct IgemmArgs {
   long c_grp_stride = 0;
   int flags = 0;
   float alpha = 1.0f;
+  // GroupNorm statistics of the OUTPUT produced in the epilogue (conv3x3.hip only; null = off): per-(image, chunk, group)
+  // (sum, sum of squares) of the stored values, double2 [Nimg][gn_chunks][gn_groups] in the layout norm.hip's gn_apply reads.
+  // The launcher sets gn_chunks (out); the buffer must hold at least Nimg * gn_chunks_bound(...) * gn_groups entries.
+  void* gn_part = nullptr;
+  int gn_groups = 0;
+  mutable int gn_chunks = 0;
   // batch z = (z0 * nb1 + z1) * nb2 + z2 ; element strides per operand
   int nb0 = 1, nb1 = 1, nb2 = 1;
   long sa[3] = {0, 0, 0}, sw[3] = {0, 0, 0}, sy[3] = {0, 0, 0};
@@ -46,6 +52,8 @@ int launch_igemm(const IgemmArgs& a, DType dtype, hipStream_t stream);
 int launch_gemm256(const IgemmArgs& a, DType dtype, hipStream_t stream);
 // LDS-halo 3x3 stride-1 kernel (conv3x3.hip); returns -1 when the shape is not covered (use launch_igemm then)
 int launch_conv3x3(const IgemmArgs& a, DType dtype, hipStream_t stream);
+// upper bound of the GroupNorm statistics chunks a conv3x3 launch with this output geometry writes per image
+int conv3x3_gn_chunks_bound(int Hout, int Wout, int N);
 
 // Skinny GEMM for the autoregressive decode steps (M <= 128 rows, weights streamed once):
 //   Y[m][n] = epi( sum_k X[m][k] * W[n][k] ),  X row stride ldx, W row stride ldw.

@@ -143,6 +143,23 @@ int launch_groupnorm(const void* X, void* Y, void* part_ws, const float* gamma, 
   return (int)hipGetLastError();
 }
 
+// apply only: the statistics were produced elsewhere (conv3x3 epilogue) as double2 [N][nchunks][groups]
+int launch_groupnorm_apply(const void* X, void* Y, const void* part, int nchunks, const float* gamma, const float* beta, const float* pos,
+                           int N, int P, int C, int groups, float eps, int silu, DType dt, hipStream_t st) {
+  const int vec = dt == BF16 ? 8 : 4;
+  if (C % vec != 0 || C % groups != 0 || C / vec > 256 || groups > 256 || nchunks <= 0) return (int)hipErrorInvalidValue;
+  const int px_per_block = 256;
+  dim3 g2(cdiv(P, px_per_block), N);
+  const size_t smem2 = (size_t)C * sizeof(f32x2);
+  if (dt == BF16)
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, g2, dim3(256), smem2, st, (const bf16_t*)X, (bf16_t*)Y, (const double2*)part, nchunks, gamma, beta,
+                       pos, P, C, groups, eps, silu, px_per_block);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<float>, g2, dim3(256), smem2, st, (const float*)X, (float*)Y, (const double2*)part, nchunks, gamma, beta, pos,
+                       P, C, groups, eps, silu, px_per_block);
+  return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ RMSNorm
 // One workgroup per row (H <= 2048), every thread owns up to 8 strided elements so all loads of a pass are
 // independent (the decode step is latency-bound: M = batch rows only).  x (T) is updated in place when split-K

@@ -11,6 +11,9 @@ int gn_num_chunks(int P);
 // pos[P][C] (fp32).  part_ws: N * gn_num_chunks(P) * groups double2 of scratch.
 int launch_groupnorm(const void* X, void* Y, void* part_ws, const float* gamma, const float* beta, const float* pos,
                      int N, int P, int C, int groups, float eps, int silu, DType dt, hipStream_t st);
+// the apply half alone, with statistics produced by a conv3x3 epilogue (IgemmArgs::gn_part): double2 [N][nchunks][groups]
+int launch_groupnorm_apply(const void* X, void* Y, const void* part, int nchunks, const float* gamma, const float* beta, const float* pos,
+                           int N, int P, int C, int groups, float eps, int silu, DType dt, hipStream_t st);
 // x[M][H] += sum_s part[s][M][H] (in place, T);  out = rmsnorm(x) * w   (out may be null: residual update only)
 int launch_add_rmsnorm(void* x, long x_stride, const float* part, int splits, const float* w, void* out, int M, int H, float eps,
                        DType dt, hipStream_t st);

@@ -23,9 +23,20 @@ namespace ivg {
 static size_t esz(DType d) { return d == BF16 ? 2 : 4; }
 
 // -------------------------------------------------------------------------------------------- primitive wrappers
+static bool gn_fuse_enabled() {   // IVG_GN_FUSE=0: every GroupNorm computes its own statistics (A/B runs)
+  static int v = -1;
+  if (v < 0) { const char* s = getenv("IVG_GN_FUSE"); v = (s && s[0] == '0') ? 0 : 1; }
+  return v == 1;
+}
+
+size_t Run::gn_stats_bytes(int N, int H, int W, int C) const {
+  return (size_t)N * conv3x3_gn_chunks_bound(H, W, C) * e->cfg.norm_num_groups * sizeof(double) * 2;
+}
+
 int Run::conv(DType dt, const void* X, int N, int H, int W, const ConvW& c, void* Y, int stride, int ups, const void* Rres, int flags,
-              int out_f32) {
+              int out_f32, GnStats* out_stats) {
   Run& R = *this;
+  if (out_stats) out_stats->chunks = 0;
   const int k = c.k;
   int Ho, Wo, pad;
   if (ups) { Ho = 2 * H; Wo = 2 * W; pad = 1; }
@@ -40,12 +51,13 @@ int Run::conv(DType dt, const void* X, int N, int H, int W, const ConvW& c, void
   a.c_img = (long)Ho * Wo * c.cout; a.c_pix = c.cout; a.c_ch = 1;
   a.flags = flags | (c.b ? IG_BIAS_N : 0) | (Rres ? IG_RESIDUAL : 0) | (out_f32 ? IG_OUT_F32 : 0);
   if (planning) return 0;
+  if (out_stats && out_stats->part && gn_fuse_enabled()) { a.gn_part = out_stats->part; a.gn_groups = e->cfg.norm_num_groups; }
   const double flops = 2.0 * N * Ho * Wo * (double)c.cout * k * k * c.cin;
   const double bytes = (double)esz(dt) * ((double)N * H * W * c.cin + (double)c.cout * k * k * c.cin) + (double)(out_f32 ? 4 : esz(dt)) * N * Ho * Wo * c.cout;
   if (k == 3 && stride == 1) {  // FLOP majority: LDS-halo kernel; shapes it does not cover fall through to the implicit GEMM
     prof_begin(dt, flops, bytes, 2);
     const int rc = launch_conv3x3(a, dt, st);
-    if (rc == 0) { prof_end(dt, 2); return 0; }
+    if (rc == 0) { prof_end(dt, 2); if (out_stats) out_stats->chunks = a.gn_chunks; return 0; }
     prof_cancel(dt, 2);
     if (rc > 0) CK(rc);
   }
@@ -78,9 +90,14 @@ int Run::linear(DType dt, const void* X, long rows, const ConvW& c, void* Y, con
               (double)esz(dt) * ((double)rows * c.cin + (double)c.cout * c.cin) + (double)(out_f32 ? 4 : esz(dt)) * rows * c.cout);
 }
 
-int Run::gnorm(DType dt, const void* X, void* Y, int N, int P, int C, const NormW& n, float eps, int silu, const float* pos) {
+int Run::gnorm(DType dt, const void* X, void* Y, int N, int P, int C, const NormW& n, float eps, int silu, const float* pos,
+               const GnStats* stats) {
   Run& R = *this;
   const int groups = e->cfg.norm_num_groups;
+  if (stats && stats->part && stats->chunks > 0 && !planning) {   // the producer's epilogue already reduced the statistics
+    CK(launch_groupnorm_apply(X, Y, stats->part, stats->chunks, n.g, n.b, pos, N, P, C, groups, eps, silu, dt, st));
+    return 0;
+  }
   const size_t m = e->ws.mark();
   void* part = e->ws.alloc((size_t)N * gn_num_chunks(P) * groups * sizeof(double) * 2);
   int rc = 0;
@@ -91,21 +108,23 @@ int Run::gnorm(DType dt, const void* X, void* Y, int N, int P, int C, const Norm
 }
 
 // x [N,H,W,cin] -> out [N,H,W,cout]
-int Run::resnet(DType dt, const void* x, int N, int H, int W, const ResnetW& r, void* out) {
+int Run::resnet(DType dt, const void* x, int N, int H, int W, const ResnetW& r, void* out, const GnStats* x_stats, GnStats* out_stats) {
   Run& R = *this;
   const size_t m = e->ws.mark();
   const size_t px = (size_t)N * H * W;
   void* t = e->ws.alloc(px * std::max(r.cin, r.cout) * esz(dt));
   void* h = e->ws.alloc(px * r.cout * esz(dt));
-  IVG_TRY(gnorm(dt, x, t, N, H * W, r.cin, r.n1, 1e-6f, 1, nullptr));
-  IVG_TRY(conv(dt, t, N, H, W, r.c1, h, 1, 0, nullptr, 0, 0));
-  IVG_TRY(gnorm(dt, h, t, N, H * W, r.cout, r.n2, 1e-6f, 1, nullptr));
+  GnStats hs;   // statistics of h for norm2, reduced by conv1's epilogue (h is read once less)
+  hs.part = e->ws.alloc(gn_stats_bytes(N, H, W, r.cout));
+  IVG_TRY(gnorm(dt, x, t, N, H * W, r.cin, r.n1, 1e-6f, 1, nullptr, x_stats));
+  IVG_TRY(conv(dt, t, N, H, W, r.c1, h, 1, 0, nullptr, 0, 0, &hs));
+  IVG_TRY(gnorm(dt, h, t, N, H * W, r.cout, r.n2, 1e-6f, 1, nullptr, &hs));
   const void* res = x;
   if (r.has_sc) {
     IVG_TRY(conv(dt, x, N, H, W, r.sc, out, 1, 0, nullptr, 0, 0));
     res = out;  // in-place residual: every element is read then written by the same thread
   }
-  IVG_TRY(conv(dt, t, N, H, W, r.c2, out, 1, 0, res, 0, 0));
+  IVG_TRY(conv(dt, t, N, H, W, r.c2, out, 1, 0, res, 0, 0, out_stats));
   e->ws.reset(m);
   return 0;
 }
@@ -257,33 +276,42 @@ int Run::encoder_trunk(const TrunkW& w, const void* pixels, DType pix_dt, int B,
   }
   void* a = e->ws.alloc((size_t)N * max_el * esz(dt));
   void* b = e->ws.alloc((size_t)N * max_el * esz(dt));
+  // GroupNorm statistics travel with the activation: a conv3x3 that produces a tensor also reduces its (sum, sum of squares) per
+  // group, so the next block's first GroupNorm does not read the tensor once more just for that (sa / sb belong to a / b)
+  size_t st_bytes = 0;
+  {
+    int s = side;
+    for (int i = 0; i < nl; ++i) { st_bytes = std::max(st_bytes, gn_stats_bytes(N, s, s, c.block_out_channels[i])); if (i != nl - 1) s /= 2; }
+  }
+  GnStats sa, sb;
+  sa.part = e->ws.alloc(st_bytes); sb.part = e->ws.alloc(st_bytes);
   if (!planning)
     CK(launch_conv_in(pixels, pix_dt, w.conv_in_raw_w, w.conv_in.b, a, dt, N, per, T_total, t0, side, side, c.block_out_channels[0], st));
   int k = 0;
   for (int i = 0; i < nl; ++i) {
     for (size_t j = 0; j < w.blocks[i].size(); ++j) {
-      IVG_TRY(resnet(dt, a, N, side, side, w.blocks[i][j], b));
-      std::swap(a, b);
+      IVG_TRY(resnet(dt, a, N, side, side, w.blocks[i][j], b, &sa, &sb));
+      std::swap(a, b); std::swap(sa, sb);
     }
     if (i != nl - 1) {
       IVG_TRY(conv(dt, a, N, side, side, w.resample[i], b, 2, 0, nullptr, 0, 0));
-      std::swap(a, b);
+      std::swap(a, b); std::swap(sa, sb); sa.chunks = 0;   // (stride-2 conv: implicit GEMM, no statistics)
       side /= 2;
     }
     const int C = c.block_out_channels[i];
     if (cond && side <= c.max_att_resolution) {
       IVG_TRY(cross_attention(dt, a, B, per, w.xatt[k], Kp[k], Vp[k], b));
-      std::swap(a, b);
+      std::swap(a, b); std::swap(sa, sb); sa.chunks = 0;
       ++k;
     }
     if (keep && (*keep)[i + 1].p && !planning)
       CK((int)hipMemcpyAsync((*keep)[i + 1].p, a, (size_t)N * side * side * C * esz(dt), hipMemcpyDeviceToDevice, st));
   }
   const int C = c.block_out_channels[nl - 1];
-  IVG_TRY(resnet(dt, a, N, side, side, w.mid0, b)); std::swap(a, b);
-  if (w.has_attn) { IVG_TRY(self_attention(dt, a, N, side * side, C, w.attn, b)); std::swap(a, b); }
-  IVG_TRY(resnet(dt, a, N, side, side, w.mid1, b)); std::swap(a, b);
-  IVG_TRY(gnorm(dt, a, b, N, side * side, C, w.norm_out, 1e-6f, 1, nullptr));
+  IVG_TRY(resnet(dt, a, N, side, side, w.mid0, b, &sa, &sb)); std::swap(a, b); std::swap(sa, sb);
+  if (w.has_attn) { IVG_TRY(self_attention(dt, a, N, side * side, C, w.attn, b)); std::swap(a, b); std::swap(sa, sb); sa.chunks = 0; }
+  IVG_TRY(resnet(dt, a, N, side, side, w.mid1, b, &sa, &sb)); std::swap(a, b); std::swap(sa, sb);
+  IVG_TRY(gnorm(dt, a, b, N, side * side, C, w.norm_out, 1e-6f, 1, nullptr, &sa));
   IVG_TRY(conv(dt, b, N, side, side, w.conv_out, latent, 1, 0, nullptr, 0, 0));
   e->ws.reset(m);
   return 0;
@@ -395,37 +423,48 @@ int Run::decoder_trunk(const TrunkW& w, const void* z, int B, int per, int T_tot
   }
   void* a = e->ws.alloc((size_t)N * max_el * esz(dt));
   void* b = e->ws.alloc((size_t)N * max_el * esz(dt));
+  size_t st_bytes = 0;   // GroupNorm statistics travel with the activation (see encoder_trunk)
+  {
+    int s = 16;
+    for (int i = 0; i < nl; ++i) {
+      const int Cl = c.block_out_channels[nl - 1 - i];
+      st_bytes = std::max(st_bytes, gn_stats_bytes(N, s, s, Cl));
+      if (i != nl - 1) { s *= 2; st_bytes = std::max(st_bytes, gn_stats_bytes(N, s, s, Cl)); }
+    }
+  }
+  GnStats sa, sb;
+  sa.part = e->ws.alloc(st_bytes); sb.part = e->ws.alloc(st_bytes);
   int side = 16;
   const int Ctop = c.block_out_channels[nl - 1];
-  IVG_TRY(conv(dt, z, N, side, side, w.conv_in, a, 1, 0, nullptr, 0, 0));
-  IVG_TRY(resnet(dt, a, N, side, side, w.mid0, b)); std::swap(a, b);
-  if (w.has_attn) { IVG_TRY(self_attention(dt, a, N, side * side, Ctop, w.attn, b)); std::swap(a, b); }
-  IVG_TRY(resnet(dt, a, N, side, side, w.mid1, b)); std::swap(a, b);
+  IVG_TRY(conv(dt, z, N, side, side, w.conv_in, a, 1, 0, nullptr, 0, 0, &sa));
+  IVG_TRY(resnet(dt, a, N, side, side, w.mid0, b, &sa, &sb)); std::swap(a, b); std::swap(sa, sb);
+  if (w.has_attn) { IVG_TRY(self_attention(dt, a, N, side * side, Ctop, w.attn, b)); std::swap(a, b); std::swap(sa, sb); sa.chunks = 0; }
+  IVG_TRY(resnet(dt, a, N, side, side, w.mid1, b, &sa, &sb)); std::swap(a, b); std::swap(sa, sb);
   if (keep && (*keep)[1].p && !planning)
     CK((int)hipMemcpyAsync((*keep)[1].p, a, (size_t)N * side * side * Ctop * esz(dt), hipMemcpyDeviceToDevice, st));
   int k = 0;
-  if (cond) { IVG_TRY(cross_attention(dt, a, B, per, w.xatt[0], Kp[0], Vp[0], b)); std::swap(a, b); k = 1; }
+  if (cond) { IVG_TRY(cross_attention(dt, a, B, per, w.xatt[0], Kp[0], Vp[0], b)); std::swap(a, b); std::swap(sa, sb); sa.chunks = 0; k = 1; }
   for (int i = 0; i < nl; ++i) {
     const int C = c.block_out_channels[nl - 1 - i];
     for (size_t j = 0; j < w.blocks[i].size(); ++j) {
-      IVG_TRY(resnet(dt, a, N, side, side, w.blocks[i][j], b));
-      std::swap(a, b);
+      IVG_TRY(resnet(dt, a, N, side, side, w.blocks[i][j], b, &sa, &sb));
+      std::swap(a, b); std::swap(sa, sb);
     }
     if (i != nl - 1) {
-      IVG_TRY(conv(dt, a, N, side, side, w.resample[i], b, 1, 1, nullptr, 0, 0));  // nearest x2 folded into the gather
-      std::swap(a, b);
+      IVG_TRY(conv(dt, a, N, side, side, w.resample[i], b, 1, 1, nullptr, 0, 0, &sb));  // nearest x2 folded into the gather
+      std::swap(a, b); std::swap(sa, sb);
       side *= 2;
     }
     if (cond && side <= c.max_att_resolution) {
       IVG_TRY(cross_attention(dt, a, B, per, w.xatt[k], Kp[k], Vp[k], b));
-      std::swap(a, b);
+      std::swap(a, b); std::swap(sa, sb); sa.chunks = 0;
       ++k;
     }
     if (keep && (*keep)[i + 2].p && !planning)
       CK((int)hipMemcpyAsync((*keep)[i + 2].p, a, (size_t)N * side * side * C * esz(dt), hipMemcpyDeviceToDevice, st));
   }
   const int C0 = c.block_out_channels[0];
-  IVG_TRY(gnorm(dt, a, b, N, side * side, C0, w.norm_out, 1e-6f, 1, nullptr));
+  IVG_TRY(gnorm(dt, a, b, N, side * side, C0, w.norm_out, 1e-6f, 1, nullptr, &sa));
   {  // conv_out straight into the planar (B, T, 3, H, W) float32 clip
     IgemmArgs g;
     g.X = b; g.W = w.conv_out.w; g.Y = out_pixels + (long)t0 * 3 * res * res; g.bias = w.conv_out.b;

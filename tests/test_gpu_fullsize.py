@@ -100,7 +100,7 @@ def test_rollout_full_batch_properties(models, monkeypatch):
     top1 = llm.generate(prompt[:8], do_sample=True, top_k=1, max_new_tokens=n_short, uniforms=u[:8, :n_short].contiguous())
     assert torch.equal(greedy, top1)
     # eager launches == replayed step graph
-    monkeypatch.setenv("IVG_NO_GRAPH", "1")
+    monkeypatch.setenv("IVG_GRAPH", "1")
     from ivideogpt_amd import LlamaForCausalLM
     from ivideogpt_amd import weights as W
     eager = LlamaForCausalLM(lcfg, W.random_llama_state_dict(lcfg, 6), dtype="bf16").to(DEV)

@@ -178,7 +178,7 @@ def test_generate_graph_replay_equals_eager(monkeypatch):
     cfg, sd, g = llama_fixture("llama_tiny_ctx1_free.npz")
     prompt = torch.from_numpy(g["prompt"]).to(DEV)
     a = make_llm(cfg, sd).generate(prompt, do_sample=False, max_new_tokens=40)
-    monkeypatch.setenv("IVG_NO_GRAPH", "1")
+    monkeypatch.setenv("IVG_GRAPH", "1")
     b = make_llm(cfg, sd).generate(prompt, do_sample=False, max_new_tokens=40)
     assert torch.equal(a, b)
 

@@ -540,3 +540,53 @@ def test_ingest_fractal_sample_matches_reference_clip():
     np.random.seed(0)
     host, _ = NPZParser(16, 64).parse(os.path.join(gold, "fractal_sample.npz"), "fractal20220817_data")
     assert torch.equal(host, ref), "host-side parser must reproduce the reference's clip bit for bit"
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("H,Cin,Cout,ups,res,silu", [(64, 128, 128, 0, 1, 1), (32, 256, 512, 0, 0, 1), (16, 512, 512, 1, 0, 0), (32, 128, 64, 1, 1, 1),
+                                                      (16, 64, 768, 0, 1, 1), (16, 64, 192, 0, 0, 0)])
+def test_conv3x3_epilogue_groupnorm_statistics(dt, H, Cin, Cout, ups, res, silu):
+    """The GroupNorm statistics a conv3x3 epilogue reduces for its own output (so the consuming GroupNorm skips its statistics
+    pass): conv -> GroupNorm(32 groups)[+ SiLU] from those statistics == torch group_norm of the conv output AS STORED, incl. groups
+    that straddle two channel tiles (768 channels: 24 per group, tiles of 128), several spatial tiles, upsampling and the in-place
+    residual."""
+    L, l = lib()
+    g = torch.Generator().manual_seed(H + Cin + Cout + 1)
+    Nb, groups = 3, 32
+    x = q(torch.randn(Nb, Cin, H, H, generator=g), dt)
+    w = q(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5, dt)
+    b = torch.randn(Cout, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(Cout, generator=g), 0.2 * torch.randn(Cout, generator=g)
+    Ho = 2 * H if ups else H
+    r = q(torch.randn(Nb, Cout, Ho, Ho, generator=g), dt) if res else None
+    X = x.permute(0, 2, 3, 1).contiguous().to(DEV, tdt(dt))
+    Wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(DEV, tdt(dt))
+    Y = torch.full((Nb, Ho, Ho, Cout), float("nan"), device=DEV, dtype=tdt(dt))
+    if res:
+        Y.copy_(r.permute(0, 2, 3, 1))
+    bd = b.to(DEV)
+    a = L.IvgIgemmArgs()
+    a.X, a.W, a.Y, a.R, a.bias = X.data_ptr(), Wp.data_ptr(), Y.data_ptr(), (Y.data_ptr() if res else None), bd.data_ptr()
+    for k, v in dict(Nimg=Nb, Hin=H, Win=H, Cin=Cin, ldx=Cin, Hout=Ho, Wout=Ho, KH=3, KW=3, stride=1, pad=1, ups=ups, N=Cout, ldw=9 * Cin,
+                     c_img=Ho * Ho * Cout, c_pix=Cout, c_ch=1, c_grp=1, c_grp_stride=0, flags=1 | (4 if res else 0), alpha=1.0, nb0=1, nb1=1,
+                     nb2=1).items():
+        setattr(a, k, v)
+    bound = ((Ho * Ho + 255) // 256) * ((Cout + 63) // 64)
+    part = torch.full((Nb * bound * groups * 2,), float("nan"), dtype=torch.float64, device=DEV)
+    out = torch.full((Nb, Ho, Ho, Cout), float("nan"), device=DEV, dtype=tdt(dt))
+    gd, btd = gamma.to(DEV), beta.to(DEV)
+    chunks = l.ivg_op_conv_gn(C.byref(a), code(dt), P(part), groups, P(gd), P(btd), P(out), 1e-6, silu, stream())
+    torch.cuda.synchronize()
+    assert 0 < chunks <= bound, chunks
+    stored = Y.float().permute(0, 3, 1, 2).cpu().double()          # the conv output as the engine stored it
+    ref = F.group_norm(stored, groups, gamma.double(), beta.double(), eps=1e-6)
+    if silu:
+        ref = F.silu(ref)
+    assert torch.isfinite(out.float()).all()
+    assert rel_err(out.float().permute(0, 3, 1, 2), ref) < (2e-5 if dt == "fp32" else TOL[dt])
+    # the statistics themselves: per (image, group) sums over the chunks
+    st = part[:Nb * chunks * groups * 2].view(Nb, chunks, groups, 2).sum(1).cpu()
+    cpg = Cout // groups
+    sv = stored.reshape(Nb, groups, cpg * Ho * Ho)
+    assert ((st[..., 0] - sv.sum(-1)).abs() / (sv.abs().sum(-1) + 1e-9)).max().item() < 1e-5
+    assert ((st[..., 1] - (sv * sv).sum(-1)).abs() / (sv * sv).sum(-1)).max().item() < 1e-5

@@ -130,6 +130,14 @@ int main(int argc, char** argv) {
     printf("T1 boundary: empty kernel grid %4d: %.2f us per launch (graph of %d)\n", grid, time_graph(ex, st, 9) / N, N);
     CK(hipGraphExecDestroy(ex));
   }
+  if (argc > 1 && argv[1][0] == 'b') {   // boundary only (A/B of runtime settings)
+    const int N = 64;
+    hipGraphExec_t ex = capture(st, [&] {
+      for (int i = 0; i < N; ++i) hipLaunchKernelGGL((burst_kernel<6, 1, 0>), dim3(192), dim3(512), 0, st, g_small, 0L, 384, g_out);
+    });
+    printf("T2 burst line L2-shared U 6 grid 192: %.2f us per launch\n", time_graph(ex, st, 9) / N);
+    return 0;
+  }
   // ---- T2
   for (int grid : {192, 256}) {
     run_burst<6, 0, 0>(st, grid, 0, "frag  L2-shared");
