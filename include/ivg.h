@@ -231,6 +231,9 @@ int ivg_op_igemm(const ivg_igemm_args* a, int dtype, ivg_stream stream);
  * into gn_out.  Returns the number of chunks per image (> 0) or a negative ivg_status. */
 int ivg_op_conv_gn(const ivg_igemm_args* a, int dtype, void* gn_part, int groups, const float* gamma, const float* beta, void* gn_out, float eps,
                    int silu, ivg_stream stream);
+/* y = conv3x3(silu(GroupNorm(x))) (+ bias, residual) with the GroupNorm applied inside the convolution's input staging: the
+ * normalised tensor is never written.  ws: scratch of at least Nimg * (ceil(Hin*Win/1024) * groups * 16 + Cin * 8) bytes. */
+int ivg_op_gn_conv(const ivg_igemm_args* a, int dtype, int groups, const float* gamma, const float* beta, float eps, void* ws, ivg_stream stream);
 int ivg_op_skinny(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy, int splits, int flags,
                   int dtype, ivg_stream stream);
 int ivg_op_groupnorm(const void* X, void* Y, void* ws /* >= N*chunks*groups*16 B */, const float* gamma, const float* beta,

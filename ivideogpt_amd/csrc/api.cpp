@@ -714,6 +714,26 @@ int ivg_op_conv_gn(const ivg_igemm_args* a, int dtype, void* gn_part, int groups
   return g.gn_chunks;
 }
 
+int ivg_op_gn_conv(const ivg_igemm_args* a, int dtype, int groups, const float* gamma, const float* beta, float eps, void* ws, ivg_stream stream) {
+  // unit-test hook: y = conv3x3(silu(GroupNorm(x))) with the normalisation applied inside the convolution's input staging.
+  // ws: scratch of at least Nimg * (ceil(H*W/1024) * groups * 16 + Cin * 8) bytes.  Returns IVG_ERR_INVALID when the fused kernel
+  // does not cover the shape.
+  IgemmArgs g;
+  g.X = a->X; g.W = a->W; g.Y = a->Y; g.R = a->R; g.bias = a->bias;
+  g.Nimg = a->Nimg; g.Hin = a->Hin; g.Win = a->Win; g.Cin = a->Cin; g.ldx = a->ldx; g.Hout = a->Hout; g.Wout = a->Wout;
+  g.KH = a->KH; g.KW = a->KW; g.stride = a->stride; g.pad = a->pad; g.ups = a->ups; g.N = a->N; g.ldw = a->ldw;
+  g.c_img = a->c_img; g.c_pix = a->c_pix; g.c_ch = a->c_ch; g.c_grp = a->c_grp; g.c_grp_stride = a->c_grp_stride;
+  g.flags = a->flags; g.alpha = a->alpha;
+  const int P = a->Hin * a->Win, nch = gn_num_chunks(P);
+  char* part = (char*)ws;
+  char* coef = part + (size_t)a->Nimg * nch * groups * 16;
+  if (launch_groupnorm_partial(a->X, part, a->Nimg, P, a->Cin, groups, (DType)dtype, (hipStream_t)stream)) return IVG_ERR_HIP;
+  if (launch_gn_coef(part, nch, gamma, beta, a->Nimg, P, a->Cin, groups, eps, coef, (hipStream_t)stream)) return IVG_ERR_HIP;
+  g.gn_in_coef = coef;
+  const int rc = launch_conv3x3(g, (DType)dtype, (hipStream_t)stream);
+  return rc == 0 ? IVG_OK : (rc > 0 ? IVG_ERR_HIP : IVG_ERR_INVALID);
+}
+
 int ivg_op_skinny(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy, int splits, int flags, int dtype, ivg_stream stream) {
   SkinnyArgs s; s.X = X; s.W = W; s.Y = Y; s.M = M; s.N = N; s.K = K; s.ldx = ldx; s.ldw = ldw; s.ldy = ldy; s.splits = splits; s.flags = flags;
   return launch_skinny(s, (DType)dtype, (hipStream_t)stream) ? IVG_ERR_HIP : IVG_OK;

@@ -36,6 +36,8 @@ struct Conv3Dev {
   int c_grp, flags;
   int hb_bytes;                      // one halo buffer
   int stage_ok;                      // the 256 x BN staging tile of the epilogue fits in the workgroup's LDS
+  const f32x2* in_coef;              // GroupNorm + SiLU of the INPUT applied while it is staged (ABL bit 16): (scale, shift) [img][Cin]
+  int coef_off;                      // byte offset of the two per-chunk coefficient rows in LDS
   double2* gn_part;                  // GroupNorm statistics of the output (null: off): [img][chunk = spatial tile x N tile][group]
   int gn_groups, gn_off;             // gn_off: byte offset of the per-channel partial sums in LDS (behind everything else)
   long long* dbg;                    // development: cycle stamps of workgroup 0 / wave 0 (null in production)
@@ -54,6 +56,9 @@ __device__ __forceinline__ int swz_key(int row) { return (row >> 1) & 3; }   // 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 64 + ((chunk ^ swz_key(row)) << 4); }
 
 // ABL (development ablations, 0 in production): 1 no MFMA, 2 no LDS reads + no MFMA, 4 no halo DMA, 8 no weight DMA
+// ABL bit 16 (production): GroupNorm(+SiLU) of the input fused into the staging -- the halo chunk is normalised IN PLACE in LDS
+// (y = silu(x * scale[c] + shift[c]), out-of-image padding stays zero) between its arrival and its first tap, piece by piece
+// under the taps of the previous chunk, so the normalised tensor never exists in HBM
 // NW = 8: 256-pixel tile, two workgroups per CU.  NW = 16: 512-pixel tile, one 1024-thread workgroup per CU whose 16 waves
 // share ONE weight ring -- half the weight bytes per pixel, for the short-K layers that re-stream the whole weight matrix
 // for every tile (launch_conv3x3 picks).
@@ -119,6 +124,51 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv3x3_kernel(const
     }
   };
 
+  constexpr bool GNA = (ABL & 16) != 0;
+  f32x2* s_coef = (f32x2*)(smem + p.coef_off);   // [2][CK] (scale, shift) of the channels of the chunk being staged
+  // the chunk's coefficient row (CK x 8 bytes) by one 4-byte-per-lane LDS-DMA of wave 0: no register-destination load may sit
+  // beside the DMA queue (the compiler would drain it with vmcnt(0)); returns the DMA instructions this wave issued
+  auto load_coef = [&](int chunk) -> int {
+    if constexpr (GNA) {
+      if (wave == 0) {
+        if (lane < 2 * CK)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const float*)(p.in_coef + (long)img * p.Cin + chunk * CK) + lane),
+                                           (__attribute__((address_space(3))) void*)(s_coef + (chunk & 1) * CK), 4, 0, 0);
+        return 1;
+      }
+    }
+    return 0;
+  };
+  // normalise one piece of a staged halo chunk in place (same lane -> (row, slot) map as issue_halo_piece)
+  auto transform_piece = [&](int chunk, int it, unsigned char* hb) {
+    if constexpr (GNA) {
+      const int q = it * NT + tid;
+      const int row = q >> 2, slot = q & 3;
+      const int c = slot ^ swz_key(row);
+      const int hy = row / p.HTW, hx = row - hy * p.HTW;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      const bool ok = (row < halo_rows) & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.Wd);
+      if (ok) {
+        Chunk16* ptr = (Chunk16*)(hb + (size_t)q * 16);
+        const f32x2* cf = s_coef + (chunk & 1) * CK + c * VEC;
+        const Chunk16 raw = *ptr;
+        if constexpr (sizeof(T) == 2) {
+          const bf16x8 x = __builtin_bit_cast(bf16x8, raw);
+          bf16x8 o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = (bf16_t)silu_f(fmaf((float)x[j], cf[j][0], cf[j][1]));
+          *ptr = __builtin_bit_cast(Chunk16, o);
+        } else {
+          const f32x4 x = __builtin_bit_cast(f32x4, raw);
+          f32x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = silu_f(fmaf(x[j], cf[j][0], cf[j][1]));
+          *ptr = __builtin_bit_cast(Chunk16, o);
+        }
+      }
+    }
+  };
+
   // ---- per-lane pixel bookkeeping: fragment fm covers pixels wm*64 + fm*16 + lr of the tile
   int py[FM], px[FM];
 #pragma unroll
@@ -147,8 +197,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv3x3_kernel(const
   for (int it = 0; it < halo_iters; ++it) issue_halo_piece(0, it, hbuf0);
   issue_w(0, wbuf0);
   if (steps > 1) issue_w(1, wbuf0 + W_BYTES);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  (void)load_coef(0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  if constexpr (GNA) {   // the first chunk is normalised before its first tap; later chunks under the taps of their predecessor
+    for (int it = 0; it < halo_iters; ++it) transform_piece(0, it, hbuf0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
   stamp();
   for (int s = 0; s < steps; ++s) {
     const int chunk = s / 9, tap = s - chunk * 9;
@@ -165,6 +221,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv3x3_kernel(const
     };
     const bool early = __builtin_amdgcn_readfirstlane(wave) < NW / 2;
     if (early) issue_dma();
+    if constexpr (GNA) {
+      if (chunk + 1 < nchunks) {
+        if (tap == 0) issued += load_coef(chunk + 1);
+        // piece `it` of the next chunk was requested at tap `it` and has landed by the end of tap `it + 1`: normalise it at
+        // tap 4 + it (visible to everyone after that step's barrier, long before the chunk's first tap)
+        if (tap >= 4 && tap - 4 < halo_iters) transform_piece(chunk + 1, tap - 4, hbuf0 + ((chunk + 1) & 1) * p.hb_bytes);
+      }
+    }
     const unsigned char* hb = hbuf0 + (chunk & 1) * p.hb_bytes;
     const unsigned char* wb = wbuf0 + (s % 3) * W_BYTES;
     const int kh = tap / 3, kw = tap - kh * 3;
@@ -343,6 +407,7 @@ static int launch_c3(const Conv3Dev& d, int nimg, hipStream_t stream) {
   dd.stage_ok = stage <= (NW == 8 ? 80 : 160) * 1024;        // NW = 8 keeps two workgroups per CU (fp32 x 128 channels stores directly)
   if (dd.stage_ok && smem < stage) smem = stage;
   if (d.gn_part) { dd.gn_off = (smem + 15) & ~15; smem = dd.gn_off + 2 * (NW / 2) * BN * 4; }
+  if constexpr ((ABL & 16) != 0) { dd.coef_off = (smem + 15) & ~15; smem = dd.coef_off + 2 * (4 * Traits<T>::VEC) * 8; }
   static unsigned long long attr_set = 0;
   auto kfn = conv3x3_kernel<T, BN, UPS, ABL, NW>;
   if (first_time_on_device(attr_set)) {
@@ -400,6 +465,10 @@ int launch_conv3x3(const IgemmArgs& a, DType dtype, hipStream_t stream) {
   if (a.c_grp <= 1 && a.c_grp_stride == 0) d.c_grp_stride = a.c_img;
   d.flags = a.flags;
   d.gn_part = nullptr; d.gn_groups = 0; d.gn_off = 0;
+  d.in_coef = nullptr; d.coef_off = 0;
+  const bool gna = a.gn_in_coef != nullptr;
+  if (gna && (a.ups || nw16)) return -1;   // (the upsampling convs take un-normalised inputs; the 16-wave variant is not instantiated)
+  d.in_coef = (const f32x2*)a.gn_in_coef;
   if (a.gn_part && a.gn_groups > 0 && a.gn_groups <= 64 && a.N % a.gn_groups == 0 && !nw16 && (a.c_grp <= 1)) {
     d.gn_part = (double2*)a.gn_part; d.gn_groups = a.gn_groups;
     a.gn_chunks = d.tiles_per_img * d.tiles_n;
@@ -441,6 +510,10 @@ int launch_conv3x3(const IgemmArgs& a, DType dtype, hipStream_t stream) {
     }
   }
   if (nw16) return a.ups ? launch_c3<bf16_t, 128, true, 0, 16>(d, a.Nimg, stream) : launch_c3<bf16_t, 128, false, 0, 16>(d, a.Nimg, stream);
+  if (gna) {
+    if (dtype == BF16) return bn == 128 ? launch_c3<bf16_t, 128, false, 16>(d, a.Nimg, stream) : launch_c3<bf16_t, 64, false, 16>(d, a.Nimg, stream);
+    return bn == 128 ? launch_c3<float, 128, false, 16>(d, a.Nimg, stream) : launch_c3<float, 64, false, 16>(d, a.Nimg, stream);
+  }
 #define IVG_C3(T, BNv) (a.ups ? launch_c3<T, BNv, true>(d, a.Nimg, stream) : launch_c3<T, BNv, false>(d, a.Nimg, stream))
   if (dtype == BF16) return bn == 128 ? IVG_C3(bf16_t, 128) : IVG_C3(bf16_t, 64);
   return bn == 128 ? IVG_C3(float, 128) : IVG_C3(float, 64);

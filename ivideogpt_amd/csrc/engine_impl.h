@@ -21,7 +21,12 @@ struct Run {
 
   // ---- primitives (tokenizer.cpp)
   int conv(DType dt, const void* X, int N, int H, int W, const ConvW& c, void* Y, int stride, int ups, const void* Rres, int flags,
-           int out_f32, GnStats* out_stats = nullptr /* in: .part = buffer; out: .chunks (0: the statistics were not produced) */);
+           int out_f32, GnStats* out_stats = nullptr /* in: .part = buffer; out: .chunks (0: the statistics were not produced) */,
+           const void* in_coef = nullptr /* GroupNorm + SiLU of X applied inside the conv3x3 staging; returns -100 when not covered */);
+  // conv(silu(GroupNorm(x))) with the normalisation fused into the convolution's input staging where the 3x3 kernel covers the
+  // shape (the normalised tensor never reaches HBM); otherwise GroupNorm into `scratch`, then the convolution
+  int norm_conv(DType dt, const void* x, int N, int H, int W, const NormW& n, float eps, const GnStats* x_stats, const ConvW& c, void* Y,
+                const void* Rres, void* scratch, GnStats* out_stats);
   int gemm(DType dt, const IgemmArgs& a, double flops, double bytes);
   int linear(DType dt, const void* X, long rows, const ConvW& c, void* Y, const void* Rres, int flags, int out_f32);
   int gnorm(DType dt, const void* X, void* Y, int N, int P, int C, const NormW& n, float eps, int silu, const float* pos,

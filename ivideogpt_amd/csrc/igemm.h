@@ -41,6 +41,9 @@ struct IgemmArgs {
   void* gn_part = nullptr;
   int gn_groups = 0;
   mutable int gn_chunks = 0;
+  // GroupNorm + SiLU of the INPUT fused into the conv3x3 staging (null = off): float2 (scale, shift) [Nimg][Cin] with
+  // x_normalised = silu(x * scale + shift)  (norm.hip: launch_gn_coef); the conv then reads the RAW tensor
+  const void* gn_in_coef = nullptr;
   // batch z = (z0 * nb1 + z1) * nb2 + z2 ; element strides per operand
   int nb0 = 1, nb1 = 1, nb2 = 1;
   long sa[3] = {0, 0, 0}, sw[3] = {0, 0, 0}, sy[3] = {0, 0, 0};

@@ -143,6 +143,46 @@ int launch_groupnorm(const void* X, void* Y, void* part_ws, const float* gamma, 
   return (int)hipGetLastError();
 }
 
+// (scale, shift) per (image, channel) from the reduced statistics: y = x * scale + shift is GroupNorm's affine output.  The
+// conv3x3 kernel applies it (+ SiLU) to its input while staging it (IgemmArgs::gn_in_coef).  Same arithmetic as gn_apply.
+__global__ __launch_bounds__(256) void gn_coef_kernel(const double2* __restrict__ part, int nchunks, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, int P, int C, int groups, float eps,
+                                                      f32x2* __restrict__ coef) {
+  const int n = blockIdx.x, cpg = C / groups;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int g = c / cpg;
+    double a = 0.0, b = 0.0;
+    for (int q = 0; q < nchunks; ++q) { const double2 t = part[((long)n * nchunks + q) * groups + g]; a += t.x; b += t.y; }
+    const double cnt = (double)P * cpg;
+    const double mean = a / cnt;
+    double var = b / cnt - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * rstd;
+    coef[(long)n * C + c] = f32x2{sc, beta[c] - (float)mean * sc};
+  }
+}
+
+int launch_gn_coef(const void* part, int nchunks, const float* gamma, const float* beta, int N, int P, int C, int groups, float eps, void* coef,
+                   hipStream_t st) {
+  if (N <= 0 || nchunks <= 0 || C % groups != 0) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(gn_coef_kernel, dim3((unsigned)N), dim3(256), 0, st, (const double2*)part, nchunks, gamma, beta, P, C, groups, eps, (f32x2*)coef);
+  return (int)hipGetLastError();
+}
+
+// statistics only (the first half of launch_groupnorm): double2 [N][gn_num_chunks(P)][groups]
+int launch_groupnorm_partial(const void* X, void* part_ws, int N, int P, int C, int groups, DType dt, hipStream_t st) {
+  const int vec = dt == BF16 ? 8 : 4;
+  if (C % vec != 0 || C % groups != 0 || C / vec > 256 || groups > 256) return (int)hipErrorInvalidValue;
+  const int chunk_px = gn_chunk_px(P), nchunks = cdiv(P, chunk_px);
+  const int pl_n = 256 / (C / vec);
+  const size_t smem1 = (size_t)2 * pl_n * C * sizeof(float);
+  dim3 g1(nchunks, N);
+  if (dt == BF16) hipLaunchKernelGGL(gn_partial_kernel<bf16_t>, g1, dim3(256), smem1, st, (const bf16_t*)X, (double2*)part_ws, P, C, groups, chunk_px);
+  else hipLaunchKernelGGL(gn_partial_kernel<float>, g1, dim3(256), smem1, st, (const float*)X, (double2*)part_ws, P, C, groups, chunk_px);
+  return (int)hipGetLastError();
+}
+
 // apply only: the statistics were produced elsewhere (conv3x3 epilogue) as double2 [N][nchunks][groups]
 int launch_groupnorm_apply(const void* X, void* Y, const void* part, int nchunks, const float* gamma, const float* beta, const float* pos,
                            int N, int P, int C, int groups, float eps, int silu, DType dt, hipStream_t st) {

@@ -11,6 +11,10 @@ int gn_num_chunks(int P);
 // pos[P][C] (fp32).  part_ws: N * gn_num_chunks(P) * groups double2 of scratch.
 int launch_groupnorm(const void* X, void* Y, void* part_ws, const float* gamma, const float* beta, const float* pos,
                      int N, int P, int C, int groups, float eps, int silu, DType dt, hipStream_t st);
+// the statistics half alone, and the (scale, shift) table [N][C] float2 the conv3x3 kernel applies to its input while staging it
+int launch_groupnorm_partial(const void* X, void* part_ws, int N, int P, int C, int groups, DType dt, hipStream_t st);
+int launch_gn_coef(const void* part, int nchunks, const float* gamma, const float* beta, int N, int P, int C, int groups, float eps, void* coef,
+                   hipStream_t st);
 // the apply half alone, with statistics produced by a conv3x3 epilogue (IgemmArgs::gn_part): double2 [N][nchunks][groups]
 int launch_groupnorm_apply(const void* X, void* Y, const void* part, int nchunks, const float* gamma, const float* beta, const float* pos,
                            int N, int P, int C, int groups, float eps, int silu, DType dt, hipStream_t st);

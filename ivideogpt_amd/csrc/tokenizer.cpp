@@ -34,7 +34,7 @@ size_t Run::gn_stats_bytes(int N, int H, int W, int C) const {
 }
 
 int Run::conv(DType dt, const void* X, int N, int H, int W, const ConvW& c, void* Y, int stride, int ups, const void* Rres, int flags,
-              int out_f32, GnStats* out_stats) {
+              int out_f32, GnStats* out_stats, const void* in_coef) {
   Run& R = *this;
   if (out_stats) out_stats->chunks = 0;
   const int k = c.k;
@@ -52,6 +52,7 @@ int Run::conv(DType dt, const void* X, int N, int H, int W, const ConvW& c, void
   a.flags = flags | (c.b ? IG_BIAS_N : 0) | (Rres ? IG_RESIDUAL : 0) | (out_f32 ? IG_OUT_F32 : 0);
   if (planning) return 0;
   if (out_stats && out_stats->part && gn_fuse_enabled()) { a.gn_part = out_stats->part; a.gn_groups = e->cfg.norm_num_groups; }
+  a.gn_in_coef = in_coef;
   const double flops = 2.0 * N * Ho * Wo * (double)c.cout * k * k * c.cin;
   const double bytes = (double)esz(dt) * ((double)N * H * W * c.cin + (double)c.cout * k * k * c.cin) + (double)(out_f32 ? 4 : esz(dt)) * N * Ho * Wo * c.cout;
   if (k == 3 && stride == 1) {  // FLOP majority: LDS-halo kernel; shapes it does not cover fall through to the implicit GEMM
@@ -61,6 +62,7 @@ int Run::conv(DType dt, const void* X, int N, int H, int W, const ConvW& c, void
     prof_cancel(dt, 2);
     if (rc > 0) CK(rc);
   }
+  if (in_coef) return -100;   // only the 3x3 kernel can normalise its input on the fly: the caller materialises the GroupNorm instead
   prof_begin(dt, flops, bytes);
   CK(launch_igemm(a, dt, st));
   prof_end(dt);
@@ -107,6 +109,48 @@ int Run::gnorm(DType dt, const void* X, void* Y, int N, int P, int C, const Norm
   return 0;
 }
 
+// IVG_GN_APPLY_FUSE=1: GroupNorm + SiLU applied inside the conv3x3 input staging instead of a separate apply pass.  Parity-tested
+// (tests/test_gpu_ops.py::test_conv3x3_with_fused_input_groupnorm) but OFF by default: measured on MI355X at config 2 the in-LDS
+// normalisation (exp + divide per element, 4 waves per SIMD competing with the MFMA stream) costs the 3x3 kernels ~9 ms per step
+// and removes ~7 ms of gn_apply (decode stage 65.5 vs 63.0 ms, profiles/r02_eager_vs_graph_and_gn_fusion.txt)
+static bool gn_apply_fuse_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* s = getenv("IVG_GN_APPLY_FUSE"); v = (s && s[0] == '1') ? 1 : 0; }
+  return v == 1;
+}
+
+int Run::norm_conv(DType dt, const void* x, int N, int H, int W, const NormW& n, float eps, const GnStats* x_stats, const ConvW& c, void* Y,
+                   const void* Rres, void* scratch, GnStats* out_stats) {
+  Run& R = *this;
+  const int groups = e->cfg.norm_num_groups, P = H * W, C = c.cin;
+  const size_t m = e->ws.mark();
+  void* part = e->ws.alloc((size_t)N * gn_num_chunks(P) * groups * sizeof(double) * 2);
+  void* coef = e->ws.alloc((size_t)N * C * sizeof(float) * 2);
+  int rc = 0;
+  if (!planning) {
+    const bool fuse = gn_apply_fuse_enabled() && c.k == 3;
+    const void* st_part = x_stats && x_stats->chunks > 0 ? x_stats->part : nullptr;
+    int chunks = st_part ? x_stats->chunks : 0;
+    if (!st_part) {   // x has no statistics from its producer: one pass over it
+      CK(launch_groupnorm_partial(x, part, N, P, C, groups, dt, st));
+      st_part = part; chunks = gn_num_chunks(P);
+    }
+    rc = -100;
+    if (fuse) {
+      CK(launch_gn_coef(st_part, chunks, n.g, n.b, N, P, C, groups, eps, coef, st));
+      rc = conv(dt, x, N, H, W, c, Y, 1, 0, Rres, 0, 0, out_stats, coef);
+    }
+    if (rc == -100) {   // not covered by the fused kernel: materialise silu(GroupNorm(x)), then convolve
+      CK(launch_groupnorm_apply(x, scratch, st_part, chunks, n.g, n.b, nullptr, N, P, C, groups, eps, 1, dt, st));
+      rc = conv(dt, scratch, N, H, W, c, Y, 1, 0, Rres, 0, 0, out_stats);
+    }
+  } else if (out_stats) {
+    out_stats->chunks = 0;
+  }
+  e->ws.reset(m);
+  return rc;
+}
+
 // x [N,H,W,cin] -> out [N,H,W,cout]
 int Run::resnet(DType dt, const void* x, int N, int H, int W, const ResnetW& r, void* out, const GnStats* x_stats, GnStats* out_stats) {
   Run& R = *this;
@@ -116,15 +160,15 @@ int Run::resnet(DType dt, const void* x, int N, int H, int W, const ResnetW& r, 
   void* h = e->ws.alloc(px * r.cout * esz(dt));
   GnStats hs;   // statistics of h for norm2, reduced by conv1's epilogue (h is read once less)
   hs.part = e->ws.alloc(gn_stats_bytes(N, H, W, r.cout));
-  IVG_TRY(gnorm(dt, x, t, N, H * W, r.cin, r.n1, 1e-6f, 1, nullptr, x_stats));
-  IVG_TRY(conv(dt, t, N, H, W, r.c1, h, 1, 0, nullptr, 0, 0, &hs));
-  IVG_TRY(gnorm(dt, h, t, N, H * W, r.cout, r.n2, 1e-6f, 1, nullptr, &hs));
+  // h = conv1(silu(norm1(x)));  out = conv2(silu(norm2(h))) + shortcut(x): both GroupNorms are applied inside the convolutions'
+  // input staging (t is only touched when a shape falls back to the implicit GEMM)
+  IVG_TRY(norm_conv(dt, x, N, H, W, r.n1, 1e-6f, x_stats, r.c1, h, nullptr, t, &hs));
   const void* res = x;
   if (r.has_sc) {
     IVG_TRY(conv(dt, x, N, H, W, r.sc, out, 1, 0, nullptr, 0, 0));
     res = out;  // in-place residual: every element is read then written by the same thread
   }
-  IVG_TRY(conv(dt, t, N, H, W, r.c2, out, 1, 0, res, 0, 0, out_stats));
+  IVG_TRY(norm_conv(dt, h, N, H, W, r.n2, 1e-6f, &hs, r.c2, out, res, t, out_stats));
   e->ws.reset(m);
   return 0;
 }

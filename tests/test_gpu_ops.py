@@ -590,3 +590,42 @@ def test_conv3x3_epilogue_groupnorm_statistics(dt, H, Cin, Cout, ups, res, silu)
     sv = stored.reshape(Nb, groups, cpg * Ho * Ho)
     assert ((st[..., 0] - sv.sum(-1)).abs() / (sv.abs().sum(-1) + 1e-9)).max().item() < 1e-5
     assert ((st[..., 1] - (sv * sv).sum(-1)).abs() / (sv * sv).sum(-1)).max().item() < 1e-5
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("H,Cin,Cout,res", [(64, 128, 128, 1), (32, 256, 512, 0), (16, 512, 512, 1), (32, 128, 64, 0), (16, 768, 768, 1),
+                                            (16, 64, 192, 0), (32, 32, 128, 1)])
+def test_conv3x3_with_fused_input_groupnorm(dt, H, Cin, Cout, res):
+    """conv3x3(silu(GroupNorm(x))) with the GroupNorm applied in place on the staged halo chunk (conv3x3.hip, ABL bit 16): against
+    torch conv2d(silu(group_norm(x))) in fp64 -- zero padding must stay zero AFTER the normalisation, single- and multi-chunk Cin,
+    several spatial tiles (halo rows outside the image on every side), residual."""
+    L, l = lib()
+    g = torch.Generator().manual_seed(H * 3 + Cin + Cout)
+    Nb, groups = 3, 32
+    x = q(torch.randn(Nb, Cin, H, H, generator=g) * 1.5 + 0.3, dt)
+    w = q(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5, dt)
+    b = torch.randn(Cout, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(Cin, generator=g), 0.2 * torch.randn(Cin, generator=g)
+    hn = F.silu(F.group_norm(x.double(), groups, gamma.double(), beta.double(), eps=1e-6))
+    hn = q(hn.float(), dt).double()                       # the engine rounds the normalised values to the storage type
+    ref = F.conv2d(hn, w.double(), b.double(), padding=1)
+    r = q(torch.randn(Nb, Cout, H, H, generator=g), dt) if res else None
+    if res:
+        ref = ref + r.double()
+    X = x.permute(0, 2, 3, 1).contiguous().to(DEV, tdt(dt))
+    Wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(DEV, tdt(dt))
+    Y = torch.full((Nb, H, H, Cout), float("nan"), device=DEV, dtype=tdt(dt))
+    if res:
+        Y.copy_(r.permute(0, 2, 3, 1))
+    bd, gd, btd = b.to(DEV), gamma.to(DEV), beta.to(DEV)
+    a = L.IvgIgemmArgs()
+    a.X, a.W, a.Y, a.R, a.bias = X.data_ptr(), Wp.data_ptr(), Y.data_ptr(), (Y.data_ptr() if res else None), bd.data_ptr()
+    for k, v in dict(Nimg=Nb, Hin=H, Win=H, Cin=Cin, ldx=Cin, Hout=H, Wout=H, KH=3, KW=3, stride=1, pad=1, ups=0, N=Cout, ldw=9 * Cin,
+                     c_img=H * H * Cout, c_pix=Cout, c_ch=1, c_grp=1, c_grp_stride=0, flags=1 | (4 if res else 0), alpha=1.0, nb0=1, nb1=1,
+                     nb2=1).items():
+        setattr(a, k, v)
+    ws = torch.empty(Nb * (((H * H + 1023) // 1024) * groups * 16 + Cin * 8) + 256, dtype=torch.uint8, device=DEV)
+    assert l.ivg_op_gn_conv(C.byref(a), code(dt), groups, P(gd), P(btd), 1e-6, P(ws), stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(Y.float()).all()
+    assert rel_err(Y.float().permute(0, 3, 1, 2), ref) < (5e-5 if dt == "fp32" else TOL[dt])
