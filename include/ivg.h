@@ -234,6 +234,10 @@ int ivg_op_conv_gn(const ivg_igemm_args* a, int dtype, void* gn_part, int groups
 /* y = conv3x3(silu(GroupNorm(x))) (+ bias, residual) with the GroupNorm applied inside the convolution's input staging: the
  * normalised tensor is never written.  ws: scratch of at least Nimg * (ceil(Hin*Win/1024) * groups * 16 + Cin * 8) bytes. */
 int ivg_op_gn_conv(const ivg_igemm_args* a, int dtype, int groups, const float* gamma, const float* beta, float eps, void* ws, ivg_stream stream);
+/* Tokenizer cross-attention in one pass (bf16 only; IVG_ERR_INVALID when the shape is not covered): q [M][P][C], Kp [M/F][kv][C],
+ * VpT [M/F][C][kv] -> out [M][P][C], heads of C / nh channels, softmax(q k^T / sqrt(C / nh)) v per head
+ * (ivideogpt/vq_model/conditional_vae.py:38-55). */
+int ivg_op_xattn(const void* q, const void* Kp, const void* VpT, void* out, int M, int F, int P, int kv, int C, int nh, int dtype, ivg_stream stream);
 int ivg_op_skinny(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy, int splits, int flags,
                   int dtype, ivg_stream stream);
 int ivg_op_groupnorm(const void* X, void* Y, void* ws /* >= N*chunks*groups*16 B */, const float* gamma, const float* beta,

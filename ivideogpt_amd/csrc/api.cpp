@@ -714,6 +714,11 @@ int ivg_op_conv_gn(const ivg_igemm_args* a, int dtype, void* gn_part, int groups
   return g.gn_chunks;
 }
 
+int ivg_op_xattn(const void* q, const void* Kp, const void* VpT, void* out, int M, int F, int P, int kv, int C, int nh, int dtype, ivg_stream stream) {
+  const int rc = launch_xattn(q, Kp, VpT, out, M, F, P, kv, C, nh, (DType)dtype, (hipStream_t)stream);
+  return rc == 0 ? IVG_OK : (rc > 0 ? IVG_ERR_HIP : IVG_ERR_INVALID);
+}
+
 int ivg_op_gn_conv(const ivg_igemm_args* a, int dtype, int groups, const float* gamma, const float* beta, float eps, void* ws, ivg_stream stream) {
   // unit-test hook: y = conv3x3(silu(GroupNorm(x))) with the normalisation applied inside the convolution's input staging.
   // ws: scratch of at least Nimg * (ceil(H*W/1024) * groups * 16 + Cin * 8) bytes.  Returns IVG_ERR_INVALID when the fused kernel

@@ -325,6 +325,135 @@ int launch_flash_prefill(const void* qkv, const void* kc, const void* vt, void* 
   return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ tokenizer cross-attention
+// CrossAttentionBlock's multi-head attention (ivideogpt/vq_model/conditional_vae.py:38-55) in one pass, bf16:
+// every future frame's P = side^2 query tokens attend to the kv = ctx * P projected context tokens of ITS trajectory.  Replaces the
+// batched score GEMM, the row softmax over an fp32 score matrix in HBM (1.9 GB at config 2) and the batched P.V GEMM.
+// Same dataflow as flash_prefill_kernel (S = K Q^T, online softmax in fp32, O += V^T P with the lane's own S registers as its P
+// fragment), without a mask, for head dims 128 / 192 (C = 512 / 768, four heads):
+//   q   [M][P][C]   frame m = b * F + f, head h reads channels [h * HD, (h + 1) * HD)
+//   Kp  [B][kv][C]  projected keys of trajectory b (shared by its F frames)
+//   VpT [B][C][kv]  projected values, transposed
+//   out [M][P][C]
+template <int HD>
+__global__ __launch_bounds__(256) void xattn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ Kp, const bf16_t* __restrict__ VpT,
+                                                    bf16_t* __restrict__ out, int P, int kv, int C, int F, int nh, float scale) {
+  constexpr int KQ = HD / 32;   // MFMA K-steps of the score product
+  constexpr int DO = HD / 16;   // 16-row tiles of V^T / output channels
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lg = lane >> 4;
+  const int qt = blockIdx.x;
+  const int mh = blockIdx.y, m = mh / nh, h = mh - m * nh, b = m / F;
+  const int qi = qt * 64 + wave * 16 + lr;               // P is a multiple of 64 (16 x 16 or 32 x 32 tokens)
+  const bf16_t* qrow = q + ((long)m * P + qi) * C + h * HD;
+  bf16x8 qf[KQ];
+#pragma unroll
+  for (int k = 0; k < KQ; ++k) qf[k] = *(const bf16x8*)(qrow + k * 32 + lg * 8);
+  const bf16_t* kb = Kp + (long)b * kv * C + h * HD;     // row stride C
+  const bf16_t* vb = VpT + ((long)b * C + h * HD) * kv;  // row stride kv
+  f32x4 o[DO];
+#pragma unroll
+  for (int d = 0; d < DO; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float mx = -INFINITY, lsum = 0.f;
+  constexpr int PK = HD + 8;    // staged K row (elements): 16 consecutive rows start in 16 distinct bank groups
+  constexpr int PV = 64 + 8;    // staged V^T row
+  __shared__ __attribute__((aligned(16))) bf16_t sK[64 * PK];
+  __shared__ __attribute__((aligned(16))) bf16_t sV[HD * PV];
+  constexpr int KC = 64 * HD / 8 / 256;   // 16-byte chunks of the K tile per thread
+  constexpr int VC = HD * 64 / 8 / 256;   // ... of the V^T tile
+  Chunk16 pk[KC], pvv[VC];
+  auto fetch = [&](int kt) {
+    const int k0 = kt * 64;
+#pragma unroll
+    for (int i = 0; i < KC; ++i) {
+      const int c = i * 256 + tid, row = c / (HD / 8), col = (c % (HD / 8)) * 8;
+      pk[i] = *(const Chunk16*)(kb + (long)(k0 + row) * C + col);
+    }
+#pragma unroll
+    for (int i = 0; i < VC; ++i) {
+      const int c = i * 256 + tid, row = c >> 3, col = (c & 7) * 8;
+      pvv[i] = *(const Chunk16*)(vb + (long)row * kv + k0 + col);
+    }
+  };
+  const int ntiles = kv >> 6;
+  fetch(0);
+  for (int kt = 0; kt < ntiles; ++kt) {
+    __syncthreads();   // every wave is done with the previous tile
+#pragma unroll
+    for (int i = 0; i < KC; ++i) { const int c = i * 256 + tid; *(Chunk16*)(sK + (c / (HD / 8)) * PK + (c % (HD / 8)) * 8) = pk[i]; }
+#pragma unroll
+    for (int i = 0; i < VC; ++i) { const int c = i * 256 + tid; *(Chunk16*)(sV + (c >> 3) * PV + (c & 7) * 8) = pvv[i]; }
+    __syncthreads();
+    if (kt + 1 < ntiles) fetch(kt + 1);
+    f32x4 sc[4];
+    float mt = -INFINITY;
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      sc[sub] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const bf16_t* krow = sK + (sub * 16 + lr) * PK + lg * 8;
+#pragma unroll
+      for (int k = 0; k < KQ; ++k) sc[sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)(krow + k * 32), qf[k], sc[sub], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { sc[sub][r] *= scale; mt = fmaxf(mt, sc[sub][r]); }
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float mn = fmaxf(mx, mt);
+    const float alpha = expf(mx - mn);        // first tile: exp(-inf) = 0
+    mx = mn;
+    float ps = 0.f;
+    bf16x8 pf[2];
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pe = expf(sc[sub][r] - mn);
+        ps += pe;
+        pf[sub >> 1][(sub & 1) * 4 + r] = (bf16_t)pe;
+      }
+    lsum = lsum * alpha + ps;
+#pragma unroll
+    for (int d = 0; d < DO; ++d) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[d][r] *= alpha;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const bf16_t* vrow = sV + (d * 16 + lr) * PV + pr * 32 + lg * 4;
+        const bf16x4 v0 = *(const bf16x4*)vrow, v1 = *(const bf16x4*)(vrow + 16);
+        const bf16x8 va = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+        o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pf[pr], o[d], 0, 0, 0);
+      }
+    }
+  }
+  lsum += __shfl_xor(lsum, 16, 64);
+  lsum += __shfl_xor(lsum, 32, 64);
+  const float inv = 1.0f / lsum;
+  bf16_t* orow = out + ((long)m * P + qi) * C + h * HD + lg * 4;
+#pragma unroll
+  for (int d = 0; d < DO; ++d)
+    *(bf16x4*)(orow + d * 16) = bf16x4{(bf16_t)(o[d][0] * inv), (bf16_t)(o[d][1] * inv), (bf16_t)(o[d][2] * inv), (bf16_t)(o[d][3] * inv)};
+}
+
+// -1: shape / dtype not covered (the caller keeps the score GEMM + softmax + P.V GEMM path)
+int launch_xattn(const void* q, const void* Kp, const void* VpT, void* out, int M, int F, int P, int kv, int C, int nh, DType dt, hipStream_t st) {
+  static const bool off = [] { const char* v = getenv("IVG_FLASH_XATT"); return v && v[0] == '0'; }();
+  if (off || dt != BF16 || C % nh != 0 || P % 64 != 0 || kv % 64 != 0 || M <= 0 || F <= 0 || M % F != 0) return -1;
+  if (((uintptr_t)q & 15) || ((uintptr_t)Kp & 15) || ((uintptr_t)VpT & 15) || ((uintptr_t)out & 7) || (C & 7)) return -1;
+  const int hd = C / nh;
+  dim3 grid((unsigned)(P / 64), (unsigned)(M * nh));
+  const float scale = 1.0f / sqrtf((float)hd);
+  if (hd == 128)
+    hipLaunchKernelGGL(xattn_kernel<128>, grid, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)Kp, (const bf16_t*)VpT, (bf16_t*)out, P, kv, C, F, nh, scale);
+  else if (hd == 192)
+    hipLaunchKernelGGL(xattn_kernel<192>, grid, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)Kp, (const bf16_t*)VpT, (bf16_t*)out, P, kv, C, F, nh, scale);
+  else if (hd == 64)
+    hipLaunchKernelGGL(xattn_kernel<64>, grid, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)Kp, (const bf16_t*)VpT, (bf16_t*)out, P, kv, C, F, nh, scale);
+  else if (hd == 32)
+    hipLaunchKernelGGL(xattn_kernel<32>, grid, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)Kp, (const bf16_t*)VpT, (bf16_t*)out, P, kv, C, F, nh, scale);
+  else
+    return -1;
+  return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ decode attention
 // One workgroup per (b, head): RoPE of the new q/k, KV-cache append and single-token attention in one launch.
 // HBM-bound stream of the K and V rows of the cache (coalesced: LPK lanes share one row, 16 bytes each, four

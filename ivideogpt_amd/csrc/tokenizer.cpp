@@ -252,6 +252,12 @@ int Run::cross_attention(DType dt, const void* z, int B, int F, const XAttW& x, 
   void* Pm = e->ws.alloc((size_t)M * nh * P * kv * esz(dt));
   IVG_TRY(gnorm(dt, z, qn, (int)M, P, C, x.qn, 1e-5f, 0, x.q_pos));
   IVG_TRY(linear(dt, qn, M * P, x.q, q, nullptr, 0, 0));
+  int fused = -1;   // one-pass attention kernel (bf16): no score matrix in HBM
+  if (!planning) {
+    fused = launch_xattn(q, Kp, VpT, o, (int)M, F, P, kv, C, nh, dt, st);
+    if (fused > 0) CK(fused);
+  }
+  if (fused != 0) {
   {  // S[b][f][h] = Q_h K_h^T / sqrt(hd)
     IgemmArgs g;
     g.X = q; g.W = Kp; g.Y = S;
@@ -274,6 +280,7 @@ int Run::cross_attention(DType dt, const void* z, int B, int F, const XAttW& x, 
     g.sw[0] = (long)C * kv; g.sw[1] = 0; g.sw[2] = (long)hd * kv;
     g.sy[0] = (long)F * P * C; g.sy[1] = (long)P * C; g.sy[2] = hd;
     IVG_TRY(gemm(dt, g, 2.0 * M * nh * (double)P * kv * hd, (double)esz(dt) * ((double)M * nh * P * kv + (double)B * kv * C + M * P * C)));
+  }
   }
   IVG_TRY(linear(dt, o, M * P, x.o, out, z, IG_SILU, 0));
   e->ws.reset(m);
