@@ -16,10 +16,19 @@
 //     spends 25 % of every step in the barrier and 22 % of its life in an un-overlapped prologue / epilogue; a second
 //     resident workgroup fills exactly those holes,
 //   * 8 waves (2 per SIMD), each a 64 x 64 (or 64 x 32) sub-tile of MFMA fragments, swapped operands so a lane owns
-//     4 consecutive output channels;  the XCD-aware block order keeps the N tiles of one spatial tile on one L2.
+//     4 consecutive output channels;  the XCD-aware block order keeps the N tiles of one spatial tile on one L2,
+//   * the step loop issues (almost) nothing but MFMAs, LDS reads and DMA: a wave64 VALU instruction occupies its SIMD for
+//     4 clocks and a bf16 step is only 16 MFMAs x 16 clocks per wave, so the ~110 address / predicate instructions per step
+//     of the first version of this loop (integer division by the halo width, swizzle keys, bounds tests, 64-bit pointer
+//     arithmetic, all per lane and per step) kept the vector pipe busier than the matrix pipe (the fp32 instances, 2048 MFMA
+//     clocks per step, hid the same overhead and ran at 70-80 % of their peak).  Now the tile geometry is a template
+//     parameter and the nine taps are unrolled: every LDS fragment address is one per-lane base register (per kw, set up
+//     once) plus an immediate offset, the DMA source pointers are per-lane registers advanced by a per-lane increment, and the
+//     halo fragments of step s + 1 are read under the MFMAs of step s.
 // Bytes per (tap, chunk) step: 8 KiB of weights + 1/9 of a ~24 KiB halo for 2.1 MFLOP -> ~195 FLOP/B (igemm: 64).
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "igemm.h"
 
@@ -28,56 +37,90 @@ namespace ivg {
 struct Conv3Dev {
   const void* X; const void* W; void* Y; const void* R; const float* bias;
   int H, Wd, Cin, Ho, Wo;            // input H x W (before upsampling), output Ho x Wo
-  int TH, TW, tw_shift;              // output tile, TW = 1 << tw_shift, TH * TW = 256
-  int HTH, HTW;                      // halo tile (input pixels)
-  int tiles_x, tiles_per_img, n_sp;  // spatial tiles
+  int tiles_x, tiles_per_img;        // spatial tiles (TH x TW output pixels each, TH * TW = 256)
   int N, ldw, tiles_n;
   long c_img, c_pix, c_ch, c_grp_stride;
   int c_grp, flags;
-  int hb_bytes;                      // one halo buffer
   int stage_ok;                      // the 256 x BN staging tile of the epilogue fits in the workgroup's LDS
-  const f32x2* in_coef;              // GroupNorm + SiLU of the INPUT applied while it is staged (ABL bit 16): (scale, shift) [img][Cin]
+  const f32x2* in_coef;              // GroupNorm + SiLU of the INPUT applied while it is staged (GNA): (scale, shift) [img][Cin]
   int coef_off;                      // byte offset of the two per-chunk coefficient rows in LDS
   double2* gn_part;                  // GroupNorm statistics of the output (null: off): [img][chunk = spatial tile x N tile][group]
   int gn_groups, gn_off;             // gn_off: byte offset of the per-channel partial sums in LDS (behind everything else)
-  long long* dbg;                    // development: cycle stamps of workgroup 0 / wave 0 (null in production)
 };
 
 // source of every out-of-image 16-byte chunk (zero-initialised device global; one per translation unit, no RDC needed)
 __device__ __attribute__((aligned(16))) unsigned char g_zero_chunk3[16];
 
-__device__ __forceinline__ void glds16b(const void* gsrc, unsigned char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+// LDS-DMA (global_load_lds, 16 B per lane, lane-linear in LDS) with the address split the way the hardware takes it: a
+// wave-uniform 64-bit base in scalar registers plus a 32-bit byte offset per lane.  __builtin_amdgcn_global_load_lds is always
+// selected with a 64-bit per-lane address, which costs a 64-bit vector add per transfer and two registers per source; written
+// out, the scalar unit advances the base (chunk / tap) and the per-lane offsets never change.  lds_wave_base: LDS byte address the wave's 64 x 16 B land at (M0).
+__device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsigned lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_wave_base), "v"(voff), "s"(sbase) : "memory");
 }
-// XOR key: ds_read_b128 of 16 CONSECUTIVE rows is bank-conflict free from ANY start row (the halo fragments of tap
-// (kh, kw) start at arbitrary rows)
-__device__ __forceinline__ int swz_key(int row) { return (row >> 1) & 3; }   // 64-byte rows, 4 chunks: found by exhaustive search
+// (M0 is a reserved register: the compiler sets it itself right before each of its own uses -- this file leaves it none, every
+// LDS-DMA goes through these two helpers)
+__device__ __forceinline__ void glds4s(const void* sbase, unsigned voff, unsigned lds_wave_base) {   // 4 bytes per lane
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(lds_wave_base), "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(unsigned long)(__attribute__((address_space(3))) const void*)p;
+}
+// 64-byte LDS rows, 4 chunks of 16 B; the chunk a lane wants sits in slot (chunk ^ key).  Weight rows (16 consecutive rows per
+// fragment) and the halo rows of the plain convolutions (16 consecutive pixels of one halo line) use key = (x >> 1) & 3:
+// ds_read_b128 of 16 CONSECUTIVE rows is then bank-conflict free from ANY start row (found by enumeration over the lane groups
+// of ds_read_b128, tools/lds_swizzle_check.py).  The halo key is a function of the pixel's COLUMN in the halo tile, so the
+// fragments of the three kh taps and of a wave's four pixel rows differ by a constant byte offset.
+__device__ __forceinline__ int swz_key(int row) { return (row >> 1) & 3; }
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 64 + ((chunk ^ swz_key(row)) << 4); }
+// Halo rows of the nearest-x2 upsampling convs are read in PAIRS (two output pixels share an input pixel): the 16 lanes of a
+// fragment touch 8 consecutive rows (tap kw = 1) or 9 (kw = 0, 2), and with the key above rows r and r + 8 of the 9-row case meet
+// on the same banks (2-way conflict on two taps of three: SQ_LDS_BANK_CONFLICT 26 % in round 1).  No single key serves both
+// access shapes, so the halo tiles of the upsampling instances use their own: the 2-bit reversal of (column >> 2),
+// conflict-free for both pair alignments.
+template <bool UPS>
+__device__ __forceinline__ int halo_key(int hx) {
+  if constexpr (UPS) { const int j = hx >> 2; return ((j & 1) << 1) | ((j >> 1) & 1); }
+  else return swz_key(hx);
+}
 
-// ABL (development ablations, 0 in production): 1 no MFMA, 2 no LDS reads + no MFMA, 4 no halo DMA, 8 no weight DMA
-// ABL bit 16 (production): GroupNorm(+SiLU) of the input fused into the staging -- the halo chunk is normalised IN PLACE in LDS
+template <int N> __device__ __forceinline__ void wait_dma_keep() {   // all DMA but the newest N transfers, and every LDS read
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+}
+
+// GNA: GroupNorm(+SiLU) of the input fused into the staging -- the halo chunk is normalised IN PLACE in LDS
 // (y = silu(x * scale[c] + shift[c]), out-of-image padding stays zero) between its arrival and its first tap, piece by piece
-// under the taps of the previous chunk, so the normalised tensor never exists in HBM
-// NW = 8: 256-pixel tile, two workgroups per CU.  NW = 16: 512-pixel tile, one 1024-thread workgroup per CU whose 16 waves
-// share ONE weight ring -- half the weight bytes per pixel, for the short-K layers that re-stream the whole weight matrix
-// for every tile (launch_conv3x3 picks).
-template <typename T, int BN, bool UPS, int ABL = 0, int NW = 8>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv3x3_kernel(const Conv3Dev p) {
+// under the taps of the previous chunk, so the normalised tensor never exists in HBM (measured slower than
+// the separate apply pass, off by default).
+// PRE: the halo fragments of step s + 1 are read under the MFMAs of step s.
+template <typename T, int BN, bool UPS, int TW, bool GNA, bool PRE>
+__global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
   constexpr int VEC = Traits<T>::VEC;
-  constexpr int NT = NW * 64;              // threads
-  constexpr int PT = NW * 32;              // output pixels per tile
   constexpr int CK = 4 * VEC;              // channels per chunk: one 64-byte LDS row per halo pixel (one MFMA K-step)
-  constexpr int WN = BN / 2;               // NW waves = NW/2 (M) x 2 (N)
+  constexpr int WN = BN / 2;               // 8 waves = 4 (pixels) x 2 (channels)
   constexpr int FM = 4, FN = WN / 16;
   constexpr int W_BYTES = BN * 64;
+  // ---- tile geometry
+  constexpr int TH = 256 / TW, TWS = TW == 32 ? 5 : 4;
+  constexpr int HTW = UPS ? TW / 2 + 2 : TW + 2, HTH = UPS ? TH / 2 + 2 : TH + 2;   // halo tile (input pixels)
+  constexpr int HROWS = HTH * HTW;
+  constexpr int HI = (HROWS * 4 + 511) / 512;      // DMA pieces (512 lanes x 16 B) per halo chunk
+  constexpr int HB = HI * 8192;                    // one halo buffer
+  // fragment b of a wave covers tile row pyw + BR(b), columns PXO(b) + lr
+  auto BR = [](int b) constexpr { return TW == 16 ? b : (b >> 1); };
+  auto PXO = [](int b) constexpr { return TW == 16 ? 0 : (b & 1) * 16; };
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* hbuf0 = smem;
-  unsigned char* wbuf0 = smem + 2 * p.hb_bytes;   // three weight buffers
+  unsigned char* wbuf0 = smem + 2 * HB;   // three weight buffers
 
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform values stay in scalar registers
   const int lr = lane & 15, lg = lane >> 4;
-  const int wm = wave % (NW / 2), wn = wave / (NW / 2);
+  const int wm = wave & 3, wn = wave >> 2;
+  const int pyw = TW == 16 ? wm * 4 : wm * 2;
 
   // ---- XCD-aware block order (blocks b, b+8, ... share an XCD/L2): give each XCD a contiguous run of work items
   // with the N tile fastest, so the N tiles of one spatial tile hit the same L2 (bijective for any grid size)
@@ -92,62 +135,74 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv3x3_kernel(const
   const int img = sp / p.tiles_per_img;
   const int t_in = sp - img * p.tiles_per_img;
   const int ty = t_in / p.tiles_x, tx = t_in - ty * p.tiles_x;
-  const int y0 = ty * p.TH, x0 = tx * p.TW;            // output tile origin
+  const int y0 = ty * TH, x0 = tx * TW;                // output tile origin
   const int iy0 = UPS ? ((y0 - 1) >> 1) : (y0 - 1);    // halo origin in input pixels
   const int ix0 = UPS ? ((x0 - 1) >> 1) : (x0 - 1);
-  const T* X = (const T*)p.X + (long)img * p.H * p.Wd * p.Cin;
-  const T* Wt = (const T*)p.W;
+  const unsigned char* Xb = (const unsigned char*)((const T*)p.X + (long)img * p.H * p.Wd * p.Cin);   // this image, chunk 0
   const int n_base = tile_n * BN;
-  const int halo_rows = p.HTH * p.HTW;
-  const int halo_iters = (halo_rows * 4 + NT - 1) / NT;
 
-  // one piece of a halo tile: NT lanes x 16 B, lane-linear in LDS
-  auto issue_halo_piece = [&](int chunk, int it, unsigned char* hb) {
-    const int q = it * NT + tid;
+  // ---- per-lane DMA sources, set up once: a 32-bit byte offset per lane from a wave-uniform base that the scalar unit
+  // advances (chunk / tap), so a transfer costs no vector instruction beyond the load itself.
+  // Halo piece `it`: lane -> (halo pixel, 16-byte slot).  Out-of-image pixels (and the tail of the last piece) are never
+  // requested: their LDS slots -- the same in every chunk -- are zeroed once here, in both buffers.
+  unsigned hoff[HI];
+  bool hok[HI];
+  int h_any[HI];     // this wave requests anything in piece `it` (wave-uniform; the counted waits need the exact number)
+#pragma unroll
+  for (int it = 0; it < HI; ++it) {
+    const int q = it * 512 + tid;
     const int row = q >> 2, slot = q & 3;
-    const int c = slot ^ swz_key(row);
-    const int hy = row / p.HTW, hx = row - hy * p.HTW;
+    const int hy = row / HTW, hx = row - hy * HTW;
+    const int c = slot ^ halo_key<UPS>(hx);
     const int iy = iy0 + hy, ix = ix0 + hx;
-    const bool ok = (row < halo_rows) & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.Wd);
-    const void* src = ok ? (const void*)(X + ((long)(iy * p.Wd + ix) * p.Cin + chunk * CK + c * VEC)) : (const void*)g_zero_chunk3;
-    glds16b(src, hb + (it * NT + wave * 64) * 16);
-  };
-  auto issue_w = [&](int step, unsigned char* wb) {
-    const int chunk = step / 9, tap = step - chunk * 9;
-    if (wave * 64 < BN * 4) {   // BN rows x 4 chunks: all 8 waves for BN = 128, the first 4 for BN = 64 (wave-uniform)
-      const int q = tid;
-      const int n = q >> 2, slot = q & 3;
-      const int c = slot ^ swz_key(n);
-      const bool ok = (n_base + n) < p.N;
-      const void* src = ok ? (const void*)(Wt + ((long)(n_base + n) * p.ldw + tap * p.Cin + chunk * CK + c * VEC)) : (const void*)g_zero_chunk3;
-      glds16b(src, wb + (wave * 64) * 16);
+    hok[it] = (row < HROWS) & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.Wd);
+    hoff[it] = hok[it] ? (unsigned)(((iy * p.Wd + ix) * p.Cin + c * VEC) * (int)sizeof(T)) : 0u;
+    h_any[it] = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(hok[it]) != 0 ? 1 : 0);
+    if (!hok[it]) {
+      *(Chunk16*)(hbuf0 + (size_t)q * 16) = Chunk16{0, 0, 0, 0};
+      *(Chunk16*)(hbuf0 + HB + (size_t)q * 16) = Chunk16{0, 0, 0, 0};
     }
+  }
+  auto issue_halo_piece = [&](int it, int chunk, unsigned char* hb) {
+    if (hok[it]) glds16s(Xb + (size_t)chunk * (CK * sizeof(T)), hoff[it], lds_addr(hb) + (it * 512 + wave * 64) * 16);
+  };
+  // weight tile of one (tap, chunk): BN rows x 4 slots; rows beyond N re-read row N - 1 (their outputs are never stored).
+  // BN = 64 is 256 lanes: waves 4..7 repeat the transfers of waves 0..3 (same bytes to the same place) so that every wave
+  // counts the same number of outstanding transfers.
+  unsigned woff;
+  {
+    const int q = BN == 128 ? tid : (tid & 255);
+    const int n = q >> 2, slot = q & 3;
+    const int c = slot ^ swz_key(n);
+    const int nrow = min(n_base + n, p.N - 1);
+    woff = (unsigned)((nrow * p.ldw + c * VEC) * (int)sizeof(T));
+  }
+  const int w_dst = (BN == 128 ? wave : (wave & 3)) * 1024;
+  auto issue_w = [&](int tap, int chunk, int ring) {
+    glds16s((const unsigned char*)p.W + (size_t)(tap * p.Cin + chunk * CK) * sizeof(T), woff, lds_addr(wbuf0) + ring * W_BYTES + w_dst);
   };
 
-  constexpr bool GNA = (ABL & 16) != 0;
   f32x2* s_coef = (f32x2*)(smem + p.coef_off);   // [2][CK] (scale, shift) of the channels of the chunk being staged
   // the chunk's coefficient row (CK x 8 bytes) by one 4-byte-per-lane LDS-DMA of wave 0: no register-destination load may sit
   // beside the DMA queue (the compiler would drain it with vmcnt(0)); returns the DMA instructions this wave issued
   auto load_coef = [&](int chunk) -> int {
     if constexpr (GNA) {
       if (wave == 0) {
-        if (lane < 2 * CK)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const float*)(p.in_coef + (long)img * p.Cin + chunk * CK) + lane),
-                                           (__attribute__((address_space(3))) void*)(s_coef + (chunk & 1) * CK), 4, 0, 0);
+        if (lane < 2 * CK) glds4s(p.in_coef + ((long)img * p.Cin + chunk * CK), (unsigned)lane * 4u, lds_addr(s_coef + (chunk & 1) * CK));
         return 1;
       }
     }
     return 0;
   };
-  // normalise one piece of a staged halo chunk in place (same lane -> (row, slot) map as issue_halo_piece)
+  // normalise one piece of a staged halo chunk in place (same lane -> (pixel, slot) map as the DMA)
   auto transform_piece = [&](int chunk, int it, unsigned char* hb) {
     if constexpr (GNA) {
-      const int q = it * NT + tid;
+      const int q = it * 512 + tid;
       const int row = q >> 2, slot = q & 3;
-      const int c = slot ^ swz_key(row);
-      const int hy = row / p.HTW, hx = row - hy * p.HTW;
+      const int hy = row / HTW, hx = row - hy * HTW;
+      const int c = slot ^ halo_key<UPS>(hx);
       const int iy = iy0 + hy, ix = ix0 + hx;
-      const bool ok = (row < halo_rows) & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.Wd);
+      const bool ok = (row < HROWS) & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.Wd);
       if (ok) {
         Chunk16* ptr = (Chunk16*)(hb + (size_t)q * 16);
         const f32x2* cf = s_coef + (chunk & 1) * CK + c * VEC;
@@ -169,14 +224,29 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv3x3_kernel(const
     }
   };
 
-  // ---- per-lane pixel bookkeeping: fragment fm covers pixels wm*64 + fm*16 + lr of the tile
-  int py[FM], px[FM];
+  // ---- per-lane LDS fragment addresses, set up once.  Halo: one base per kw (and per column half where the key differs);
+  // the pixel row of fragment b and the kh tap are constant byte offsets.  Weights: one base; ring slot and the FN
+  // 16-row groups are constant offsets.
+  constexpr int NPX = (UPS && TW == 32) ? 2 : 1;
+  int a_base[3][NPX];   // byte offsets into halo buffer 0 (buffer 1: + HB, an immediate -- the chunk loop is unrolled by two)
 #pragma unroll
-  for (int b = 0; b < FM; ++b) {
-    const int pl = wm * 64 + b * 16 + lr;
-    py[b] = pl >> p.tw_shift;
-    px[b] = pl & (p.TW - 1);
-  }
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int pi = 0; pi < NPX; ++pi) {
+      int hx, rowbase;
+      if constexpr (UPS) { hx = ((lr + pi * 16 + kw - 1) >> 1) + 1; rowbase = (pyw >> 1) * HTW; }
+      else { hx = lr + kw; rowbase = pyw * HTW; }
+      a_base[kw][pi] = (rowbase + hx) * 64 + ((lg ^ halo_key<UPS>(hx)) << 4);
+    }
+  auto a_imm = [&](int b, int kh) constexpr -> int {   // folds to an immediate after unrolling
+    if constexpr (UPS) return ((((BR(b) + kh - 1) >> 1) + 1) * HTW) * 64;
+    else return ((BR(b) + kh) * HTW + PXO(b)) * 64;
+  };
+  auto read_a = [&](int buf, int tap, int b) -> Chunk16 {
+    const int kh = tap / 3, kw = tap - kh * 3;
+    return *(const Chunk16*)(hbuf0 + a_base[kw][NPX == 2 ? (b & 1) : 0] + (buf * HB + a_imm(b, kh)));
+  };
+  const int w_base = swz(wn * WN + lr, lg);
 
   f32x4 acc[FN][FM];
 #pragma unroll
@@ -185,78 +255,67 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv3x3_kernel(const
     for (int b = 0; b < FM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nchunks = p.Cin / CK;
-  const int steps = nchunks * 9;
-  const bool dbg = p.dbg && blockIdx.x == 8 && tid == 0;
-  int dbg_n = 0;
-  auto stamp = [&]() { if (dbg) p.dbg[dbg_n++] = (long long)__builtin_readcyclecounter(); };
-  stamp();
   // Pipeline: the weight tile of step s+2 and one piece of the next chunk's halo are issued at the top of step s;
   // the end-of-step wait is COUNTED (all DMA except what this step just issued), so a transfer has two full steps
   // to land and the barrier never drains the queue (cdna_hip_programming.md 5, "Pipelining across barriers").
-  const int W_IT = (wave * 64 < BN * 4) ? 1 : 0;   // DMA instructions this wave issues per weight tile
-  for (int it = 0; it < halo_iters; ++it) issue_halo_piece(0, it, hbuf0);
-  issue_w(0, wbuf0);
-  if (steps > 1) issue_w(1, wbuf0 + W_BYTES);
+#pragma unroll
+  for (int it = 0; it < HI; ++it) issue_halo_piece(it, 0, hbuf0);
+  issue_w(0, 0, 0);
+  issue_w(1, 0, 1);
   (void)load_coef(0);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if constexpr (GNA) {   // the first chunk is normalised before its first tap; later chunks under the taps of their predecessor
-    for (int it = 0; it < halo_iters; ++it) transform_piece(0, it, hbuf0);
+    for (int it = 0; it < HI; ++it) transform_piece(0, it, hbuf0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
-  stamp();
-  for (int s = 0; s < steps; ++s) {
-    const int chunk = s / 9, tap = s - chunk * 9;
-    int issued = 0;
-    // the two waves of a SIMD (w, w + 4) issue their DMA at different points of the step, so one of them is always
-    // feeding the matrix pipe (an in-order wave cannot issue MFMAs while it is issuing LDS-DMA)
-    auto issue_dma = [&]() {
-      if constexpr (!(ABL & 8)) {
-        if (s + 2 < steps) { issue_w(s + 2, wbuf0 + ((s + 2) % 3) * W_BYTES); issued += W_IT; }
-      }
-      if constexpr (!(ABL & 4)) {
-        if (chunk + 1 < nchunks && tap < halo_iters) { issue_halo_piece(chunk + 1, tap, hbuf0 + ((chunk + 1) & 1) * p.hb_bytes); issued += 1; }
-      }
-    };
-    const bool early = __builtin_amdgcn_readfirstlane(wave) < NW / 2;
-    if (early) issue_dma();
-    if constexpr (GNA) {
-      if (chunk + 1 < nchunks) {
-        if (tap == 0) issued += load_coef(chunk + 1);
-        // piece `it` of the next chunk was requested at tap `it` and has landed by the end of tap `it + 1`: normalise it at
-        // tap 4 + it (visible to everyone after that step's barrier, long before the chunk's first tap)
-        if (tap >= 4 && tap - 4 < halo_iters) transform_piece(chunk + 1, tap - 4, hbuf0 + ((chunk + 1) & 1) * p.hb_bytes);
-      }
-    }
-    const unsigned char* hb = hbuf0 + (chunk & 1) * p.hb_bytes;
-    const unsigned char* wb = wbuf0 + (s % 3) * W_BYTES;
-    const int kh = tap / 3, kw = tap - kh * 3;
-    int hr[FM];
+  Chunk16 xa[FM];
+  if constexpr (PRE) {
 #pragma unroll
-    for (int b = 0; b < FM; ++b) {
-      if constexpr (UPS) hr[b] = (((y0 + py[b] + kh - 1) >> 1) - iy0) * p.HTW + (((x0 + px[b] + kw - 1) >> 1) - ix0);
-      else hr[b] = (py[b] + kh) * p.HTW + (px[b] + kw);
-    }
-    {
+    for (int b = 0; b < FM; ++b) xa[b] = read_a(0, 0, b);
+  }
+  // the two waves of a SIMD (w, w + 4) issue their DMA at different points of the step, so one of them is always
+  // feeding the matrix pipe (an in-order wave cannot issue MFMAs while it is issuing LDS-DMA)
+  const bool early = __builtin_amdgcn_readfirstlane(wave) < 4;
+  // one 32-channel chunk = nine steps; PAR (the halo buffer it is consumed from) is a compile-time value, so that buffer
+  // addresses are immediates: the chunk loop below alternates the two instances
+  auto run_chunk = [&](int chunk, auto par) {
+    constexpr int PAR = decltype(par)::value;
+    const bool more = chunk + 1 < nchunks;                       // another chunk follows: its halo is staged under this one
+    unsigned char* hb_next = hbuf0 + (1 - PAR) * HB;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int tap2 = (tap + 2) % 9, chunk2 = chunk + (tap + 2) / 9;   // the step whose weights are requested now
+      const bool w_more = tap < 7 || more;
+      const bool h_more = tap < HI && more;
+      int issued = 0;
+      auto issue_dma = [&]() {
+        if (w_more) { issue_w(tap2, chunk2, (tap + 2) % 3); issued += 1; }
+        if (tap < HI) { if (more) { issue_halo_piece(tap, chunk + 1, hb_next); issued += h_any[tap < HI ? tap : 0]; } }
+      };
+      (void)h_more;
+      if (early) issue_dma();
+      if constexpr (GNA) {
+        if (more) {
+          if (tap == 0) issued += load_coef(chunk + 1);
+          // piece `it` of the next chunk was requested at tap `it` and has landed by the end of tap `it + 1`: normalise it at
+          // tap 4 + it (visible to everyone after that step's barrier, long before the chunk's first tap)
+          if (tap >= 4 && tap - 4 < HI) transform_piece(chunk + 1, tap - 4, hb_next);
+        }
+      }
       if (!early) issue_dma();
-      const int c = lg;
-      Chunk16 xa[FM], wv[FN];
+      Chunk16 wv[FN];
+      if constexpr (!PRE) {
 #pragma unroll
-      for (int b = 0; b < FM; ++b) xa[b] = *(const Chunk16*)(hb + swz(hr[b], c));
-#pragma unroll
-      for (int a = 0; a < FN; ++a) wv[a] = *(const Chunk16*)(wb + swz(wn * WN + a * 16 + lr, c));
-      if constexpr (ABL & 1) {
-#pragma unroll
-        for (int b = 0; b < FM; ++b) asm volatile("" :: "v"(xa[b]));
-#pragma unroll
-        for (int a = 0; a < FN; ++a) asm volatile("" :: "v"(wv[a]));
+        for (int b = 0; b < FM; ++b) xa[b] = read_a(PAR, tap, b);
       }
-      if constexpr (!(ABL & 1))
 #pragma unroll
-      for (int a = 0; a < FN; ++a)
+      for (int a = 0; a < FN; ++a) wv[a] = *(const Chunk16*)(wbuf0 + w_base + ((tap % 3) * W_BYTES + a * 1024));
 #pragma unroll
-        for (int b = 0; b < FM; ++b) {
+      for (int b = 0; b < FM; ++b) {
+#pragma unroll
+        for (int a = 0; a < FN; ++a) {
           if constexpr (sizeof(T) == 2) {
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[a]), __builtin_bit_cast(bf16x8, xa[b]),
                                                                 acc[a][b], 0, 0, 0);
@@ -266,27 +325,39 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv3x3_kernel(const
             for (int u = 0; u < 4; ++u) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u], xf[u], acc[a][b], 0, 0, 0);
           }
         }
+        // the halo tile of the next step is already resident (same chunk, or the next chunk whose pieces landed by tap 4):
+        // its fragment b replaces the one whose last MFMA was just issued and travels under the remaining MFMAs of this step
+        if constexpr (PRE) { if (tap < 8 || more) xa[b] = read_a(tap < 8 ? PAR : 1 - PAR, (tap + 1) % 9, b); }
+      }
+      if constexpr (PRE) {   // keep the order written above: FN (x 4 for fp32) MFMAs, then the read that follows them
+#pragma unroll
+        for (int b = 0; b < FM; ++b) {
+          __builtin_amdgcn_sched_group_barrier(0x008, sizeof(T) == 2 ? FN : 4 * FN, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      }
+      // everything issued BEFORE this step has landed once at most `issued` transfers are still in flight
+      if (issued == 0) wait_dma_keep<0>();
+      else if (issued == 1) wait_dma_keep<1>();
+      else if (issued == 2) wait_dma_keep<2>();
+      else wait_dma_keep<3>();
+      __builtin_amdgcn_s_barrier();
     }
-    if (s < 16) stamp();
-    // everything issued BEFORE this step has landed once at most `issued` transfers are still in flight
-    if (issued == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    else if (issued == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
-    else if (issued == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (s < 16) stamp();
+  };
+  for (int chunk = 0; chunk < nchunks; chunk += 2) {
+    run_chunk(chunk, std::integral_constant<int, 0>{});
+    if (chunk + 1 < nchunks) run_chunk(chunk + 1, std::integral_constant<int, 1>{});
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  stamp();
 
   // ---- epilogue (same contract as igemm.hip): lane holds 4 consecutive n of pixel (py, px)
   const int flags = p.flags;
-  // dense NHWC output of element type T: stage the PT x BN tile through LDS (the halo buffers are free now) and store
+  // dense NHWC output of element type T: stage the 256 x BN tile through LDS (the halo buffers are free now) and store
   // whole pixel rows, 16 B per lane, instead of 8-byte pieces at a 256-byte stride (store-issue bound otherwise)
   const bool staged = !(flags & IG_OUT_F32) && p.c_ch == 1 && p.c_pix == p.N && (p.N % BN) == 0 && p.stage_ok;
   constexpr int PITCH = BN * (int)sizeof(T) + 16;   // bytes per staged pixel row (+16: spreads the 16 pixel rows of a fragment over banks)
   // GroupNorm statistics of what this workgroup stores (the consumer's GroupNorm then needs no pass of its own over the tensor):
-  // per lane the sums over its FM pixels of every channel it owns, reduced over the 16 pixel lanes, the NW / 2 pixel waves and
+  // per lane the sums over its FM pixels of every channel it owns, reduced over the 16 pixel lanes, the 4 pixel waves and
   // finally the channels of a group -- all in a fixed order
   const bool gn = p.gn_part != nullptr;
   float gs[FN][4], gq[FN][4];
@@ -296,7 +367,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv3x3_kernel(const
     for (int r = 0; r < 4; ++r) { gs[a][r] = 0.f; gq[a][r] = 0.f; }
 #pragma unroll
   for (int b = 0; b < FM; ++b) {
-    const int pix = (y0 + py[b]) * p.Wo + (x0 + px[b]);
+    const int pix = (y0 + pyw + BR(b)) * p.Wo + (x0 + PXO(b) + lr);
     const long obase = (long)(img / p.c_grp) * p.c_grp_stride + (long)(img % p.c_grp) * p.c_img + (long)pix * p.c_pix;
 #pragma unroll
     for (int a = 0; a < FN; ++a) {
@@ -363,8 +434,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv3x3_kernel(const
     }
   }
   if (gn) {
-    float* ch_s = (float*)(smem + p.gn_off);          // [NW / 2 pixel waves][BN channels]
-    float* ch_q = ch_s + (NW / 2) * BN;
+    float* ch_s = (float*)(smem + p.gn_off);          // [4 pixel waves][BN channels]
+    float* ch_q = ch_s + (4) * BN;
 #pragma unroll
     for (int a = 0; a < FN; ++a)
 #pragma unroll
@@ -376,12 +447,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv3x3_kernel(const
   if (staged || gn) __syncthreads();
   if (gn && tid < p.gn_groups) {
     const float* ch_s = (const float*)(smem + p.gn_off);
-    const float* ch_q = ch_s + (NW / 2) * BN;
+    const float* ch_q = ch_s + (4) * BN;
     const int cpg = p.N / p.gn_groups;
     const int c0 = max(tid * cpg, n_base), c1 = min(min((tid + 1) * cpg, n_base + BN), p.N);
     double a1 = 0.0, a2 = 0.0;
     for (int c = c0; c < c1; ++c)
-      for (int w = 0; w < NW / 2; ++w) { a1 += (double)ch_s[w * BN + c - n_base]; a2 += (double)ch_q[w * BN + c - n_base]; }
+      for (int w = 0; w < 4; ++w) { a1 += (double)ch_s[w * BN + c - n_base]; a2 += (double)ch_q[w * BN + c - n_base]; }
     const long chunk = (long)t_in * p.tiles_n + tile_n;
     p.gn_part[((long)img * p.tiles_per_img * p.tiles_n + chunk) * p.gn_groups + tid] = double2{a1, a2};
   }
@@ -389,33 +460,36 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void conv3x3_kernel(const
     constexpr int CPR = BN * (int)sizeof(T) / 16;   // 16-byte chunks per staged pixel row
     T* Y = (T*)p.Y;
     const long ibase = (long)(img / p.c_grp) * p.c_grp_stride + (long)(img % p.c_grp) * p.c_img;
-    for (int q = tid; q < PT * CPR; q += NT) {
+    for (int q = tid; q < 256 * CPR; q += 512) {
       const int pl = q / CPR, ch = q - pl * CPR;
-      const int oy = y0 + (pl >> p.tw_shift), ox = x0 + (pl & (p.TW - 1));
+      const int oy = y0 + (pl >> TWS), ox = x0 + (pl & (TW - 1));
       const Chunk16 val = *(const Chunk16*)(smem + pl * PITCH + ch * 16);
       *(Chunk16*)(Y + ibase + (long)(oy * p.Wo + ox) * p.c_pix + n_base + ch * (16 / (int)sizeof(T))) = val;
     }
   }
-  if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(); p.dbg[63] = dbg_n; }
 }
 
-template <typename T, int BN, bool UPS, int ABL = 0, int NW = 8>
+template <typename T, int BN, bool UPS, int TW, bool GNA, bool PRE>
 static int launch_c3(const Conv3Dev& d, int nimg, hipStream_t stream) {
-  int smem = 2 * d.hb_bytes + 3 * BN * 64;
-  const int stage = NW * 32 * (BN * (int)sizeof(T) + 16);   // LDS-staged epilogue tile
+  constexpr int TH = 256 / TW;
+  constexpr int HROWS = (UPS ? TH / 2 + 2 : TH + 2) * (UPS ? TW / 2 + 2 : TW + 2);
+  constexpr int HB = (HROWS * 4 + 511) / 512 * 8192;
+  int smem = 2 * HB + 3 * BN * 64;
+  static_assert(2 * HB + 3 * BN * 64 <= 80 * 1024, "two workgroups per CU");
+  const int stage = 256 * (BN * (int)sizeof(T) + 16);   // LDS-staged epilogue tile
   Conv3Dev dd = d;
-  dd.stage_ok = stage <= (NW == 8 ? 80 : 160) * 1024;        // NW = 8 keeps two workgroups per CU (fp32 x 128 channels stores directly)
+  dd.stage_ok = stage <= 80 * 1024;                      // keeps two workgroups per CU (fp32 x 128 channels stores directly)
   if (dd.stage_ok && smem < stage) smem = stage;
-  if (d.gn_part) { dd.gn_off = (smem + 15) & ~15; smem = dd.gn_off + 2 * (NW / 2) * BN * 4; }
-  if constexpr ((ABL & 16) != 0) { dd.coef_off = (smem + 15) & ~15; smem = dd.coef_off + 2 * (4 * Traits<T>::VEC) * 8; }
+  if (d.gn_part) { dd.gn_off = (smem + 15) & ~15; smem = dd.gn_off + 2 * 4 * BN * 4; }
+  if constexpr (GNA) { dd.coef_off = (smem + 15) & ~15; smem = dd.coef_off + 2 * (4 * Traits<T>::VEC) * 8; }
   static unsigned long long attr_set = 0;
-  auto kfn = conv3x3_kernel<T, BN, UPS, ABL, NW>;
+  auto kfn = conv3x3_kernel<T, BN, UPS, TW, GNA, PRE>;
   if (first_time_on_device(attr_set)) {
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
   }
   const long blocks = (long)nimg * d.tiles_per_img * d.tiles_n;
-  hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(NW * 64), smem, stream, dd);
+  hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(512), smem, stream, dd);
   return (int)hipGetLastError();
 }
 
@@ -427,97 +501,54 @@ bool conv3x3_enabled() {
   return v == 1;
 }
 
-// Measured choice between the two tile sizes (tools/conv_bench.py, IVG_C3_NW): filled in from the sweep.
-static bool conv3x3_prefers_16(int cin, int ho, bool ups) {
-  (void)cin; (void)ho; (void)ups;
-  return false;
-}
-
 // Returns -1 when the shape is not covered (caller falls back to the generic implicit GEMM).
 int launch_conv3x3(const IgemmArgs& a, DType dtype, hipStream_t stream) {
+  a.gn_chunks = 0;
   if (!conv3x3_enabled()) return -1;
   if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1) return -1;
   if (a.nb0 * a.nb1 * a.nb2 != 1 || a.alpha != 1.0f || (a.flags & (IG_GLU | IG_BIAS_M))) return -1;
   const int ck = dtype == BF16 ? 32 : 16;
-  if (a.Cin % ck != 0 || a.ldx != a.Cin) return -1;
+  if (a.Cin % ck != 0 || a.ldx != a.Cin || a.N < 1) return -1;
   const int Ho = a.Hout, Wo = a.Wout;
   if (a.ups ? (Ho != 2 * a.Hin || Wo != 2 * a.Win) : (Ho != a.Hin || Wo != a.Win)) return -1;
-  int TW = Wo >= 32 ? 32 : Wo;   // 16x16 or 8x32 output tiles: halo <= 10 x 34 pixels = 49 KiB per buffer
+  const int TW = Wo >= 32 ? 32 : Wo;   // 16x16 or 8x32 output tiles: halo <= 10 x 34 pixels = 24 KiB per buffer
   if (TW != 16 && TW != 32) return -1;
   const int bn = a.N > 64 ? 128 : 64;
-  // 16-wave / 512-pixel (16 x 32) tiles: bf16, 128-channel N tiles, images at least 16 x 32 (IVG_C3_NW=8 / 16 forces)
-  static int nw_env = -1;
-  if (nw_env < 0) { const char* e = getenv("IVG_C3_NW"); nw_env = e ? atoi(e) : 0; }
-  const bool can16 = dtype == BF16 && bn == 128 && TW == 32 && Ho % 16 == 0 && Wo % 32 == 0;
-  const bool nw16 = can16 && (nw_env == 16 || (nw_env == 0 && conv3x3_prefers_16(a.Cin, Ho, a.ups != 0)));
-  const int TH = (nw16 ? 512 : 256) / TW;
+  const int TH = 256 / TW;
   if (Wo % TW != 0 || Ho % TH != 0) return -1;
+  if (((uintptr_t)a.X & 15) || ((uintptr_t)a.W & 15)) return -1;
   Conv3Dev d;
   d.X = a.X; d.W = a.W; d.Y = a.Y; d.R = a.R; d.bias = a.bias;
   d.H = a.Hin; d.Wd = a.Win; d.Cin = a.Cin; d.Ho = Ho; d.Wo = Wo;
-  d.TH = TH; d.TW = TW; d.tw_shift = TW == 32 ? 5 : 4;
-  if (a.ups) { d.HTH = TH / 2 + 2; d.HTW = TW / 2 + 2; }
-  else { d.HTH = TH + 2; d.HTW = TW + 2; }
-  d.tiles_x = Wo / TW; d.tiles_per_img = d.tiles_x * (Ho / TH); d.n_sp = a.Nimg * d.tiles_per_img;
+  d.tiles_x = Wo / TW; d.tiles_per_img = d.tiles_x * (Ho / TH);
   d.N = a.N; d.ldw = a.ldw;
   d.tiles_n = cdiv(a.N, bn);
   d.c_img = a.c_img; d.c_pix = a.c_pix; d.c_ch = a.c_ch; d.c_grp = a.c_grp > 0 ? a.c_grp : 1; d.c_grp_stride = a.c_grp_stride;
   if (a.c_grp <= 1 && a.c_grp_stride == 0) d.c_grp_stride = a.c_img;
-  d.flags = a.flags;
+  d.flags = a.flags; d.stage_ok = 0;
   d.gn_part = nullptr; d.gn_groups = 0; d.gn_off = 0;
   d.in_coef = nullptr; d.coef_off = 0;
   const bool gna = a.gn_in_coef != nullptr;
-  if (gna && (a.ups || nw16)) return -1;   // (the upsampling convs take un-normalised inputs; the 16-wave variant is not instantiated)
+  if (gna && a.ups) return -1;   // (the upsampling convs take un-normalised inputs)
   d.in_coef = (const f32x2*)a.gn_in_coef;
-  if (a.gn_part && a.gn_groups > 0 && a.gn_groups <= 64 && a.N % a.gn_groups == 0 && !nw16 && (a.c_grp <= 1)) {
+  if (a.gn_part && a.gn_groups > 0 && a.gn_groups <= 64 && a.N % a.gn_groups == 0 && (a.c_grp <= 1)) {
     d.gn_part = (double2*)a.gn_part; d.gn_groups = a.gn_groups;
     a.gn_chunks = d.tiles_per_img * d.tiles_n;
-  } else {
-    a.gn_chunks = 0;
   }
-  d.hb_bytes = nw16 ? cdiv(d.HTH * d.HTW * 4, 1024) * 16384 : cdiv(d.HTH * d.HTW * 4, 512) * 8192;
-  {
-    static long long* dbg_buf = nullptr;
-    static int want = -1;
-    if (want < 0) { const char* e = getenv("IVG_C3_DEBUG"); want = (e && e[0] == '1') ? 1 : 0; if (want) (void)hipMalloc((void**)&dbg_buf, 64 * 8); }
-    d.dbg = dbg_buf;
-    if (want) {
-      static int calls = 0;
-      if (++calls == 8) {  // after warm-up: dump the previous launch's stamps
-        long long h[64]; (void)hipDeviceSynchronize(); (void)hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost);
-        const int n = (int)h[63];
-        fprintf(stderr, "[c3 dbg] stamps=%d total=%lld cycles: prologue %lld", n, h[n - 1] - h[0], h[1] - h[0]);
-        for (int i = 2; i + 1 < n - 2; i += 2) fprintf(stderr, " | step %d: compute %lld wait+bar %lld", (i - 2) / 2, h[i] - h[i - 1], h[i + 1] - h[i]);
-        fprintf(stderr, " | drain %lld epilogue %lld\n", h[n - 2] - h[n - 3], h[n - 1] - h[n - 2]);
-      }
-    }
+  // IVG_C3_PRE=0: the halo fragments of a step are read at its top instead of under the MFMAs of the step before
+  static int pre = -1;
+  if (pre < 0) { const char* e = getenv("IVG_C3_PRE"); pre = e ? (e[0] != '0') : 1; }
+#define IVG_C3_TW(T, BNv, U, G, PR) (TW == 16 ? launch_c3<T, BNv, U, 16, G, PR>(d, a.Nimg, stream) : launch_c3<T, BNv, U, 32, G, PR>(d, a.Nimg, stream))
+#define IVG_C3_BN(T, U, G, PR) (bn == 128 ? IVG_C3_TW(T, 128, U, G, PR) : IVG_C3_TW(T, 64, U, G, PR))
+  if (gna) return dtype == BF16 ? IVG_C3_BN(bf16_t, false, true, false) : IVG_C3_BN(float, false, true, false);
+  if (pre) {
+    if (a.ups) return dtype == BF16 ? IVG_C3_BN(bf16_t, true, false, true) : IVG_C3_BN(float, true, false, true);
+    return dtype == BF16 ? IVG_C3_BN(bf16_t, false, false, true) : IVG_C3_BN(float, false, false, true);
   }
-  if (2 * d.hb_bytes + 3 * bn * 64 > (nw16 ? 160 : 80) * 1024) { a.gn_chunks = 0; return -1; }
-  if (((uintptr_t)a.X & 15) || ((uintptr_t)a.W & 15)) { a.gn_chunks = 0; return -1; }
-  {  // development ablations of the bf16 / BN = 128 / no-upsample instance (IVG_C3_ABLATE=<mask>)
-    static int abl = -1;
-    if (abl < 0) { const char* e = getenv("IVG_C3_ABLATE"); abl = e ? atoi(e) : 0; }
-    if (abl && dtype == BF16 && bn == 128 && !a.ups) {
-      switch (abl) {
-        case 1: return launch_c3<bf16_t, 128, false, 1>(d, a.Nimg, stream);
-        case 2: return launch_c3<bf16_t, 128, false, 2>(d, a.Nimg, stream);
-        case 4: return launch_c3<bf16_t, 128, false, 4>(d, a.Nimg, stream);
-        case 8: return launch_c3<bf16_t, 128, false, 8>(d, a.Nimg, stream);
-        case 12: return launch_c3<bf16_t, 128, false, 12>(d, a.Nimg, stream);
-        case 14: return launch_c3<bf16_t, 128, false, 14>(d, a.Nimg, stream);
-        default: break;
-      }
-    }
-  }
-  if (nw16) return a.ups ? launch_c3<bf16_t, 128, true, 0, 16>(d, a.Nimg, stream) : launch_c3<bf16_t, 128, false, 0, 16>(d, a.Nimg, stream);
-  if (gna) {
-    if (dtype == BF16) return bn == 128 ? launch_c3<bf16_t, 128, false, 16>(d, a.Nimg, stream) : launch_c3<bf16_t, 64, false, 16>(d, a.Nimg, stream);
-    return bn == 128 ? launch_c3<float, 128, false, 16>(d, a.Nimg, stream) : launch_c3<float, 64, false, 16>(d, a.Nimg, stream);
-  }
-#define IVG_C3(T, BNv) (a.ups ? launch_c3<T, BNv, true>(d, a.Nimg, stream) : launch_c3<T, BNv, false>(d, a.Nimg, stream))
-  if (dtype == BF16) return bn == 128 ? IVG_C3(bf16_t, 128) : IVG_C3(bf16_t, 64);
-  return bn == 128 ? IVG_C3(float, 128) : IVG_C3(float, 64);
-#undef IVG_C3
+  if (a.ups) return dtype == BF16 ? IVG_C3_BN(bf16_t, true, false, false) : IVG_C3_BN(float, true, false, false);
+  return dtype == BF16 ? IVG_C3_BN(bf16_t, false, false, false) : IVG_C3_BN(float, false, false, false);
+#undef IVG_C3_BN
+#undef IVG_C3_TW
 }
 
 }  // namespace ivg
