@@ -8,6 +8,7 @@ namespace ivg {
 typedef __bf16 bf16_t;
 typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));
 typedef bf16_t bf16x4 __attribute__((ext_vector_type(4)));
+typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -32,6 +33,12 @@ template <> __device__ __forceinline__ float from_f32<float>(float v) { return v
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }  // RNE (v_cvt_pk_bf16_f32)
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+// SiLU whose result is stored as T: for bf16 the IEEE division sequence (~10 vector instructions) is replaced by v_rcp_f32
+// (1 ulp, far below the bf16 rounding that follows); fp32 keeps the exact quotient (the tokenizer's bit-exact ids depend on it)
+template <typename T> __device__ __forceinline__ float silu_t(float v) {
+  if constexpr (sizeof(T) == 2) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+  else return silu_f(v);
+}
 
 // wave64 reductions (gfx950 wavefront = 64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {

@@ -211,13 +211,13 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
           const bf16x8 x = __builtin_bit_cast(bf16x8, raw);
           bf16x8 o;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = (bf16_t)silu_f(fmaf((float)x[j], cf[j][0], cf[j][1]));
+          for (int j = 0; j < 8; ++j) o[j] = (bf16_t)silu_t<T>(fmaf((float)x[j], cf[j][0], cf[j][1]));
           *ptr = __builtin_bit_cast(Chunk16, o);
         } else {
           const f32x4 x = __builtin_bit_cast(f32x4, raw);
           f32x4 o;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = silu_f(fmaf(x[j], cf[j][0], cf[j][1]));
+          for (int j = 0; j < 4; ++j) o[j] = silu_t<T>(fmaf(x[j], cf[j][0], cf[j][1]));
           *ptr = __builtin_bit_cast(Chunk16, o);
         }
       }
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
       }
       if (flags & IG_SILU) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+        for (int r = 0; r < 4; ++r) v[r] = silu_t<T>(v[r]);
       }
       if (gn) {   // statistics of the STORED values (rounded to the output type, as a separate pass over the tensor would see them)
 #pragma unroll

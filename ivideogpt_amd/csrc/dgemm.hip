@@ -33,14 +33,18 @@ struct DgDev {
   unsigned long long* prof; const int* pos; int prof_ld;
 };
 
-__device__ __forceinline__ void dg_dma16(const void* gsrc, unsigned char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+// LDS-DMA with the address split the way the hardware takes it: wave-uniform 64-bit base (scalar registers, advanced per burst /
+// line group by the scalar unit) + 32-bit byte offset per lane (set up once).  __builtin_amdgcn_global_load_lds always gets a
+// 64-bit per-lane address: a 64-bit vector add and a v_readfirstlane for M0 per transfer -- with 36 transfers per burst that
+// was a third of the vector instructions of this kernel, which has ONE wave per SIMD and so nothing to hide them under.
+// lds_wave_base: LDS byte address the wave's 64 x 16 B land at (M0; reserved register, the compiler has no use of its own here).
+__device__ __forceinline__ void dg_dma16(const void* sbase, unsigned voff, unsigned lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_wave_base), "v"(voff), "s"(sbase) : "memory");
 }
-__device__ __forceinline__ void dg_dma16_nt(const void* gsrc, unsigned char* lds_wave_base) {   // aux 2 = nt: streamed-once weights
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2);
+__device__ __forceinline__ void dg_dma16_nt(const void* sbase, unsigned voff, unsigned lds_wave_base) {   // nt: streamed-once weights
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(lds_wave_base), "v"(voff), "s"(sbase) : "memory");
 }
+__device__ __forceinline__ unsigned dg_lds_addr(const void* p) { return (unsigned)(unsigned long)(__attribute__((address_space(3))) const void*)p; }
 
 template <typename T> struct Vec4T;
 template <> struct Vec4T<bf16_t> { typedef bf16x4 type; };
@@ -56,7 +60,8 @@ __global__ __launch_bounds__(WMAX * 64) void dgemm_kernel(const DgDev p) {
   const unsigned long long t_start = p.prof ? (unsigned long long)wall_clock64() : 0ull;
   const int prof_pos = p.prof ? *p.pos : 0;   // read up front: the lm_head launch advances the counter at its end
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, waves = (int)blockDim.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, waves = (int)blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform values stay in scalar registers
   const int lr = lane & 15, lg = lane >> 4;
   const int n_tile = blockIdx.x * 16 * FN, m_tile = blockIdx.y * 16 * MF;
   unsigned char* stage = smem + (size_t)wave * (LG * (MF + FN) * 2048);   // [LG][MF] activation tiles, then [LG][FN] weight tiles
@@ -84,27 +89,25 @@ __global__ __launch_bounds__(WMAX * 64) void dgemm_kernel(const DgDev p) {
   }
 
   // ---- per-lane source addresses
+  // (32-bit byte offsets from X / W: the launcher checks that the operands are smaller than 2 GiB)
   const int r8 = lane >> 3, jj = lane & 7;
-  long xrow[MF][2];
-  int xsw[2];
+  unsigned xoff[MF][2], woff[FN][2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int r = h * 8 + r8;
-    xsw[h] = jj ^ ((r >> 1) & 7);
+    const unsigned sw = (unsigned)(jj ^ ((r >> 1) & 7)) * 16u;   // chunk of the line this lane fetches
 #pragma unroll
     for (int b = 0; b < MF; ++b) {
       const int m = min(m_tile + b * 16 + r, p.M - 1);
-      xrow[b][h] = (long)m * p.ldx * (long)sizeof(T);
+      xoff[b][h] = (unsigned)m * (unsigned)p.ldx * (unsigned)sizeof(T) + sw;
     }
-  }
-  long wrow[FN][2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int a = 0; a < FN; ++a) {
-      const int n = min(n_tile + a * 16 + h * 8 + r8, p.N - 1);
-      wrow[a][h] = (long)n * p.ldw * (long)sizeof(T);
+      const int n = min(n_tile + a * 16 + r, p.N - 1);
+      woff[a][h] = (unsigned)n * (unsigned)p.ldw * (unsigned)sizeof(T) + sw;
     }
+  }
+  const unsigned stage_lds = dg_lds_addr(stage), stage_w_lds = dg_lds_addr(stage_w);
 
   f32x4 acc[FN][MF];
 #pragma unroll
@@ -126,12 +129,12 @@ __global__ __launch_bounds__(WMAX * 64) void dgemm_kernel(const DgDev p) {
       for (int b = 0; b < MF; ++b)
 #pragma unroll
         for (int h = 0; h < 2; ++h)
-          dg_dma16(X + xrow[b][h] + (c0 + g * 8 + xsw[h]) * 16, stage + ((g * MF + b) * 2 + h) * 1024);
+          dg_dma16(X + (c0 + g * 8) * 16, xoff[b][h], stage_lds + ((g * MF + b) * 2 + h) * 1024);
 #pragma unroll
       for (int a = 0; a < FN; ++a)
 #pragma unroll
         for (int h = 0; h < 2; ++h)
-          dg_dma16_nt(W + wrow[a][h] + (c0 + g * 8 + xsw[h]) * 16, stage_w + ((g * FN + a) * 2 + h) * 1024);
+          dg_dma16_nt(W + (c0 + g * 8) * 16, woff[a][h], stage_w_lds + ((g * FN + a) * 2 + h) * 1024);
     }
 #pragma unroll
     for (int g = 0; g < LG; ++g) {
@@ -155,9 +158,13 @@ __global__ __launch_bounds__(WMAX * 64) void dgemm_kernel(const DgDev p) {
 #pragma unroll
           for (int b = 0; b < MF; ++b) {
             if constexpr (sizeof(T) == 2) {
+              // v_dot2c_f32_bf16: two squares per instruction, no unpacking (4 instead of 12 instructions per fragment)
               const bf16x8 xx = __builtin_bit_cast(bf16x8, xa[tt][b]);
 #pragma unroll
-              for (int u = 0; u < 8; ++u) { const float f = (float)xx[u]; ssq[b] = fmaf(f, f, ssq[b]); }
+              for (int u = 0; u < 4; ++u) {
+                const bf16x2 pr = bf16x2{xx[2 * u], xx[2 * u + 1]};
+                ssq[b] = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, ssq[b], false);
+              }
             } else {
               const f32x4 xx = __builtin_bit_cast(f32x4, xa[tt][b]);
 #pragma unroll
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(WMAX * 64) void dgemm_kernel(const DgDev p) {
         f32x4 u = red[((0 * FN + a1) * MF + b) * 64 + lane];
         for (int w = 1; w < waves; ++w) u += red[((w * FN + a1) * MF + b) * 64 + lane];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]) * (u[r] * rs);
+        for (int r = 0; r < 4; ++r) v[r] = silu_t<T>(v[r]) * (u[r] * rs);
       }
       n0 = (n_tile >> 1) + (a >> 1) * 16 + lg * 4;
       nlim = p.N >> 1;
@@ -359,6 +366,7 @@ int launch_dgemm(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
   if (a.M <= 0 || a.N <= 0 || a.M > 128) return -1;
   if (((long)a.K * es) % 128 != 0 || ((long)a.ldx * es) % 16 != 0 || ((long)a.ldw * es) % 16 != 0) return -1;
   if (((uintptr_t)a.X & 15) || ((uintptr_t)a.W & 15)) return -1;
+  if ((long)a.N * a.ldw * es >= (1L << 31) || (long)a.M * a.ldx * es >= (1L << 31)) return -1;   // 32-bit per-lane offsets
   const bool glu = a.flags & IG_GLU;
   if (glu && a.N % 32 != 0) return -1;
   if ((a.flags & IG_RESIDUAL) && !(a.flags & IG_OUT_F32) && ((a.ldy & 3) != 0 || ((uintptr_t)a.Y & (4 * es - 1)))) return -1;

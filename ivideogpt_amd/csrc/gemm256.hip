@@ -127,7 +127,7 @@ __global__ __launch_bounds__(1024) void gemm256_kernel(const G256Dev p) {
       if (glu) {  // rows [16 gate | 16 up] per 32 packed weight rows: fragment a = gate, a + 1 = up of the same 16 outputs
         const int a1 = a + 1 < 4 ? a + 1 : a;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v4[r] = silu_f(v4[r]) * acc[a1][b][r];
+        for (int r = 0; r < 4; ++r) v4[r] = silu_t<bf16_t>(v4[r]) * acc[a1][b][r];
         ocol = (wn * 64 + a * 16) / 2 + lg * 4;
       }
       if ((flags & IG_RESIDUAL) && m < p.M) {
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(1024) void gemm256_kernel(const G256Dev p) {
       }
       if (flags & IG_SILU) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v4[r] = silu_f(v4[r]);
+        for (int r = 0; r < 4; ++r) v4[r] = silu_t<bf16_t>(v4[r]);
       }
       *(bf16x4*)(smem + row * G256_PITCH + ocol * 2) = bf16x4{(bf16_t)v4[0], (bf16_t)v4[1], (bf16_t)v4[2], (bf16_t)v4[3]};
     }

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDev p) {
             for (int r = 0; r < 4; ++r) u[r] += p.bias[n0 + 16 + r];
           }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]) * u[r];
+          for (int r = 0; r < 4; ++r) v[r] = silu_t<T>(v[r]) * u[r];
         }
         no = (n0 >> 5) * 16 + (n0 & 15);
       }
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDev p) {
       }
       if (flags & IG_SILU) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+        for (int r = 0; r < 4; ++r) v[r] = silu_t<T>(v[r]);
       }
       if (flags & IG_OUT_F32) {
         float* Y = (float*)p.Y;

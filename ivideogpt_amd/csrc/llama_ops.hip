@@ -458,6 +458,32 @@ int launch_xattn(const void* q, const void* Kp, const void* VpT, void* out, int 
 // One workgroup per (b, head): RoPE of the new q/k, KV-cache append and single-token attention in one launch.
 // HBM-bound stream of the K and V rows of the cache (coalesced: LPK lanes share one row, 16 bytes each, four
 // independent row loads in flight per lane).  Two passes over LDS-held scores -> deterministic reduction order.
+// q of one lane for the key dot products: fp32 values (fp32 caches) or packed bf16 pairs (bf16 caches)
+template <typename T> struct QPack;
+template <> struct QPack<float> {
+  __device__ __forceinline__ void set(const float*) {}
+  __device__ __forceinline__ float dot(const float* qf, Chunk16 raw) const {
+    const f32x4 kk = __builtin_bit_cast(f32x4, raw);
+    float d = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d = fmaf(qf[j], kk[j], d);
+    return d;
+  }
+};
+template <> struct QPack<bf16_t> {
+  bf16x2 q[4];
+  __device__ __forceinline__ void set(const float* qf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q[j] = bf16x2{(bf16_t)qf[2 * j], (bf16_t)qf[2 * j + 1]};
+  }
+  __device__ __forceinline__ float dot(const float*, Chunk16 raw) const {
+    const bf16x8 kk = __builtin_bit_cast(bf16x8, raw);
+    float d = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d = __builtin_amdgcn_fdot2_f32_bf16(q[j], bf16x2{kk[2 * j], kk[2 * j + 1]}, d, false);
+    return d;
+  }
+};
 template <typename T> __device__ __forceinline__ float dot_chunk(const float* qf, Chunk16 raw) {
   constexpr int VEC = Traits<T>::VEC;
   float d = 0.f;
@@ -503,12 +529,16 @@ __device__ __forceinline__ float group_sum(float d, int lpk) {
 // development (IVG_ATTN_DEBUG): wall-clock (100 MHz) phase stamps of workgroups 0 and last at cache position 640
 __device__ unsigned long long g_attn_dbg[2][8];
 
-template <typename T, bool NT>   // NT: non-temporal loads of the cache rows (streamed once per step: keep them from evicting the weights)
+// NT: non-temporal loads of the cache rows (streamed once per step: keep them from evicting the weights)
+// HD: head dimension as a compile-time value (64 for the released transformers; 0 = generic, read from the argument) -- with it
+// the lane-group reductions, the group counts and the row strides are constants instead of chains of scalar branches per chunk
+template <typename T, bool NT, int HD>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
                                                           T* __restrict__ out, const float* __restrict__ cosT,
-                                                          const float* __restrict__ sinT, int heads, int hd, int Lmax,
+                                                          const float* __restrict__ sinT, int heads, int hd_arg, int Lmax,
                                                           const StepState* __restrict__ state, unsigned long long* prof) {
   constexpr int VEC = Traits<T>::VEC;
+  const int hd = HD > 0 ? HD : hd_arg;
   constexpr int UNR = 8;   // 16-byte loads in flight per lane: 3 workgroups x 256 lanes x 8 x 16 B = 96 KiB per CU
   // measurement hook (bench.py roofline): launch window = [min start, max end] over workgroups on the 100 MHz wall clock,
   // reduced per slot here (min kept as max of the complement so that 0 = not stamped) and over slots by the host
@@ -535,12 +565,17 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   T* kb = kc + ((long)b * heads + h) * Lmax * hd;
   T* vb = vc + ((long)b * heads + h) * Lmax * hd;
   const int step = gpb * UNR;
+  // rows beyond the cached keys are not zero-filled but re-read row pos - 1 (row 0 before anything is cached) and ignored by
+  // the consumers: no select / zero moves per load; 32-bit byte offsets from the (wave-uniform) head base
+  const int last_row = pos > 0 ? pos - 1 : 0;
+  const unsigned lane_off = (unsigned)(sub * VEC) * (unsigned)sizeof(T);
   auto load_rows = [&](Chunk16 (&dst)[UNR], const T* base, int t0) {
+    const char* bb = (const char*)base;
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      const int t = t0 + u * gpb + grp;
-      const Chunk16* src = (const Chunk16*)(base + (long)t * hd + sub * VEC);
-      dst[u] = t < pos ? (NT ? __builtin_nontemporal_load(src) : *src) : Chunk16{0u, 0u, 0u, 0u};
+      const int t = min(t0 + u * gpb + grp, last_row);
+      const Chunk16* src = (const Chunk16*)(bb + ((unsigned)(t * hd) * (unsigned)sizeof(T) + lane_off));
+      dst[u] = NT ? __builtin_nontemporal_load(src) : *src;
     }
   };
   Chunk16 cur[UNR], nxt[UNR];
@@ -570,20 +605,40 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   float qf[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) qf[j] = sq[sub * VEC + j];
+  // bf16: q (already rounded to bf16) as packed pairs for v_dot2c_f32_bf16 -- two products per instruction, no unpacking of
+  // the key chunk (the products are exact either way; 4 instead of 16 instructions per 16-byte chunk)
+  QPack<T> qp;
+  qp.set(qf);
   // pass A: scores of the cached keys (the new key comes from LDS); the next rows are requested before the current
-  // ones are consumed, and the first value rows before the softmax statistics
-  for (int t0 = 0; t0 < pos; t0 += step) {
-    if (t0 + step < pos) load_rows(nxt, kb, t0 + step);
-    else load_rows(nxt, vb, 0);
+  // ones are consumed, and the first value rows before the softmax statistics.  The two row buffers swap roles every
+  // iteration (unrolled by two: no register copies); the value rows requested last end up in `cur` for pass C.
+  auto scores = [&](Chunk16 (&rows)[UNR], int t0) {
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int t = t0 + u * gpb + grp;
-      float d = dot_chunk<T>(qf, cur[u]);
+      float d = qp.dot(qf, rows[u]);
       d = group_sum(d, lpk);
       if (t < pos && sub == 0) sc[t] = d * scale;
     }
+  };
+  {
+    int t0 = 0;
+    bool in_nxt = false;   // the rows to consume next are in `nxt`
+    while (t0 < pos) {
+      if (t0 + step < pos) load_rows(nxt, kb, t0 + step); else load_rows(nxt, vb, 0);
+      scores(cur, t0);
+      t0 += step;
+      in_nxt = true;
+      if (t0 >= pos) break;
+      if (t0 + step < pos) load_rows(cur, kb, t0 + step); else load_rows(cur, vb, 0);
+      scores(nxt, t0);
+      t0 += step;
+      in_nxt = false;
+    }
+    if (in_nxt) {
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) cur[u] = nxt[u];
+      for (int u = 0; u < UNR; ++u) cur[u] = nxt[u];
+    }
   }
   if (dbg) dslot[3] = wall_clock64();
   if (grp == 0) {
@@ -612,15 +667,19 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   float of[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) of[j] = 0.f;
-  for (int t0 = 0; t0 < pos; t0 += step) {  // cur holds value rows [t0, t0 + step) (requested during pass A / the last iteration)
-    if (t0 + step < pos) load_rows(nxt, vb, t0 + step);
+  auto weighted = [&](Chunk16 (&rows)[UNR], int t0) {
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int t = t0 + u * gpb + grp;
-      if (t < pos) axpy_chunk<T>(of, sc[t], cur[u]);
+      if (t < pos) axpy_chunk<T>(of, sc[t], rows[u]);
     }
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) cur[u] = nxt[u];
+  };
+  for (int t0 = 0; t0 < pos; t0 += 2 * step) {  // cur holds value rows [t0, t0 + step) (requested during pass A / the last iteration)
+    if (t0 + step < pos) load_rows(nxt, vb, t0 + step);
+    weighted(cur, t0);
+    if (t0 + step >= pos) break;
+    if (t0 + 2 * step < pos) load_rows(cur, vb, t0 + 2 * step);
+    weighted(nxt, t0 + step);
   }
   if (dbg) dslot[5] = wall_clock64();
   if (grp == 0) {
@@ -663,15 +722,13 @@ int launch_decode_attn(const void* qkv, void* kc, void* vc, void* out, const flo
   dim3 g(B * heads);
   // non-temporal cache-row loads: 5.57 -> 6.28 TB/s on a pure stream, 203 -> 191 ms per rollout (IVG_ATTN_NT=0: plain loads, A/B)
   static const bool nt = [] { const char* v = getenv("IVG_ATTN_NT"); return !(v && v[0] == '0'); }();
-  if (dt == BF16 && nt)
-    hipLaunchKernelGGL((decode_attn_kernel<bf16_t, true>), g, dim3(256), smem, st, (const bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc, (bf16_t*)out,
-                       cosT, sinT, heads, hd, Lmax, state, prof);
-  else if (dt == BF16)
-    hipLaunchKernelGGL((decode_attn_kernel<bf16_t, false>), g, dim3(256), smem, st, (const bf16_t*)qkv, (bf16_t*)kc, (bf16_t*)vc, (bf16_t*)out,
-                       cosT, sinT, heads, hd, Lmax, state, prof);
-  else
-    hipLaunchKernelGGL((decode_attn_kernel<float, false>), g, dim3(256), smem, st, (const float*)qkv, (float*)kc, (float*)vc, (float*)out, cosT,
-                       sinT, heads, hd, Lmax, state, prof);
+#define IVG_DA(T, NTv, HDv)                                                                                                       \
+  hipLaunchKernelGGL((decode_attn_kernel<T, NTv, HDv>), g, dim3(256), smem, st, (const T*)qkv, (T*)kc, (T*)vc, (T*)out, cosT, sinT, heads, hd, \
+                     Lmax, state, prof)
+  if (dt == BF16 && nt) { if (hd == 64) IVG_DA(bf16_t, true, 64); else IVG_DA(bf16_t, true, 0); }
+  else if (dt == BF16) { if (hd == 64) IVG_DA(bf16_t, false, 64); else IVG_DA(bf16_t, false, 0); }
+  else { if (hd == 64) IVG_DA(float, false, 64); else IVG_DA(float, false, 0); }
+#undef IVG_DA
   return (int)hipGetLastError();
 }
 

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ X, 
     for (int j = 0; j < VEC; ++j) {
       const f32x2 cf = coef[c0 + j];
       float y = fmaf(f[j], cf[0], cf[1]);
-      if (silu) y = silu_f(y);
+      if (silu) y = silu_t<T>(y);
       if (pos) y += pos[(long)p * C + c0 + j];
       f[j] = y;
     }

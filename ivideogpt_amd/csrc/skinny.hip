@@ -170,7 +170,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(const SkinnyDev p) {
 #pragma unroll
         for (int w = 1; w < WAVES; ++w) u += red[((w * FN + a1) * MF + b) * 64 + lane];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]) * (u[r] * rs);
+        for (int r = 0; r < 4; ++r) v[r] = silu_t<T>(v[r]) * (u[r] * rs);
       }
       n0 = (n_tile >> 1) + (a >> 1) * 16 + lg * 4;
       nlim = p.N >> 1;
