@@ -179,6 +179,8 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
   }
   const int w_dst = (BN == 128 ? wave : (wave & 3)) * 1024;
   auto issue_w = [&](int tap, int chunk, int ring) {
+    // (the 64-byte-per-row shape of these requests is not what bounds the kernel: requesting the same bytes as whole 128-byte
+    // lines -- a probe with wrong results -- changed nothing, profiles/r02_conv3x3_wline_probe.txt)
     glds16s((const unsigned char*)p.W + (size_t)(tap * p.Cin + chunk * CK) * sizeof(T), woff, lds_addr(wbuf0) + ring * W_BYTES + w_dst);
   };
 

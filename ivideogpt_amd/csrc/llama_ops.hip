@@ -565,17 +565,16 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   T* kb = kc + ((long)b * heads + h) * Lmax * hd;
   T* vb = vc + ((long)b * heads + h) * Lmax * hd;
   const int step = gpb * UNR;
-  // rows beyond the cached keys are not zero-filled but re-read row pos - 1 (row 0 before anything is cached) and ignored by
-  // the consumers: no select / zero moves per load; 32-bit byte offsets from the (wave-uniform) head base
-  const int last_row = pos > 0 ? pos - 1 : 0;
+  // rows beyond the cached keys are not requested (on average half of the last block of 256: re-reading a clamped row instead
+  // measured +1 us per launch); 32-bit byte offsets from the (wave-uniform) head base
   const unsigned lane_off = (unsigned)(sub * VEC) * (unsigned)sizeof(T);
   auto load_rows = [&](Chunk16 (&dst)[UNR], const T* base, int t0) {
     const char* bb = (const char*)base;
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      const int t = min(t0 + u * gpb + grp, last_row);
+      const int t = t0 + u * gpb + grp;
       const Chunk16* src = (const Chunk16*)(bb + ((unsigned)(t * hd) * (unsigned)sizeof(T) + lane_off));
-      dst[u] = NT ? __builtin_nontemporal_load(src) : *src;
+      dst[u] = t < pos ? (NT ? __builtin_nontemporal_load(src) : *src) : Chunk16{0u, 0u, 0u, 0u};
     }
   };
   Chunk16 cur[UNR], nxt[UNR];
