@@ -27,6 +27,7 @@
 //     halo fragments of step s + 1 are read under the MFMAs of step s.
 // Bytes per (tap, chunk) step: 8 KiB of weights + 1/9 of a ~24 KiB halo for 2.1 MFLOP -> ~195 FLOP/B (igemm: 64).
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -95,8 +96,10 @@ template <int N> __device__ __forceinline__ void wait_dma_keep() {   // all DMA 
 // (y = silu(x * scale[c] + shift[c]), out-of-image padding stays zero) between its arrival and its first tap, piece by piece
 // under the taps of the previous chunk, so the normalised tensor never exists in HBM (measured slower than
 // the separate apply pass, off by default).
-// PRE: the halo fragments of step s + 1 are read under the MFMAs of step s.
-template <typename T, int BN, bool UPS, int TW, bool GNA, bool PRE>
+// TPB2: two (tap, chunk) steps per workgroup barrier -- the weight ring holds two slots of two tiles and is refilled one PAIR of
+// steps ahead, the fragment registers are reused by the second step; 80 KiB of LDS, still two workgroups per CU.
+// (Reading the halo fragments of step s + 1 under the MFMAs of step s was measured: +-0.5 %, removed.)
+template <typename T, int BN, bool UPS, int TW, bool GNA, bool TPB2>
 __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
   constexpr int VEC = Traits<T>::VEC;
   constexpr int CK = 4 * VEC;              // channels per chunk: one 64-byte LDS row per halo pixel (one MFMA K-step)
@@ -156,7 +159,9 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
     const int c = slot ^ halo_key<UPS>(hx);
     const int iy = iy0 + hy, ix = ix0 + hx;
     hok[it] = (row < HROWS) & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.Wd);
-    hoff[it] = hok[it] ? (unsigned)(((iy * p.Wd + ix) * p.Cin + c * VEC) * (int)sizeof(T)) : 0u;
+    // (24-bit multiply: pixel index < 2^24, bytes per pixel < 2^24 -- keeps the offset a single 32-bit register; the generic
+    // form is selected as a 64-bit multiply-add whose register pair stays allocated through the loop)
+    hoff[it] = hok[it] ? (unsigned)__umul24((unsigned)(iy * p.Wd + ix), (unsigned)(p.Cin * (int)sizeof(T))) + (unsigned)(c * VEC * (int)sizeof(T)) : 0u;
     h_any[it] = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(hok[it]) != 0 ? 1 : 0);
     if (!hok[it]) {
       *(Chunk16*)(hbuf0 + (size_t)q * 16) = Chunk16{0, 0, 0, 0};
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
     const int n = q >> 2, slot = q & 3;
     const int c = slot ^ swz_key(n);
     const int nrow = min(n_base + n, p.N - 1);
-    woff = (unsigned)((nrow * p.ldw + c * VEC) * (int)sizeof(T));
+    woff = (unsigned)(nrow * p.ldw) * (unsigned)sizeof(T) + (unsigned)(c * VEC * (int)sizeof(T));
   }
   const int w_dst = (BN == 128 ? wave : (wave & 3)) * 1024;
   auto issue_w = [&](int tap, int chunk, int ring) {
@@ -229,24 +234,29 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
   // ---- per-lane LDS fragment addresses, set up once.  Halo: one base per kw (and per column half where the key differs);
   // the pixel row of fragment b and the kh tap are constant byte offsets.  Weights: one base; ring slot and the FN
   // 16-row groups are constant offsets.
-  constexpr int NPX = (UPS && TW == 32) ? 2 : 1;
-  int a_base[3][NPX];   // byte offsets into halo buffer 0 (buffer 1: + HB, an immediate -- the chunk loop is unrolled by two)
+  // Upsampling instances with 32-pixel rows: the second column half of a wave's fragments sits 8 halo columns further, where
+  // the key differs in its low bit (bitrev2 of (column >> 2) + 2): its address is (base + 8 * 64) ^ 16 -- two instructions at
+  // the read instead of three more registers that the loop cannot spare.
+  constexpr bool XHALF = UPS && TW == 32;
+  int a_base[3];   // byte offsets into halo buffer 0 (buffer 1: + HB, an immediate -- the chunk loop is unrolled by two)
 #pragma unroll
-  for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-    for (int pi = 0; pi < NPX; ++pi) {
-      int hx, rowbase;
-      if constexpr (UPS) { hx = ((lr + pi * 16 + kw - 1) >> 1) + 1; rowbase = (pyw >> 1) * HTW; }
-      else { hx = lr + kw; rowbase = pyw * HTW; }
-      a_base[kw][pi] = (rowbase + hx) * 64 + ((lg ^ halo_key<UPS>(hx)) << 4);
-    }
+  for (int kw = 0; kw < 3; ++kw) {
+    int hx, rowbase;
+    if constexpr (UPS) { hx = ((lr + kw - 1) >> 1) + 1; rowbase = (pyw >> 1) * HTW; }
+    else { hx = lr + kw; rowbase = pyw * HTW; }
+    a_base[kw] = (rowbase + hx) * 64 + ((lg ^ halo_key<UPS>(hx)) << 4);
+  }
   auto a_imm = [&](int b, int kh) constexpr -> int {   // folds to an immediate after unrolling
     if constexpr (UPS) return ((((BR(b) + kh - 1) >> 1) + 1) * HTW) * 64;
     else return ((BR(b) + kh) * HTW + PXO(b)) * 64;
   };
   auto read_a = [&](int buf, int tap, int b) -> Chunk16 {
     const int kh = tap / 3, kw = tap - kh * 3;
-    return *(const Chunk16*)(hbuf0 + a_base[kw][NPX == 2 ? (b & 1) : 0] + (buf * HB + a_imm(b, kh)));
+    int base = a_base[kw];
+    if constexpr (XHALF) {
+      if (b & 1) { asm volatile("" : "+v"(base)); base = (base + 8 * 64) ^ 16; }   // (opaque: or the compiler hoists the three results back into registers)
+    }
+    return *(const Chunk16*)(hbuf0 + base + (buf * HB + a_imm(b, kh)));
   };
   const int w_base = swz(wn * WN + lr, lg);
 
@@ -263,7 +273,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
 #pragma unroll
   for (int it = 0; it < HI; ++it) issue_halo_piece(it, 0, hbuf0);
   issue_w(0, 0, 0);
-  issue_w(1, 0, 1);
+  issue_w(1, 0, 1);   // (slot 1 of the three-slot ring = second half of slot 0 of the pair ring)
   (void)load_coef(0);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -273,10 +283,6 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
     __builtin_amdgcn_s_barrier();
   }
   Chunk16 xa[FM];
-  if constexpr (PRE) {
-#pragma unroll
-    for (int b = 0; b < FM; ++b) xa[b] = read_a(0, 0, b);
-  }
   // the two waves of a SIMD (w, w + 4) issue their DMA at different points of the step, so one of them is always
   // feeding the matrix pipe (an in-order wave cannot issue MFMAs while it is issuing LDS-DMA)
   const bool early = __builtin_amdgcn_readfirstlane(wave) < 4;
@@ -307,11 +313,10 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
         }
       }
       if (!early) issue_dma();
+      __builtin_amdgcn_sched_barrier(0);   // (as in the two-step loop: bounds the register pressure of the unrolled taps)
       Chunk16 wv[FN];
-      if constexpr (!PRE) {
 #pragma unroll
-        for (int b = 0; b < FM; ++b) xa[b] = read_a(PAR, tap, b);
-      }
+      for (int b = 0; b < FM; ++b) xa[b] = read_a(PAR, tap, b);
 #pragma unroll
       for (int a = 0; a < FN; ++a) wv[a] = *(const Chunk16*)(wbuf0 + w_base + ((tap % 3) * W_BYTES + a * 1024));
 #pragma unroll
@@ -327,16 +332,6 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
             for (int u = 0; u < 4; ++u) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u], xf[u], acc[a][b], 0, 0, 0);
           }
         }
-        // the halo tile of the next step is already resident (same chunk, or the next chunk whose pieces landed by tap 4):
-        // its fragment b replaces the one whose last MFMA was just issued and travels under the remaining MFMAs of this step
-        if constexpr (PRE) { if (tap < 8 || more) xa[b] = read_a(tap < 8 ? PAR : 1 - PAR, (tap + 1) % 9, b); }
-      }
-      if constexpr (PRE) {   // keep the order written above: FN (x 4 for fp32) MFMAs, then the read that follows them
-#pragma unroll
-        for (int b = 0; b < FM; ++b) {
-          __builtin_amdgcn_sched_group_barrier(0x008, sizeof(T) == 2 ? FN : 4 * FN, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
       }
       // everything issued BEFORE this step has landed once at most `issued` transfers are still in flight
       if (issued == 0) wait_dma_keep<0>();
@@ -346,9 +341,69 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
       __builtin_amdgcn_s_barrier();
     }
   };
-  for (int chunk = 0; chunk < nchunks; chunk += 2) {
-    run_chunk(chunk, std::integral_constant<int, 0>{});
-    if (chunk + 1 < nchunks) run_chunk(chunk + 1, std::integral_constant<int, 1>{});
+  if constexpr (!TPB2) {
+    for (int chunk = 0; chunk < nchunks; chunk += 2) {
+      run_chunk(chunk, std::integral_constant<int, 0>{});
+      if (chunk + 1 < nchunks) run_chunk(chunk + 1, std::integral_constant<int, 1>{});
+    }
+  } else {
+    static_assert(!(GNA && TPB2), "the fused input GroupNorm runs on the one-step-per-barrier loop");
+    // Two chunks = 18 steps = nine PAIRS of steps, unrolled: step s of the group is (chunk cg + s / 9, tap s % 9) and reads halo
+    // buffer (s / 9) & 1.  Weight ring: two slots of two tiles; the pair after this one is requested at the top of this pair
+    // into the other slot (free since the barrier that ended the previous pair) and has landed at this pair's end -- the
+    // end-of-pair wait lets only the halo piece requested in this pair stay in flight.  Halo of chunk cg + 1 (buffer 1, last
+    // read in the previous group's last pair): pieces at pairs 0 .. HI-1, first needed in pair 4; halo of chunk cg + 2
+    // (buffer 0, last read in the first half of pair 4): pieces at pairs 5 .. 5+HI-1, first needed in the next group's pair 0.
+    int pair = 0;
+    for (int cg = 0; cg < nchunks; cg += 2) {
+      const bool has_c1 = cg + 1 < nchunks, has_c2 = cg + 2 < nchunks;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const int s0 = 2 * k, s1 = 2 * k + 1;
+        if (s0 >= 9) { if (!has_c1) break; }
+        const bool second = s1 < 9 || has_c1;
+        const int slot = pair & 1;
+        int issued_h = 0;
+        auto issue_dma = [&]() {
+          const int n0 = s0 + 2, n1 = s1 + 2;   // the next pair's steps (>= 18: the next group)
+          const bool e0 = n0 < 9 ? true : (n0 < 18 ? has_c1 : has_c2);
+          const bool e1 = n1 < 9 ? true : (n1 < 18 ? has_c1 : has_c2);
+          const int nslot = (slot ^ 1) * 2;
+          if (e0) issue_w(n0 % 9, cg + n0 / 9, nslot);
+          if (e1) issue_w(n1 % 9, cg + n1 / 9, nslot + 1);
+          if (k < HI) { if (has_c1) { issue_halo_piece(k, cg + 1, hbuf0 + HB); issued_h += h_any[k < HI ? k : 0]; } }
+          if (k >= 5 && k - 5 < HI) { if (has_c2) { issue_halo_piece(k - 5, cg + 2, hbuf0); issued_h += h_any[(k >= 5 && k - 5 < HI) ? k - 5 : 0]; } }
+        };
+        const int w_cur = w_base + slot * 2 * W_BYTES;
+        auto half_step = [&](int s, int half) {
+          __builtin_amdgcn_sched_barrier(0);   // keep the next step's fragment reads from being hoisted over this step's MFMAs (registers)
+          Chunk16 wv[FN];
+#pragma unroll
+          for (int b = 0; b < FM; ++b) xa[b] = read_a((s / 9) & 1, s % 9, b);
+#pragma unroll
+          for (int a = 0; a < FN; ++a) wv[a] = *(const Chunk16*)(wbuf0 + w_cur + (half * W_BYTES + a * 1024));
+#pragma unroll
+          for (int b = 0; b < FM; ++b)
+#pragma unroll
+            for (int a = 0; a < FN; ++a) {
+              if constexpr (sizeof(T) == 2) {
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[a]), __builtin_bit_cast(bf16x8, xa[b]),
+                                                                    acc[a][b], 0, 0, 0);
+              } else {
+                const f32x4 wf = __builtin_bit_cast(f32x4, wv[a]), xf = __builtin_bit_cast(f32x4, xa[b]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u], xf[u], acc[a][b], 0, 0, 0);
+              }
+            }
+        };
+        issue_dma();
+        half_step(s0, 0);
+        if (second) half_step(s1, 1);
+        if (issued_h == 0) wait_dma_keep<0>(); else wait_dma_keep<1>();
+        __builtin_amdgcn_s_barrier();
+        ++pair;
+      }
+    }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
@@ -471,21 +526,23 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
   }
 }
 
-template <typename T, int BN, bool UPS, int TW, bool GNA, bool PRE>
+template <typename T, int BN, bool UPS, int TW, bool GNA, bool TPB2>
 static int launch_c3(const Conv3Dev& d, int nimg, hipStream_t stream) {
   constexpr int TH = 256 / TW;
   constexpr int HROWS = (UPS ? TH / 2 + 2 : TH + 2) * (UPS ? TW / 2 + 2 : TW + 2);
   constexpr int HB = (HROWS * 4 + 511) / 512 * 8192;
-  int smem = 2 * HB + 3 * BN * 64;
-  static_assert(2 * HB + 3 * BN * 64 <= 80 * 1024, "two workgroups per CU");
+  constexpr int MAIN = 2 * HB + (TPB2 ? 4 : 3) * BN * 64;   // halo double buffer + weight ring
+  static_assert(MAIN <= 80 * 1024, "two workgroups per CU");
+  int smem = MAIN;
   const int stage = 256 * (BN * (int)sizeof(T) + 16);   // LDS-staged epilogue tile
   Conv3Dev dd = d;
   dd.stage_ok = stage <= 80 * 1024;                      // keeps two workgroups per CU (fp32 x 128 channels stores directly)
   if (dd.stage_ok && smem < stage) smem = stage;
-  if (d.gn_part) { dd.gn_off = (smem + 15) & ~15; smem = dd.gn_off + 2 * 4 * BN * 4; }
+  // the statistics partials of the epilogue sit behind the staging tile (the main-loop buffers are dead by then)
+  if (d.gn_part) { dd.gn_off = dd.stage_ok ? ((stage + 15) & ~15) : 0; smem = std::max(smem, dd.gn_off + 2 * 4 * BN * 4); }
   if constexpr (GNA) { dd.coef_off = (smem + 15) & ~15; smem = dd.coef_off + 2 * (4 * Traits<T>::VEC) * 8; }
   static unsigned long long attr_set = 0;
-  auto kfn = conv3x3_kernel<T, BN, UPS, TW, GNA, PRE>;
+  auto kfn = conv3x3_kernel<T, BN, UPS, TW, GNA, TPB2>;
   if (first_time_on_device(attr_set)) {
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
@@ -537,16 +594,15 @@ int launch_conv3x3(const IgemmArgs& a, DType dtype, hipStream_t stream) {
     d.gn_part = (double2*)a.gn_part; d.gn_groups = a.gn_groups;
     a.gn_chunks = d.tiles_per_img * d.tiles_n;
   }
-  // IVG_C3_PRE=0: the halo fragments of a step are read at its top instead of under the MFMAs of the step before
-  static int pre = -1;
-  if (pre < 0) { const char* e = getenv("IVG_C3_PRE"); pre = e ? (e[0] != '0') : 1; }
+  // IVG_C3_TPB=1: one step per barrier everywhere (A/B); default: two steps per barrier for bf16
+  static int tpb = -1;
+  if (tpb < 0) { const char* e = getenv("IVG_C3_TPB"); tpb = e ? atoi(e) : 2; }
 #define IVG_C3_TW(T, BNv, U, G, PR) (TW == 16 ? launch_c3<T, BNv, U, 16, G, PR>(d, a.Nimg, stream) : launch_c3<T, BNv, U, 32, G, PR>(d, a.Nimg, stream))
 #define IVG_C3_BN(T, U, G, PR) (bn == 128 ? IVG_C3_TW(T, 128, U, G, PR) : IVG_C3_TW(T, 64, U, G, PR))
   if (gna) return dtype == BF16 ? IVG_C3_BN(bf16_t, false, true, false) : IVG_C3_BN(float, false, true, false);
-  if (pre) {
-    if (a.ups) return dtype == BF16 ? IVG_C3_BN(bf16_t, true, false, true) : IVG_C3_BN(float, true, false, true);
-    return dtype == BF16 ? IVG_C3_BN(bf16_t, false, false, true) : IVG_C3_BN(float, false, false, true);
-  }
+  // (measured per shape, profiles/r02_conv3x3_tpb.txt: +2 ... +3.5 % on the plain convolutions, -0.8 % on the upsampling ones,
+  // whose 32-pixel-row instance also spills registers in the two-step form: those keep one step per barrier)
+  if (tpb == 2 && dtype == BF16 && !a.ups) return IVG_C3_BN(bf16_t, false, false, true);
   if (a.ups) return dtype == BF16 ? IVG_C3_BN(bf16_t, true, false, false) : IVG_C3_BN(float, true, false, false);
   return dtype == BF16 ? IVG_C3_BN(bf16_t, false, false, false) : IVG_C3_BN(float, false, false, false);
 #undef IVG_C3_BN
