@@ -40,6 +40,9 @@ constexpr int G256_SLAB = 256 * 64;               // bytes of one 256-row x 32-e
 constexpr int G256_STAGE = 2 * G256_SLAB;         // A | W
 constexpr int G256_PITCH = 256 * 2 + 16;          // staged output row (bytes): + 16 spreads the 16 rows of a fragment over banks
 
+// PAIR: two K steps per workgroup barrier (the 16-wave barrier is the expensive event of this loop): the ring is used as two
+// double stages, the pair after this one is requested at the top of this pair and waited for at its end.
+template <bool PAIR>
 __global__ __launch_bounds__(1024) void gemm256_kernel(const G256Dev p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -73,15 +76,7 @@ __global__ __launch_bounds__(1024) void gemm256_kernel(const G256Dev p) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int s = 0; s < G256_STAGES - 1 && s < steps; ++s) issue(s);
-  // step 0 must have landed: at most the (min(steps, STAGES - 1) - 1) younger steps (2 DMA instructions each) stay in flight
-  if (steps >= 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if (steps == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  for (int s = 0; s < steps; ++s) {
-    if (s + G256_STAGES - 1 < steps) issue(s + G256_STAGES - 1);   // its stage was read at step s - 1, before the last barrier
+  auto mma_step = [&](int s) {
     const unsigned char* sa = smem + (s % G256_STAGES) * G256_STAGE;
     const unsigned char* sw = sa + G256_SLAB;
     Chunk16 xa[4], wv[4];
@@ -95,12 +90,38 @@ __global__ __launch_bounds__(1024) void gemm256_kernel(const G256Dev p) {
       for (int b = 0; b < 4; ++b)
         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[a]), __builtin_bit_cast(bf16x8, xa[b]),
                                                             acc[a][b], 0, 0, 0);
+  };
+  if constexpr (PAIR) {
+    issue(0);
+    if (steps > 1) issue(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int s = 0; s < steps; s += 2) {
+      if (s + 2 < steps) issue(s + 2);   // stages (s + 2) % 4, (s + 3) % 4 were read in the previous pair, before the last barrier
+      if (s + 3 < steps) issue(s + 3);
+      mma_step(s);
+      if (s + 1 < steps) mma_step(s + 1);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  } else {
+  for (int s = 0; s < G256_STAGES - 1 && s < steps; ++s) issue(s);
+  // step 0 must have landed: at most the (min(steps, STAGES - 1) - 1) younger steps (2 DMA instructions each) stay in flight
+  if (steps >= 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if (steps == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  for (int s = 0; s < steps; ++s) {
+    if (s + G256_STAGES - 1 < steps) issue(s + G256_STAGES - 1);   // its stage was read at step s - 1, before the last barrier
+    mma_step(s);
     // step s + 1 must have landed before anyone reads it: everything but the younger steps still allowed in flight
     const int young = min(G256_STAGES - 2, steps - 2 - s);   // steps s + 2 .. in flight after this wait
     if (young >= 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     else if (young == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+  }
   }
 
   // ---- epilogue: lane holds 4 consecutive columns n of row (wm*64 + b*16 + lr)
@@ -177,13 +198,17 @@ int launch_gemm256(const IgemmArgs& a, DType dtype, hipStream_t stream) {
   d.tiles_n = a.N / 256;
   d.flags = a.flags;
   const int smem = 256 * G256_PITCH > G256_STAGES * G256_STAGE ? 256 * G256_PITCH : G256_STAGES * G256_STAGE;
+  // IVG_G256_PAIR=1: two K steps per barrier -- measured, no change (rollout 147.3-147.9 ms either way, profiles/r02_gemm256_pair.txt)
+  static const bool pair = [] { const char* v = getenv("IVG_G256_PAIR"); return v && v[0] == '1'; }();
   static unsigned long long attr_set = 0;
   if (first_time_on_device(attr_set)) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
   }
   const long tiles = (long)cdiv(M, 256) * d.tiles_n;
-  hipLaunchKernelGGL(gemm256_kernel, dim3((unsigned)tiles), dim3(1024), smem, stream, d);
+  if (pair) hipLaunchKernelGGL(gemm256_kernel<true>, dim3((unsigned)tiles), dim3(1024), smem, stream, d);
+  else hipLaunchKernelGGL(gemm256_kernel<false>, dim3((unsigned)tiles), dim3(1024), smem, stream, d);
   return (int)hipGetLastError();
 }
 

@@ -105,10 +105,12 @@ def test_conv_modes(dt, mode):
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 @pytest.mark.parametrize("H,Cin,Cout,ups,res", [(64, 128, 128, 0, 1), (32, 256, 512, 0, 0), (16, 512, 512, 1, 0), (32, 128, 64, 1, 1),
-                                                 (128, 64, 128, 0, 0), (16, 64, 192, 0, 1)])
+                                                 (128, 64, 128, 0, 0), (16, 64, 192, 0, 1), (16, 96, 128, 0, 0), (32, 32, 64, 0, 1),
+                                                 (16, 160, 64, 1, 0), (64, 32, 128, 1, 1)])
 def test_conv3x3_halo_kernel(dt, H, Cin, Cout, ups, res):
-    """the LDS-halo 3x3 kernel (conv3x3.hip): every tile shape (16x16 / 8x32 / 4x64), multi-chunk Cin, several N tiles,
-    nearest-x2 upsampling folded into the halo gather, bias + in-place residual"""
+    """the LDS-halo 3x3 kernel (conv3x3.hip): both tile shapes (16x16 / 8x32), one to sixteen K chunks incl. ODD chunk counts
+    (the step loop is unrolled over two chunks, two steps per barrier for bf16: the tail of the last group), several N tiles,
+    ragged N (192 = 128 + 64), nearest-x2 upsampling folded into the halo gather, bias + in-place residual"""
     g = torch.Generator().manual_seed(H + Cin + Cout)
     Nb = 3
     x = q(torch.randn(Nb, Cin, H, H, generator=g), dt)
@@ -433,12 +435,15 @@ def test_decode_gemm_model_shapes(K, N, mode, dt, gen, monkeypatch):
         assert rel_err(Y.float(), ref) < tol, (M, K, N, mode, dt, gen)
 
 
-@pytest.mark.parametrize("mode", ["plain", "bias_residual_inplace", "glu", "silu", "k_short", "nimg"])
+@pytest.mark.parametrize("mode", ["plain", "bias_residual_inplace", "glu", "silu", "k_short", "k_odd_steps", "nimg"])
 def test_gemm256_large_dense(mode, monkeypatch):
-    """256 x 256-tile GEMM of the prompt pass (bf16, rows not a multiple of 256): every epilogue against fp64, and bit-for-bit
+    """(k_odd_steps also runs the two-steps-per-barrier variant, IVG_G256_PAIR=1, whose last pair is half empty)
+    256 x 256-tile GEMM of the prompt pass (bf16, rows not a multiple of 256): every epilogue against fp64, and bit-for-bit
     agreement is NOT required with the 128 x 128 kernel -- but both must sit inside the same bf16 tolerance."""
     g = torch.Generator().manual_seed(len(mode))
-    M, N, K = 4900, 512, (64 if mode == "k_short" else 384)
+    if mode == "k_odd_steps":
+        monkeypatch.setenv("IVG_G256_PAIR", "1")   # (read once per process: effective when this is the first gemm256 launch of the run)
+    M, N, K = 4900, 512, {"k_short": 64, "k_odd_steps": 96 + 64}.get(mode, 384)   # 2 / 5 / 12 K steps (two per barrier)
     dt = "bf16"
     X = q(torch.randn(M, K, generator=g), dt)
     W_ = q(torch.randn(N, K, generator=g) / K ** 0.5, dt)
