@@ -199,7 +199,7 @@ int launch_gemm256(const IgemmArgs& a, DType dtype, hipStream_t stream) {
   d.flags = a.flags;
   const int smem = 256 * G256_PITCH > G256_STAGES * G256_STAGE ? 256 * G256_PITCH : G256_STAGES * G256_STAGE;
   // IVG_G256_PAIR=1: two K steps per barrier -- measured, no change (rollout 147.3-147.9 ms either way, profiles/r02_gemm256_pair.txt)
-  static const bool pair = [] { const char* v = getenv("IVG_G256_PAIR"); return v && v[0] == '1'; }();
+  const bool pair = [] { const char* v = getenv("IVG_G256_PAIR"); return v && v[0] == '1'; }();   // (read per launch: the test flips it)
   static unsigned long long attr_set = 0;
   if (first_time_on_device(attr_set)) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

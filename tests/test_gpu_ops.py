@@ -442,7 +442,7 @@ def test_gemm256_large_dense(mode, monkeypatch):
     agreement is NOT required with the 128 x 128 kernel -- but both must sit inside the same bf16 tolerance."""
     g = torch.Generator().manual_seed(len(mode))
     if mode == "k_odd_steps":
-        monkeypatch.setenv("IVG_G256_PAIR", "1")   # (read once per process: effective when this is the first gemm256 launch of the run)
+        monkeypatch.setenv("IVG_G256_PAIR", "1")
     M, N, K = 4900, 512, {"k_short": 64, "k_odd_steps": 96 + 64}.get(mode, 384)   # 2 / 5 / 12 K steps (two per barrier)
     dt = "bf16"
     X = q(torch.randn(M, K, generator=g), dt)
