@@ -188,10 +188,11 @@ def test_npz_ingest_and_resize(tmp_path):
 
 
 def test_committed_bench_line_keeps_the_contract():
-    """profiles/r01_bench_n1.json is the line bench.py printed on the MI355X: it must carry every key of the driver's contract,
-    the roofline of the kernel with the most time per step (with PMC traffic) and the bounded host-CPU baseline."""
+    """profiles/r02_bench_n1.json is the line bench.py printed on the MI355X at the end of round 2: it must carry every key of the
+    driver's contract, the roofline of the kernel with the most time per step (with PMC traffic), the other measured kernel
+    classes incl. the decode GEMMs, the fp32-mode throughput and the bounded host-CPU baseline."""
     import json
-    path = os.path.join(ROOT, "profiles", "r01_bench_n1.json")
+    path = os.path.join(ROOT, "profiles", "r02_bench_n1.json")
     d = json.load(open(path))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -205,6 +206,9 @@ def test_committed_bench_line_keeps_the_contract():
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert r["traffic"] is None or r["traffic"] > 0
     assert all(o["kernel_ms_per_step"] <= r["kernel_ms_per_step"] for o in d.get("roofline_other", []))
+    assert any("dgemm" in o["kernel"] for o in d["roofline_other"]) and all(0 < o["frac"] <= 1 for o in d["roofline_other"])
+    assert d["fp32_mode"]["value"] > 0 and d["fp32_mode"]["value"] < d["value"] and len(d["per_rank_frames_per_s"]) == 1
+    assert sum(d["stage_ms"].values()) <= d["ms_per_step"] * 1.02
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
