@@ -9,10 +9,11 @@
 //     nine taps out of it (A traffic / 9, no im2col), double-buffered across channel chunks, the next chunk's halo
 //     arriving in pieces under the current chunk's taps,
 //   * streams the [BN][64 B] weight tile of each (tap, chunk) through a ring of three buffers, issued two steps ahead
-//     and retired by COUNTED s_waitcnt vmcnt(n) + raw s_barrier (the DMA queue is never drained inside the loop),
-//   * both by LDS-DMA (global_load_lds, 16 B/lane; out-of-image pixels source a zero page), 64-byte LDS rows with an
-//     XOR swizzle on the SOURCE chunk (conflict-free ds_read_b128 from any start row),
-//   * 72 KiB of LDS per workgroup -> TWO workgroups (16 waves) per CU: measured with cycle stamps, one workgroup per CU
+//     and retired by COUNTED s_waitcnt vmcnt(n) + raw s_barrier (the DMA queue is never drained inside the loop); the plain
+//     bf16 instances run TWO steps per barrier on a ring of two double slots requested one pair ahead,
+//   * both by LDS-DMA (global_load_lds, 16 B/lane; out-of-image pixels are never requested, their LDS slots are zeroed
+//     once), 64-byte LDS rows with an XOR swizzle on the SOURCE chunk (conflict-free ds_read_b128 from any start row),
+//   * 72-80 KiB of LDS per workgroup -> TWO workgroups (16 waves) per CU: measured with cycle stamps, one workgroup per CU
 //     spends 25 % of every step in the barrier and 22 % of its life in an un-overlapped prologue / epilogue; a second
 //     resident workgroup fills exactly those holes,
 //   * 8 waves (2 per SIMD), each a 64 x 64 (or 64 x 32) sub-tile of MFMA fragments, swapped operands so a lane owns
@@ -23,11 +24,13 @@
 //     arithmetic, all per lane and per step) kept the vector pipe busier than the matrix pipe (the fp32 instances, 2048 MFMA
 //     clocks per step, hid the same overhead and ran at 70-80 % of their peak).  Now the tile geometry is a template
 //     parameter and the nine taps are unrolled: every LDS fragment address is one per-lane base register (per kw, set up
-//     once) plus an immediate offset, the DMA source pointers are per-lane registers advanced by a per-lane increment, and the
-//     halo fragments of step s + 1 are read under the MFMAs of step s.
+//     once) plus an immediate offset, and every DMA source is a per-lane 32-bit offset (set up once) from a base the scalar
+//     unit advances.  Register allocation of this loop is tight (acc 64 + fragments 32 + ~10 addresses of 128): check
+//     `-Rpass-analysis=kernel-resource-usage` for spills after any change -- a reload shares the counter with the LDS-DMA
+//     queue and drains it.
 // Bytes per (tap, chunk) step: 8 KiB of weights + 1/9 of a ~24 KiB halo for 2.1 MFLOP -> ~195 FLOP/B (igemm: 64).
-#include <cstdio>
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 

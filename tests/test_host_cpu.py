@@ -229,3 +229,19 @@ def test_bench_launch_line_and_config_presets():
     assert c[3]["batch"] * 8 == 256 and c[3]["action_dim"] == 4 and c[3]["ctx"] == 1            # bair-64-act-cond, 256 over 8 GPUs
     assert c[4]["res"] == 256 and c[4]["batch"] == 16
     assert c[5]["medium"] and c[5]["batch"] * 8 == 512 and 257 * 2 - 1 + 17 * (c[5]["frames"] - 2) + 1 == 990   # 989-token sequences
+
+
+def test_lds_swizzle_keys_are_conflict_free_for_their_access_shapes():
+    """csrc/conv3x3.hip reads its LDS tiles with ds_read_b128 under two XOR keys; tools/lds_swizzle_check.py restates the bank
+    model of the microarchitecture guide.  The plain key serves 16 consecutive rows from any start row, the upsampling key both
+    pair alignments -- and neither serves the other's shape (which is why there are two)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import lds_swizzle_check as L
+    assert L.worst(L.key_plain) == (4, 4, 8)
+    assert L.worst(L.key_ups) == (8, 4, 4)
+    # the arithmetic form of the second column half of the 32-pixel-row upsampling fragments: address(hx + 8) = (address(hx) + 512) ^ 16
+    for hx in range(24):
+        for lg in range(4):
+            a = hx * 64 + ((lg ^ L.key_ups(hx)) << 4)
+            b = (hx + 8) * 64 + ((lg ^ L.key_ups(hx + 8)) << 4)
+            assert ((a + 512) ^ 16) == b
