@@ -306,7 +306,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
         if (tap < HI) { if (more) { issue_halo_piece(tap, chunk + 1, hb_next); issued += h_any[tap < HI ? tap : 0]; } }
       };
       (void)h_more;
-      if (early) issue_dma();
+      if (GNA || early) issue_dma();   // (the fused-GroupNorm instances issue at the top in every wave: one code path less, no spills)
       if constexpr (GNA) {
         if (more) {
           if (tap == 0) issued += load_coef(chunk + 1);
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
           if (tap >= 4 && tap - 4 < HI) transform_piece(chunk + 1, tap - 4, hb_next);
         }
       }
-      if (!early) issue_dma();
+      if (!GNA && !early) issue_dma();
       __builtin_amdgcn_sched_barrier(0);   // (as in the two-step loop: bounds the register pressure of the unrolled taps)
       Chunk16 wv[FN];
 #pragma unroll

@@ -109,14 +109,14 @@ int Run::gnorm(DType dt, const void* X, void* Y, int N, int P, int C, const Norm
   return 0;
 }
 
-// IVG_GN_APPLY_FUSE=1: GroupNorm + SiLU applied inside the conv3x3 input staging instead of a separate apply pass.  Parity-tested
-// (tests/test_gpu_ops.py::test_conv3x3_with_fused_input_groupnorm) but OFF by default: measured on MI355X at config 2 the in-LDS
-// normalisation (exp + divide per element, 4 waves per SIMD competing with the MFMA stream) costs the 3x3 kernels ~9 ms per step
-// and removes ~7 ms of gn_apply (decode stage 65.5 vs 63.0 ms, profiles/r02_eager_vs_graph_and_gn_fusion.txt)
-static bool gn_apply_fuse_enabled() {
-  static int v = -1;
-  if (v < 0) { const char* s = getenv("IVG_GN_APPLY_FUSE"); v = (s && s[0] == '1') ? 1 : 0; }
-  return v == 1;
+// GroupNorm + SiLU applied inside the conv3x3 input staging instead of a separate apply pass (the normalised tensor never exists
+// in HBM; tests/test_gpu_ops.py::test_conv3x3_with_fused_input_groupnorm).  With the round-1 conv3x3 loop, whose vector pipe was
+// already the busier one, this cost more than the apply pass it removed (decode 65.5 vs 63.0 ms,
+// profiles/r02_eager_vs_graph_and_gn_fusion.txt); with the rebuilt loop (2 vector instructions per step) it wins: 214.0 vs 216.2 ms
+// per step (encode -1.1, decode -1.0; profiles/r02_gn_apply_fusion_ab.txt).  IVG_GN_APPLY_FUSE=0: separate apply pass (A/B).
+static bool gn_apply_fuse_enabled() {   // (read per call: tests/test_gpu_models.py flips it)
+  const char* s = getenv("IVG_GN_APPLY_FUSE");
+  return !(s && s[0] == '0');
 }
 
 int Run::norm_conv(DType dt, const void* x, int N, int H, int W, const NormW& n, float eps, const GnStats* x_stats, const ConvW& c, void* Y,
