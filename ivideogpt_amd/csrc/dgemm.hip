@@ -31,6 +31,7 @@ struct DgDev {
   int* bump;
   int nburst;   // bursts of 8 * LG chunks per wave
   unsigned long long* prof; const int* pos; int prof_ld;
+  long long* dbg;   // development (tools/ubench/dgemm_phase.hip): per (workgroup, wave) phase stamps, null in production
 };
 
 // LDS-DMA with the address split the way the hardware takes it: wave-uniform 64-bit base (scalar registers, advanced per burst /
@@ -62,6 +63,10 @@ __global__ __launch_bounds__(WMAX * 64) void dgemm_kernel(const DgDev p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, waves = (int)blockDim.x >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform values stay in scalar registers
+  long long* dbg = p.dbg ? p.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + wave) * 16 : nullptr;
+  auto stamp = [&](int i) { if (dbg && lane == 0) dbg[i] = (long long)__builtin_readcyclecounter(); };
+  if (dbg && lane == 0) dbg[8] = (long long)wall_clock64();
+  stamp(0);
   const int lr = lane & 15, lg = lane >> 4;
   const int n_tile = blockIdx.x * 16 * FN, m_tile = blockIdx.y * 16 * MF;
   unsigned char* stage = smem + (size_t)wave * (LG * (MF + FN) * 2048);   // [LG][MF] activation tiles, then [LG][FN] weight tiles
@@ -136,12 +141,15 @@ __global__ __launch_bounds__(WMAX * 64) void dgemm_kernel(const DgDev p) {
         for (int h = 0; h < 2; ++h)
           dg_dma16_nt(W + (c0 + g * 8) * 16, woff[a][h], stage_w_lds + ((g * FN + a) * 2 + h) * 1024);
     }
+    if (burst == 0) stamp(1);
 #pragma unroll
     for (int g = 0; g < LG; ++g) {
       constexpr int PER = 2 * MF + 2 * FN;
       if (g == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LG - 1) * PER) : "memory");
       else if (g == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((LG > 1 ? LG - 2 : 0) * PER) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (burst == 0 && g == 0) stamp(2);
+      if (burst == p.nburst - 1 && g == LG - 1) stamp(3);
       Chunk16 xa[2][MF], wa[2][FN];
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
@@ -191,7 +199,9 @@ __global__ __launch_bounds__(WMAX * 64) void dgemm_kernel(const DgDev p) {
   }
 
   // ---- combine the waves' K slices (fixed order w = 0 .. waves-1); the combine area aliases the staging areas
+  stamp(4);
   __syncthreads();
+  stamp(5);
   f32x4* red = (f32x4*)smem;                                  // [waves][FN][MF][64 lanes]
   float* s_ss = (float*)(red + (size_t)waves * NFRAG * 64);   // [waves][MF * 16 rows]
 #pragma unroll
@@ -208,6 +218,7 @@ __global__ __launch_bounds__(WMAX * 64) void dgemm_kernel(const DgDev p) {
     }
   }
   __syncthreads();
+  stamp(6);
 
   const bool f32out = p.flags & IG_OUT_F32;
 #pragma unroll
@@ -275,6 +286,8 @@ __global__ __launch_bounds__(WMAX * 64) void dgemm_kernel(const DgDev p) {
       }
     }
   }
+  stamp(7);
+  if (dbg && lane == 0) dbg[9] = (long long)wall_clock64();
   if (p.prof && tid == 0) {
     unsigned long long* slot = p.prof + (size_t)((blockIdx.x * 7 + blockIdx.y) % IVG_GEMM_PROF_SLOTS) * 2 * p.prof_ld;
     atomicMax(slot + prof_pos, ~t_start);
@@ -401,6 +414,15 @@ int launch_dgemm(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
     nburst = (int)(chunks / ((long)waves * 8 * lgv));
     if (glu && FN < 2) return (int)hipErrorInvalidValue;
   }
+  // The wave count (the K partition) is a function of (K bytes, N) only; the register class that holds it bounds the fragments a
+  // workgroup may own (launch_dg_t: <= 4 waves any tile, <= 8 waves MF * FN <= 8, 16 waves MF * FN <= 2).  A tile the batch size
+  // asked for that does not fit is CLAMPED here -- never answered with -1: falling back to skinny.hip for some batch sizes only
+  // would give a trajectory a different K-summation order depending on its batch-mates (fp32 parity mode: M = 64 vs a 16-row shard).
+  if (!forced) {
+    const int allowed = waves <= 4 ? 16 : (waves <= 8 ? 8 : 2);
+    while (MF * FN > allowed && MF > 1) MF >>= 1;
+    while (MF * FN > allowed && FN > (glu ? 2 : 1)) FN >>= 1;
+  }
   // staging budget: waves * LG * (MF + FN) * 2 KiB of LDS.  Over budget: first more (shorter) bursts per wave -- the K partition over
   // the waves, and so every sum order, stays what it is -- then fewer row tiles per workgroup
   while (lgv > 1 && waves * lgv * (MF + FN) * 2048 > 160 * 1024) {
@@ -410,7 +432,7 @@ int launch_dgemm(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
     nburst = total / lgv;
   }
   while (MF > 1 && waves * lgv * (MF + FN) * 2048 > 160 * 1024) MF >>= 1;
-  DgDev d{a.X, a.W, a.Y, a.M, a.N, a.K, a.ldx, a.ldw, a.ldy, a.flags, a.eps, a.bump, nburst, a.pos ? a.prof : nullptr, a.pos, a.prof_ld};
+  DgDev d{a.X, a.W, a.Y, a.M, a.N, a.K, a.ldx, a.ldw, a.ldy, a.flags, a.eps, a.bump, nburst, a.pos ? a.prof : nullptr, a.pos, a.prof_ld, a.dbg};
   int rc;
   if (dtype == BF16) rc = lgv == 3 ? launch_dg_t<bf16_t, 3>(d, MF, FN, waves, stream) : lgv == 2 ? launch_dg_t<bf16_t, 2>(d, MF, FN, waves, stream)
                                                                                      : launch_dg_t<bf16_t, 1>(d, MF, FN, waves, stream);

@@ -108,6 +108,7 @@ struct ivg_engine {
   bool snap_valid = false;                  // emb_snap holds the inputs of positions [0, kv_len)
   bool ids_valid = false;                   // gen_buf ids hold the tokens of positions [0, kv_len)
   int last_act_T = 0;                       // rows per trajectory of last_act (0: the cache was built without actions)
+  int last_ctx = 0;                         // context length of the call that built the kept cache (action slot positions depend on it)
   int* h_flag = nullptr;                    // pinned host word for the verification result
   int attn_prof_B = 0;
   double attn_fit_fixed_us = 0, attn_fit_gbps = 0;   // line fit of the last ivg_profile_read(IVG_K_DECODE_ATTN)

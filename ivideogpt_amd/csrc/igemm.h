@@ -75,6 +75,7 @@ struct SkinnyArgs {
   unsigned long long* prof = nullptr;
   const int* pos = nullptr;
   int prof_ld = 0;
+  long long* dbg = nullptr;   // development: phase stamps of the second-generation kernel (tools/ubench/dgemm_phase.hip)
 };
 #define IVG_GEMM_PROF_SLOTS 8
 int launch_skinny(const SkinnyArgs& a, DType dtype, hipStream_t stream);

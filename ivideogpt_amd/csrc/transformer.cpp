@@ -421,6 +421,7 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
     e->kv_len = L0 + n_new - 1; e->kv_B = B;
     e->snap_valid = embeds != nullptr; e->ids_valid = embeds == nullptr;
     e->last_act_T = actions ? act_T : 0;
+    e->last_ctx = ctx;
   }
   return 0;
 }
@@ -441,13 +442,18 @@ int kv_prefix_matches_ids(ivg_engine* e, const int64_t* prompt, int64_t prompt_s
   size_t tot = 0;
   gen_layout(e, g, e->gen_buf, &tot);
   if (!e->ids_valid || e->kv_B != B || e->kv_len != L0 - 1 || B > g.Bc) return 0;
+  // the cache must have been built the same way: with / without actions, the same context length, the same action-table shape;
+  // whatever cannot be compared row for row is a mismatch, never a silent "ok"
+  if ((actions != nullptr) != (e->last_act_T > 0)) return 0;
+  if (ctx != e->last_ctx) return 0;
   if (actions && (e->last_act_T != act_T)) return 0;
   CK((int)hipMemsetAsync(g.flag, 0, sizeof(int), st));
   CK(launch_compare_rows(prompt, prompt_stride * 8, g.ids, (long)g.ids_ld * 8, B, (long)(L0 - 1) * 8, g.flag, st));
   if (actions) {   // the action rows already baked into the cached sdf slots: slot i (position 257*ctx - 1 + 17*i < kv_len) used row i + ctx - 1
     const int A = e->cfg.action_dim;
     const int slots = std::max(0, (e->kv_len - (257 * ctx - 1) + 16) / 17);
-    if (slots > 0 && ctx - 1 + slots <= act_T)
+    if (slots > 0 && ctx - 1 + slots > act_T) return 0;   // the cached slots used action rows the presented table does not have
+    if (slots > 0)
       CK(launch_compare_rows(actions + (long)(ctx - 1) * A, (long)act_T * A * 4, g.last_act + (long)(ctx - 1) * A, (long)act_T * A * 4, B,
                              (long)slots * A * 4, g.flag, st));
   }

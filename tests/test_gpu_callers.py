@@ -319,7 +319,7 @@ def test_kept_cache_is_verified_not_assumed():
 def test_config1_predict_cli_on_fractal_sample_full_width(tmp_path):
     """BASELINE config 1: ``predict.py`` on the reference's own sample episode (tests/golden/fractal_sample.npz, a data file
     of the reference: inference/samples/fractal_sample.npz) with ivideogpt-oxe-64-act-free shapes at FULL width (114 M tokenizer,
-    138 M transformer; seeded random weights, codebooks cut to 1024 entries to keep the CPU oracle's cdist quick), repeat_times 5,
+    138 M transformer with the real 16386-token vocabulary; seeded random weights), repeat_times 5,
     2 context + 14 predicted frames, fp32 -- tokens identical to the oracle fed the same uniforms, pixels within 1e-3; the clip
     the CLI fed the tokenizer is the one the REFERENCE's NPZParser produces (tests/golden/fractal_clip_seed0.npz)."""
     sys.path.insert(0, os.path.join(ROOT, "inference"))
@@ -327,9 +327,9 @@ def test_config1_predict_cli_on_fractal_sample_full_width(tmp_path):
     predict = importlib.import_module("predict")
     from oracle.llama import generate_cached
     from ivideogpt_amd import weights as W
-    tcfg = W.tokenizer_config(**W.CTX_VAE64)
-    tcfg["num_vq_embeddings"] = tcfg["num_dyn_embeddings"] = 1024
-    lcfg = dict(W.LLAMA_SMALL, vocab_size=2050)
+    tcfg = W.tokenizer_config(**W.CTX_VAE64)               # 8192 + 8192 codes
+    lcfg = dict(W.LLAMA_SMALL)                             # vocab 16386 = 8192 + 8192 + 2 (train_gpt.py:144-146)
+    assert lcfg["vocab_size"] == 16386
     tsd = W.random_tokenizer_state_dict(tcfg, 71, codebook_std=0.4)
     lsd = W.random_llama_state_dict(lcfg, 72)
     ck = str(tmp_path / "ckpt")
@@ -347,9 +347,13 @@ def test_config1_predict_cli_on_fractal_sample_full_width(tmp_path):
     u = torch.rand(5, 17 * 14 - 1, device=DEV).cpu()
     tok, llm = oracle_tokenizer(tcfg, tsd, 2), oracle_llama(lcfg, lsd)
     ids_ref, _ = tok.tokenize(clip[None], 2)
-    out_ref = generate_cached(llm, ids_ref[:, :514].repeat(5, 1), 17 * 14 - 1, top_k=100, uniforms=u)
-    from helpers import assert_sampled_rollout_matches
+    from helpers import assert_sampled_rollout_matches, vq_near_tie_audit
     toks = torch.from_numpy(saved["tokens"])
+    assert all(torch.equal(toks[r, :514], toks[0, :514]) for r in range(5))
+    hybrid = ids_ref.clone()
+    hybrid[:, :514] = toks[:1, :514]                       # the context tokens the CLI produced; SURVEY 7 (iii) near-tie audit at 8192 codes
+    vq_near_tie_audit(tok, clip[None], 2, hybrid, ids_ref, what="predict CLI, context tokens of fractal_sample.npz")
+    out_ref = generate_cached(llm, toks[:, :514], 17 * 14 - 1, top_k=100, uniforms=u)
     n_tie = assert_sampled_rollout_matches(toks, out_ref, llm, u, 100, 514, what="predict CLI on fractal_sample.npz")
     assert n_tie <= 1, f"{n_tie} of 5 rows diverged at a sampling near-tie"
     # pixels: the oracle decodes the tokens the engine produced (rows that left the oracle's path at a near-tie included)

@@ -1,0 +1,148 @@
+// Decode-layer GEMM chain with per-phase stamps (development aid, not part of libivg).  Build: make -C tools/ubench ; run on the GPU box.
+// Compiles the product's dgemm.hip into this binary and runs the five launches of a decode layer of the small / medium
+// transformer (q/k/v, an HBM streamer standing in for the decode attention, o-proj, gate/up, down) as a chain of `layers` layers,
+// eagerly on one stream, exactly as transformer.cpp issues them:
+//   * us per layer and per GEMM class (HIP events around the whole chain; per-class by leaving one class out);
+//   * with the kernel's development stamps on (SkinnyArgs::dbg): where a launch's time goes -- entry -> DMA issued -> first line
+//     group landed -> last group landed -> MFMAs done -> combine -> stores issued, per wave, min / median / max over the
+//     workgroups, plus the spread of the workgroups' start and end times on the 100 MHz wall clock.
+// Usage: dgemm_phase [small|medium] [M]      (env IVG_DG_FORCE etc. act as in the product)
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../ivideogpt_amd/csrc/dgemm.hip"
+
+#define CKH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+using namespace ivg;
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void stream_nt_kernel(const char* __restrict__ src, long bytes_per_wg, float* __restrict__ out) {
+  const char* base = src + (long)blockIdx.x * bytes_per_wg;
+  unsigned acc = 0;
+  for (long o = (long)threadIdx.x * 16; o < bytes_per_wg; o += 256L * 16 * 8) {
+    u32x4_t v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long oo = o + (long)u * 256 * 16;
+      v[u] = __builtin_nontemporal_load((const u32x4_t*)(base + (oo < bytes_per_wg ? oo : 0)));
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc ^= v[u][0] ^ v[u][3];
+  }
+  if (acc == 0x12345678u) out[blockIdx.x] = 1.f;
+}
+
+__global__ void fill_bf16(bf16_t* p, long n, unsigned seed, float scale) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    unsigned h = (unsigned)i * 2654435761u + seed;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    p[i] = (bf16_t)(((int)(h & 0xffff) - 32768) / 32768.0f * scale);
+  }
+}
+
+struct Layer { bf16_t *wqkv, *wo, *wgu, *wdown; };
+
+int main(int argc, char** argv) {
+  const bool medium = argc > 1 && !strcmp(argv[1], "medium");
+  const int M = argc > 2 ? atoi(argv[2]) : 64;
+  const int H = medium ? 1024 : 768, I = 4 * H, layers = medium ? 24 : 12;
+  CKH(hipSetDevice(0));
+  hipStream_t st;
+  CKH(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  auto alloc = [&](long n, unsigned seed, float scale) {
+    bf16_t* p; CKH(hipMalloc((void**)&p, n * 2));
+    hipLaunchKernelGGL(fill_bf16, dim3(1024), dim3(256), 0, st, p, n, seed, scale);
+    return p;
+  };
+  std::vector<Layer> L(layers);
+  for (int l = 0; l < layers; ++l)
+    L[l] = Layer{alloc(3L * H * H, 11 + l, 0.03f), alloc((long)H * H, 211 + l, 0.03f), alloc(2L * I * H, 411 + l, 0.03f), alloc((long)H * I, 611 + l, 0.02f)};
+  bf16_t* x = alloc((long)128 * H, 1, 1.0f);
+  bf16_t* qkv = alloc((long)128 * 3 * H, 2, 1.0f);
+  bf16_t* attn = alloc((long)128 * H, 3, 1.0f);
+  bf16_t* act = alloc((long)128 * I, 4, 1.0f);
+  const int heads = H / 64;
+  const long kv_per_wg = 2L * 632 * 64 * 2;           // K and V rows of one (trajectory, head) at the mean cache length of config 2
+  const int G = M * heads;
+  const int kv_slots = 16;
+  char* kvbuf; CKH(hipMalloc((void**)&kvbuf, (size_t)kv_slots * G * kv_per_wg)); CKH(hipMemsetAsync(kvbuf, 1, (size_t)kv_slots * G * kv_per_wg, st));
+  float* sink; CKH(hipMalloc((void**)&sink, 1 << 20));
+  const size_t dbg_per = (size_t)1024 * 16 * 16;       // workgroups x waves x stamps
+  long long* dbg; CKH(hipMalloc((void**)&dbg, 4 * dbg_per * 8)); CKH(hipMemsetAsync(dbg, 0, 4 * dbg_per * 8, st));
+  CKH(hipStreamSynchronize(st));
+
+  auto gemm = [&](int which, const Layer& w, long long* d) {
+    SkinnyArgs s;
+    s.M = M; s.eps = 1e-6f; s.dbg = d;
+    if (which == 0) { s.X = x; s.W = w.wqkv; s.Y = qkv; s.N = 3 * H; s.K = H; s.ldx = H; s.ldw = H; s.ldy = 3 * H; s.flags = SK_NORM; }
+    if (which == 1) { s.X = attn; s.W = w.wo; s.Y = x; s.N = H; s.K = H; s.ldx = H; s.ldw = H; s.ldy = H; s.flags = IG_RESIDUAL; }
+    if (which == 2) { s.X = x; s.W = w.wgu; s.Y = act; s.N = 2 * I; s.K = H; s.ldx = H; s.ldw = H; s.ldy = I; s.flags = IG_GLU | SK_NORM; }
+    if (which == 3) { s.X = act; s.W = w.wdown; s.Y = x; s.N = H; s.K = I; s.ldx = I; s.ldw = I; s.ldy = H; s.flags = IG_RESIDUAL; }
+    const int rc = launch_dgemm(s, BF16, st);
+    if (rc != 0) { fprintf(stderr, "launch_dgemm(%d) -> %d\n", which, rc); exit(1); }
+  };
+  int rot = 0;
+  auto layer = [&](int l, unsigned mask, bool stream, long long* d) {
+    if (mask & 1) gemm(0, L[l], d ? d + 0 * dbg_per : nullptr);
+    if (stream) hipLaunchKernelGGL(stream_nt_kernel, dim3(G), dim3(256), 0, st, kvbuf + (size_t)(rot++ % kv_slots) * G * kv_per_wg, kv_per_wg, sink);
+    if (mask & 2) gemm(1, L[l], d ? d + 1 * dbg_per : nullptr);
+    if (mask & 4) gemm(2, L[l], d ? d + 2 * dbg_per : nullptr);
+    if (mask & 8) gemm(3, L[l], d ? d + 3 * dbg_per : nullptr);
+  };
+  hipEvent_t e0, e1; CKH(hipEventCreate(&e0)); CKH(hipEventCreate(&e1));
+  auto time_chain = [&](unsigned mask, bool stream, int steps) {
+    for (int l = 0; l < layers; ++l) layer(l, mask, stream, nullptr);   // warm-up (attributes, code upload)
+    CKH(hipStreamSynchronize(st));
+    std::vector<float> t;
+    for (int rep = 0; rep < 5; ++rep) {
+      CKH(hipEventRecord(e0, st));
+      for (int s = 0; s < steps; ++s) for (int l = 0; l < layers; ++l) layer(l, mask, stream, nullptr);
+      CKH(hipEventRecord(e1, st)); CKH(hipStreamSynchronize(st));
+      float ms; CKH(hipEventElapsedTime(&ms, e0, e1)); t.push_back(ms * 1e3f / (steps * layers));
+    }
+    std::sort(t.begin(), t.end());
+    return t[t.size() / 2];
+  };
+  const char* names[4] = {"q/k/v", "o-proj", "gate/up", "down"};
+  const float all_s = time_chain(15, true, 8), all = time_chain(15, false, 8), str = time_chain(0, true, 8);
+  printf("%s transformer, M = %d: layer chain %.2f us (4 GEMMs + streamer), streamer alone %.2f, 4 GEMMs alone %.2f us per layer\n",
+         medium ? "medium" : "small", M, all_s, str, all);
+  for (int k = 0; k < 4; ++k) {
+    const float without = time_chain(15 & ~(1u << k), true, 8);
+    printf("  %-8s %.2f us per launch inside the chain (chain without it %.2f)\n", names[k], all_s - without, without);
+  }
+  // ---- phase stamps of the last layer of a chain
+  for (int s = 0; s < 3; ++s) for (int l = 0; l < layers; ++l) layer(l, 15, true, l == layers - 1 && s == 2 ? dbg : nullptr);
+  CKH(hipStreamSynchronize(st));
+  std::vector<long long> h(4 * dbg_per);
+  CKH(hipMemcpy(h.data(), dbg, 4 * dbg_per * 8, hipMemcpyDeviceToHost));
+  const char* ph[8] = {"entry", "dma issued", "first group", "last group", "mfma done", "barrier 1", "barrier 2", "stores issued"};
+  for (int k = 0; k < 4; ++k) {
+    const long long* d = h.data() + k * dbg_per;
+    std::vector<int> wgs;
+    int maxw = 0;
+    for (int wg = 0; wg < 1024; ++wg) if (d[((size_t)wg * 16) * 16 + 8] != 0) { wgs.push_back(wg); for (int w = 0; w < 16; ++w) if (d[((size_t)wg * 16 + w) * 16 + 8] != 0) maxw = std::max(maxw, w + 1); }
+    if (wgs.empty()) { printf("%s: no stamps\n", names[k]); continue; }
+    long long w0 = 1LL << 62, w1 = 0, s_last = 0, e_first = 1LL << 62;
+    for (int wg : wgs) for (int w = 0; w < maxw; ++w) {
+      const long long* r = d + ((size_t)wg * 16 + w) * 16;
+      w0 = std::min(w0, r[8]); w1 = std::max(w1, r[9]); s_last = std::max(s_last, r[8]); e_first = std::min(e_first, r[9]);
+    }
+    printf("%s: %zu workgroups x %d waves; launch window %.2f us (first start -> last end), starts spread %.2f us, ends spread %.2f us\n", names[k], wgs.size(),
+           maxw, (w1 - w0) * 0.01, (s_last - w0) * 0.01, (w1 - e_first) * 0.01);
+    printf("    cycles from the wave's entry (min / median / max over workgroups and waves):\n");
+    for (int i = 1; i < 8; ++i) {
+      std::vector<long long> v;
+      for (int wg : wgs) for (int w = 0; w < maxw; ++w) { const long long* r = d + ((size_t)wg * 16 + w) * 16; if (r[i] && r[0]) v.push_back(r[i] - r[0]); }
+      if (v.empty()) continue;
+      std::sort(v.begin(), v.end());
+      printf("      %-14s %7lld %7lld %7lld\n", ph[i], v.front(), v[v.size() / 2], v.back());
+    }
+  }
+  return 0;
+}
