@@ -318,8 +318,17 @@ def main():
     ev[2].record()
     tok.detokenize(toks, ctx).clamp_(0, 1)
     ev[3].record()
+    # not part of a prediction step: the eval path's full-clip tokenize (train_gpt.py:356: context encoder on the ctx frames +
+    # CONDITIONAL encoder with cross-attention on all F future frames of every trajectory, SURVEY.md rows a1 / a3 at batch)
+    tok.tokenize(pixels, ctx)   # warm-up (workspace plan)
+    ev_t = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev_t[0].record()
+    tok.tokenize(pixels, ctx)
+    ev_t[1].record()
     torch.cuda.synchronize()
-    stage = {"encode_ms": ev[0].elapsed_time(ev[1]), "rollout_ms": ev[1].elapsed_time(ev[2]), "decode_ms": ev[2].elapsed_time(ev[3])}
+    stage = {"encode_ms": ev[0].elapsed_time(ev[1]), "rollout_ms": ev[1].elapsed_time(ev[2]), "decode_ms": ev[2].elapsed_time(ev[3]),
+             "tokenize_full_ms": ev_t[0].elapsed_time(ev_t[1]),
+             "tokenize_full_note": f"full-clip tokenize of {B} x {T} frames (eval path, outside the timed step): {B * T / max(ev_t[0].elapsed_time(ev_t[1]), 1e-9) * 1e3:.0f} frames/s"}
 
     fp32_mode = None
     if world == 1 and not a.no_fp32_mode and (a.decode_dtype, a.llm_dtype) != ("fp32", "fp32"):

@@ -217,11 +217,15 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(const bf16_t* __rest
 #pragma unroll
   for (int d = 0; d < 4; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m = -INFINITY, lsum = 0.f;
-  // The four waves of the workgroup need the same 64-key tile of K and V^T: it is staged once in LDS (rows of 128 + 16
-  // bytes: 16 consecutive rows hit 16 distinct bank groups) instead of being pulled from L2 by every wave, and the next
-  // tile travels from global memory into registers while the current one is consumed.
-  constexpr int PITCH = HD + 8;
-  __shared__ __attribute__((aligned(16))) bf16_t sK[64 * PITCH];
+  // The four waves of the workgroup need the same 64-key tile of K and V^T: it is staged once in LDS instead of being pulled
+  // from L2 by every wave, and the next tile travels from global memory into registers while the current one is consumed.
+  // Row pitches per access shape (bank model of MI355X_MICROARCH.md, tools/lds_swizzle_check.py): the K rows are read back as
+  // 16-byte MFMA fragments (ds_read_b128: 4 groups of 16 lanes) -- a pad of 32 bytes is conflict-free, the 16 bytes of round 2
+  // cost every read a second LDS cycle (PMC: 41 % bank-conflict cycles); the V^T rows are read as 8-byte halves (ds_read_b64:
+  // 2 groups of 32 lanes), conflict-free at 16 bytes of pad.
+  constexpr int PITCH = HD + 8;       // V^T rows
+  constexpr int PITCHK = HD + 16;     // K rows
+  __shared__ __attribute__((aligned(16))) bf16_t sK[64 * PITCHK];
   __shared__ __attribute__((aligned(16))) bf16_t sV[64 * PITCH];
   const int srow0 = tid >> 3, scol = (tid & 7) * 8;   // this thread stages chunks (srow0, scol) and (srow0 + 32, scol)
   Chunk16 pk[2], pv[2];
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(const bf16_t* __rest
     __syncthreads();   // every wave is done with the previous tile
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      *(Chunk16*)(sK + (srow0 + i * 32) * PITCH + scol) = pk[i];
+      *(Chunk16*)(sK + (srow0 + i * 32) * PITCHK + scol) = pk[i];
       *(Chunk16*)(sV + (srow0 + i * 32) * PITCH + scol) = pv[i];
     }
     __syncthreads();
@@ -249,7 +253,7 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(const bf16_t* __rest
     bf16x8 kf[4][2];
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
-      const bf16_t* krow = sK + (sub * 16 + lr) * PITCH;
+      const bf16_t* krow = sK + (sub * 16 + lr) * PITCHK;
       kf[sub][0] = *(const bf16x8*)(krow + lg * 8);
       kf[sub][1] = *(const bf16x8*)(krow + 32 + lg * 8);
     }
@@ -354,8 +358,9 @@ __global__ __launch_bounds__(256) void xattn_kernel(const bf16_t* __restrict__ q
 #pragma unroll
   for (int d = 0; d < DO; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
   float mx = -INFINITY, lsum = 0.f;
-  constexpr int PK = HD + 8;    // staged K row (elements): 16 consecutive rows start in 16 distinct bank groups
-  constexpr int PV = 64 + 8;    // staged V^T row
+  constexpr int PK = HD + 16;   // staged K row (elements), read back as 16-byte fragments: 32 bytes of pad are conflict-free for
+                                // ds_read_b128's lane groups (16 bytes cost every read a second cycle: 42 % conflict cycles in round 2)
+  constexpr int PV = 64 + 8;    // staged V^T row, read as 8-byte halves: conflict-free at 16 bytes of pad
   __shared__ __attribute__((aligned(16))) bf16_t sK[64 * PK];
   __shared__ __attribute__((aligned(16))) bf16_t sV[HD * PV];
   constexpr int KC = 64 * HD / 8 / 256;   // 16-byte chunks of the K tile per thread

@@ -279,8 +279,11 @@ int launch_skinny(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
   const bool glu = a.flags & IG_GLU;
   if (glu && (a.N % 32 != 0 || d.splits != 1)) return (int)hipErrorInvalidValue;
   if ((a.flags & (SK_NORM | IG_RESIDUAL)) && d.splits != 1) return (int)hipErrorInvalidValue;
-  {  // second-generation kernel (dgemm.hip: activations as whole lines through LDS) wherever it covers the shape
-    const int rc = launch_dgemm(a, dtype, stream);
+  {  // third-generation kernel (dgemm3.hip), then the second (dgemm.hip), wherever they cover the shape -- coverage is a function
+     // of (K, N, dtype, flags) only, so a GEMM of the model always runs on the same kernel whatever the batch
+    int rc = launch_dgemm3(a, dtype, stream);
+    if (rc != -1) return rc;
+    rc = launch_dgemm(a, dtype, stream);
     if (rc != -1) return rc;
   }
   int MF, FN;

@@ -221,33 +221,53 @@ static int step_chain(ivg_engine* e, hipStream_t st, const GenBuf& g, int chain,
     if (!e->gemm_prof_on || !e->gemm_prof) return;
     a.prof = e->gemm_prof + (size_t)idx * gp_ld; a.pos = (const int*)state; a.prof_ld = e->Lmax;
   };
-  for (int l = 0; l < c.num_layers; ++l) {
+  // every launch also pulls the weight tiles of the NEXT launch of the chain into the XCD-local L2s (dgemm3.hip): the dependent
+  // GEMM then starts on L2 hits instead of a cold HBM stream
+  auto link_next = [&](SkinnyArgs& cur, const SkinnyArgs& nxt) {
+    const int rows = dgemm3_w_rows_per_block(nxt, dt);
+    if (rows <= 0 || nxt.ldw != nxt.K) return;
+    cur.next_W = nxt.W; cur.next_tile_bytes = (long)rows * nxt.K * (long)es; cur.next_tiles = nxt.N / rows;
+  };
+  auto layer_args = [&](int l, SkinnyArgs* g) {
     const LayerW& w = e->layers[l];
-    SkinnyArgs s;
+    SkinnyArgs& s = g[0];
     s.X = x; s.W = w.wqkv; s.Y = qkv; s.M = B; s.N = 3 * H; s.K = H; s.ldx = H; s.ldw = H; s.ldy = 3 * H;
     s.flags = SK_NORM; s.eps = c.rms_norm_eps;
-    gprof(s, 4 * l + 0);
-    CK(launch_skinny(s, dt, st));
-    CK(launch_decode_attn(qkv, kc_ptr(e, l, 0) + kv_off, kc_ptr(e, l, 1) + kv_off, attn, e->rope_cos, e->rope_sin, B, e->heads, e->hd,
-                          e->Lmax, state, e->attn_prof_on ? e->attn_prof + (size_t)l * IVG_ATTN_PROF_SLOTS * 2 * e->Lmax : nullptr, dt, st));
-    SkinnyArgs o;
+    SkinnyArgs& o = g[1];
     o.X = attn; o.W = w.wo; o.Y = x; o.M = B; o.N = H; o.K = H; o.ldx = H; o.ldw = H; o.ldy = H; o.flags = IG_RESIDUAL;
-    gprof(o, 4 * l + 1);
-    CK(launch_skinny(o, dt, st));
-    SkinnyArgs u;
+    SkinnyArgs& u = g[2];
     u.X = x; u.W = w.wgu; u.Y = act; u.M = B; u.N = 2 * I; u.K = H; u.ldx = H; u.ldw = H; u.ldy = I;
     u.flags = IG_GLU | SK_NORM; u.eps = c.rms_norm_eps;
-    gprof(u, 4 * l + 2);
-    CK(launch_skinny(u, dt, st));
-    SkinnyArgs d;
+    SkinnyArgs& d = g[3];
     d.X = act; d.W = w.wdown; d.Y = x; d.M = B; d.N = H; d.K = I; d.ldx = I; d.ldw = I; d.ldy = H; d.flags = IG_RESIDUAL;
-    gprof(d, 4 * l + 3);
-    CK(launch_skinny(d, dt, st));
-  }
+  };
   SkinnyArgs lm;
   lm.X = x; lm.W = e->lm_head; lm.Y = logits; lm.M = B; lm.N = V; lm.K = H; lm.ldx = H; lm.ldw = H; lm.ldy = V;
   lm.flags = IG_OUT_F32 | SK_NORM; lm.eps = c.rms_norm_eps;
   lm.bump = (int*)state;  // pos += 1, j += 1 once the last reader of this chain's state (its last attention) is done
+  SkinnyArgs cur[4], nxt[4];
+  layer_args(0, cur);
+  for (int l = 0; l < c.num_layers; ++l) {
+    const bool last = l + 1 == c.num_layers;
+    if (!last) layer_args(l + 1, nxt);
+    link_next(cur[0], cur[1]); link_next(cur[1], cur[2]); link_next(cur[2], cur[3]); link_next(cur[3], last ? lm : nxt[0]);
+    gprof(cur[0], 4 * l + 0);
+    CK(launch_skinny(cur[0], dt, st));
+    CK(launch_decode_attn(qkv, kc_ptr(e, l, 0) + kv_off, kc_ptr(e, l, 1) + kv_off, attn, e->rope_cos, e->rope_sin, B, e->heads, e->hd,
+                          e->Lmax, state, e->attn_prof_on ? e->attn_prof + (size_t)l * IVG_ATTN_PROF_SLOTS * 2 * e->Lmax : nullptr, dt, st));
+    gprof(cur[1], 4 * l + 1);
+    CK(launch_skinny(cur[1], dt, st));
+    gprof(cur[2], 4 * l + 2);
+    CK(launch_skinny(cur[2], dt, st));
+    gprof(cur[3], 4 * l + 3);
+    CK(launch_skinny(cur[3], dt, st));
+    if (!last) for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
+  }
+  {   // the first GEMM of the next step's chain: q/k/v of layer 0
+    SkinnyArgs first[4];
+    layer_args(0, first);
+    link_next(lm, first[0]);
+  }
   gprof(lm, 4 * c.num_layers);
   CK(launch_skinny(lm, dt, st));
   return 0;

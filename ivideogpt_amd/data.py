@@ -104,8 +104,8 @@ class NPZParser:
         window = pick_window(len(rgb), self.segment_length, frame_stride(dataset_name))
         if self.device is not None:
             frames = ingest_frames(torch.from_numpy(np.ascontiguousarray(rgb[window])).to(self.device), self.image_size)
-            actions = torch.from_numpy(np.asarray(episode["action"][window])).float() if load_action else None
-            return frames, actions
+            actions = torch.from_numpy(np.asarray(episode["action"][window])).float().to(self.device) if load_action else None
+            return frames, actions      # both on self.device
         frames = torch.from_numpy(np.ascontiguousarray(rgb[window])).float().permute(0, 3, 1, 2)   # T,H,W,C -> T,C,H,W
         frames = resize_frames(frames / 255, self.image_size)
         actions = torch.from_numpy(np.asarray(episode["action"][window])).float() if load_action else None

@@ -32,10 +32,28 @@ def frame_metric_rows(video_gt, video_pred, gt_t0=0, pred_t0=0, frames=None):
 
 
 class Evaluator:
-    """``Evaluator(video_1, video_2)`` of the reference's eval loop (train_gpt.py:469-472) -> (mse, psnr, ssim) scalars: the mean
-    over trajectories of the best-of-t rows (LPIPS and FVD need network weights that do not ship: not provided)."""
+    """``Evaluator(video_1, video_2)`` of the reference's eval loop (train_gpt.py:469-472; ivideogpt/utils/video_metric.py:63-100):
+    video_1 = ground truth (B, T, 3, H, W), video_2 = predictions (t * B, T, 3, H, W), sample k of trajectory b at row k * B + b.
+    -> ``(mse, psnr, ssim, lpips)`` scalars like the reference's 4-tuple: per-frame metrics, mean over a trajectory's frames, best of
+    its t samples (min mse, max psnr / ssim), mean over trajectories -- computed by libivg ``ivg_frame_metrics``.  ``lpips`` is NaN:
+    LPIPS (and FVD) need network weights that do not ship with the reference (out of scope); a caller that
+    unpacks four values keeps working and sees an explicit not-a-number instead of a silently missing metric.
+    ``rows(video_1, video_2)`` returns the per-trajectory (B, 3) rows -- the payload of the multi-GPU all-gather."""
+
+    def __init__(self, i3d_path=None, max_batchsize=None):
+        self.i3d_path, self.max_batchsize = i3d_path, max_batchsize     # accepted for signature compatibility; FVD is out of scope
+
+    def rows(self, video_1, video_2):
+        return frame_metric_rows(video_1, video_2)
 
     def __call__(self, video_1, video_2):
-        rows = frame_metric_rows(video_1, video_2)
-        m = rows.mean(0)
-        return m[0], m[1], m[2]
+        m = self.rows(video_1, video_2).mean(0)
+        return m[0], m[1], m[2], torch.full((), float("nan"), device=m.device)
+
+    forward = __call__
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self

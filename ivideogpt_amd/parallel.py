@@ -13,7 +13,7 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("IVG_FORCE_COLLECTIVE") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -53,9 +53,12 @@ def gather_metric_rows(local_rows, total_rows=None):
     return rows
 
 
-def gather_metric_rows_even(local_rows):
-    """Fast path when every rank holds the same number of rows: one ncclAllGather of [B_local, n_metrics]."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+def gather_metric_rows_even(local_rows, force_collective=False):
+    """Fast path when every rank holds the same number of rows: one ncclAllGather of [B_local, n_metrics].
+    ``force_collective`` (or IVG_FORCE_COLLECTIVE=1): issue the collective even in a 1-rank group -- how a single-GPU lease
+    exercises the RCCL path the N-GPU run takes."""
+    force = force_collective or os.environ.get("IVG_FORCE_COLLECTIVE") == "1"
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return local_rows
     out = local_rows.new_empty(dist.get_world_size() * local_rows.shape[0], *local_rows.shape[1:])
     dist.all_gather_into_tensor(out, local_rows.contiguous())
@@ -67,9 +70,58 @@ def barrier():
         dist.barrier()
 
 
-def max_over_ranks(value, device):
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+def max_over_ranks(value, device, force_collective=False):
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force_collective):
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+class LocalAccelerator:
+    """The slice of HF ``accelerate.Accelerator`` the reference's eval loop uses (train_gpt.py:321-512: ``device``,
+    ``num_processes``, ``is_main_process``, ``is_local_main_process``, ``gather``, ``unwrap_model``, ``log``,
+    ``wait_for_everyone``) over ``torch.distributed`` -- backend "nccl" (RCCL over xGMI) on the GPUs, "gloo" in the CPU tests.
+    ``force_collective=True`` issues the collectives even in a 1-rank group (how a single-GPU lease exercises the RCCL path)."""
+
+    def __init__(self, device=None, force_collective=None):
+        self.device = torch.device(device) if device is not None else torch.device("cpu")
+        self.force_collective = os.environ.get("IVG_FORCE_COLLECTIVE") == "1" if force_collective is None else force_collective
+        self.logged = []
+
+    @property
+    def num_processes(self):
+        return dist.get_world_size() if dist.is_initialized() else 1
+
+    @property
+    def process_index(self):
+        return dist.get_rank() if dist.is_initialized() else 0
+
+    @property
+    def is_main_process(self):
+        return self.process_index == 0
+
+    @property
+    def is_local_main_process(self):
+        return int(os.environ.get("LOCAL_RANK", "0")) == 0
+
+    def gather(self, tensor):
+        """Concatenation over ranks along dim 0, on every rank (``accelerator.gather``; equal shapes on all ranks)."""
+        if not dist.is_initialized() or (dist.get_world_size() == 1 and not self.force_collective):
+            return tensor
+        t = tensor.contiguous()
+        if t.dim() == 0:
+            t = t[None]
+        out = t.new_empty(dist.get_world_size() * t.shape[0], *t.shape[1:])
+        dist.all_gather_into_tensor(out, t)
+        return out
+
+    def unwrap_model(self, model):
+        return getattr(model, "module", model)
+
+    def wait_for_everyone(self):
+        if dist.is_initialized() and (dist.get_world_size() > 1 or self.force_collective):
+            dist.barrier()
+
+    def log(self, values, step=None):
+        self.logged.append((step, dict(values)))

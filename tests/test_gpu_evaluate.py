@@ -1,0 +1,102 @@
+"""``train_gpt.evaluate`` (mirror of /root/reference/train_gpt.py:152-195,321-512) on the MI355X engine against the same loop over
+the CPU oracle (fp32 engine mode, t = 2 samples per trajectory, B = 3, chunked generation and decoding), the RCCL collectives on
+one GPU, and the eval CLI."""
+import math
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from helpers import oracle_llama, oracle_tokenizer
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+TOK_CFG = dict(block_out_channels=(64, 128, 128), layers_per_block=1, latent_channels=64, num_vq_embeddings=512, num_dyn_embeddings=512,
+               norm_num_groups=32, mid_block_add_attention=False, context_length=2, resolution=64, max_att_resolution=16)
+LLM_CFG = dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=2, rms_norm_eps=1e-6,
+               rope_theta=10000.0, max_position_embeddings=1024, vocab_size=1026)
+
+
+def test_evaluate_matches_the_oracle_loop():
+    import train_gpt
+    from eval_standins import OracleEvaluator, OracleLM
+    from ivideogpt_amd import CompressiveVQModel, LlamaForCausalLM, weights as W
+    from ivideogpt_amd.metrics import Evaluator
+    from ivideogpt_amd.parallel import LocalAccelerator
+    tcfg = W.tokenizer_config(**TOK_CFG)
+    tsd = W.random_tokenizer_state_dict(tcfg, 81, codebook_std=0.4)
+    lsd = W.random_llama_state_dict(LLM_CFG, 82)
+    g = torch.Generator().manual_seed(83)
+    T, ctx, B, t = 5, 2, 3, 2
+    batches = [torch.rand(B, T, 3, 64, 64, generator=g) for _ in range(2)]
+    args = train_gpt.eval_args(context_length=ctx, segment_length=T, eval_generate_times=t, max_generate_batchsize=B, max_decode_batchsize=4,
+                               log_gif_interval=1000)
+    n_new = 17 * (T - ctx) - 1
+    # the engine draws its uniforms with torch.rand on the GPU, one call per generate: replay the same stream for the oracle
+    torch.manual_seed(1234)
+    draws = [torch.rand(B, n_new, device=DEV).cpu() for _ in range(len(batches) * t)]
+    tok = CompressiveVQModel(tcfg, tsd, encode_dtype="fp32", decode_dtype="fp32").to(DEV)
+    llm = LlamaForCausalLM(dict(LLM_CFG), lsd, dtype="fp32").to(DEV)
+    torch.manual_seed(1234)
+    acc = LocalAccelerator(DEV)
+    logs = train_gpt.evaluate(args, acc, tok, llm, batches, Evaluator(), 7)
+    assert acc.logged and acc.logged[0][0] == 7
+    it = iter(draws)
+    ref = train_gpt.evaluate(args, LocalAccelerator("cpu"), oracle_tokenizer(tcfg, tsd, ctx), OracleLM(oracle_llama(LLM_CFG, lsd), lambda b, n: next(it)),
+                             batches, OracleEvaluator(), 7)
+    print("engine", logs, "\noracle", ref)
+    assert abs(logs["eval/eval_loss"] - ref["eval/eval_loss"]) < 1e-3
+    assert abs(logs["eval/perplexity"] - ref["eval/perplexity"]) < 2e-3 * ref["eval/perplexity"]
+    assert abs(logs["eval/mse"] - ref["eval/mse"]) < 1e-4 and abs(logs["eval/psnr"] - ref["eval/psnr"]) < 2e-2
+    assert abs(logs["eval/ssim"] - ref["eval/ssim"]) < 1e-3
+    assert math.isnan(logs["eval/lpips"])
+
+
+def test_rccl_collectives_on_one_gpu():
+    """The RCCL path of the multi-GPU run, with what a 1-GPU lease allows: ``nccl`` backend initialised through
+    ``parallel.init_from_env`` with WORLD_SIZE = 1, ``all_gather_into_tensor`` of the [B, 3] metric rows, ``all_reduce(MAX)``,
+    ``barrier``, teardown -- in a subprocess (a process group cannot be re-initialised inside the pytest process)."""
+    code = r"""
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+os.environ["IVG_FORCE_COLLECTIVE"] = "1"
+from ivideogpt_amd import parallel
+import torch.distributed as dist
+rank, world, local = parallel.init_from_env("nccl")
+assert dist.is_initialized() and dist.get_backend() == "nccl" and world == 1
+dev = torch.device("cuda", local)
+rows = torch.arange(64 * 3, dtype=torch.float32, device=dev).view(64, 3)
+out = parallel.gather_metric_rows_even(rows)                      # ncclAllGather through RCCL
+assert out.data_ptr() != rows.data_ptr() and torch.equal(out, rows)
+acc = parallel.LocalAccelerator(dev, force_collective=True)
+assert torch.equal(acc.gather(rows[:, 0]), rows[:, 0])
+assert parallel.max_over_ranks(3.5, dev, force_collective=True) == 3.5   # ncclAllReduce(MAX)
+acc.wait_for_everyone()
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print("RCCL-OK", torch.cuda.get_device_name(0))
+"""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(24000 + os.getpid() % 4000),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", code, ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "RCCL-OK" in p.stdout, p.stdout + p.stderr
+
+
+def test_eval_cli_runs_full_width_with_forced_collectives():
+    """``python train_gpt.py`` (seeded random weights, ivideogpt-oxe-64-act-free shapes, bf16): 2 batches of 4 clips, 2 samples each,
+    gathers issued through RCCL (IVG_FORCE_COLLECTIVE=1, 1 rank)."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(25000 + os.getpid() % 4000),
+               IVG_FORCE_COLLECTIVE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "train_gpt.py"), "--batch", "4", "--iters", "2", "--segment_length", "6",
+                        "--eval_generate_times", "2", "--max_generate_batchsize", "4", "--max_decode_batchsize", "6"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout + p.stderr
+    import json
+    logs = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert math.isfinite(logs["eval/eval_loss"]) and 0 < logs["eval/ssim"] <= 1 and logs["eval/psnr"] > 0

@@ -386,18 +386,21 @@ DECODE_SHAPES = [  # (K, N, flags): every decode-step GEMM of the small (768 / 3
 ]
 
 
-@pytest.mark.parametrize("gen", ["gen2", "gen1"])
+@pytest.mark.parametrize("gen", ["gen3", "gen2", "gen1"])
 @pytest.mark.parametrize("dt", ["bf16", "fp32"])
 @pytest.mark.parametrize("K,N,mode", DECODE_SHAPES)
 def test_decode_gemm_model_shapes(K, N, mode, dt, gen, monkeypatch):
     """The decode-step GEMMs at the shapes the rollouts run (BASELINE configs 2 and 5), with their fused epilogues -- RMSNorm row
-    scale, in-place residual, SiLU(gate) * up, fp32 logits -- against fp64, for the second-generation kernel (dgemm.hip:
-    activations as whole lines through LDS) and the first-generation one (IVG_DG=0, skinny.hip)."""
+    scale, in-place residual, SiLU(gate) * up, fp32 logits -- against fp64, for the third-generation kernel (dgemm3.hip: K over up
+    to 16 waves, one barrier; the default), the second (IVG_DG3=0, dgemm.hip: activations as whole lines through LDS) and the
+    first (IVG_DG=0, skinny.hip)."""
     L, l = lib()
+    monkeypatch.delenv("IVG_DG", raising=False)
+    monkeypatch.delenv("IVG_DG3", raising=False)
+    if gen in ("gen2", "gen1"):
+        monkeypatch.setenv("IVG_DG3", "0")
     if gen == "gen1":
         monkeypatch.setenv("IVG_DG", "0")
-    else:
-        monkeypatch.delenv("IVG_DG", raising=False)
     g = torch.Generator().manual_seed(K + N)
     for M in (64, 37, 128):
         x = q(torch.randn(M, K, generator=g) * 1.7, dt)

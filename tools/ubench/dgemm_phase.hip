@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../ivideogpt_amd/csrc/dgemm.hip"
+#include "../../ivideogpt_amd/csrc/dgemm3.hip"
 
 #define CKH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -76,23 +77,37 @@ int main(int argc, char** argv) {
   long long* dbg; CKH(hipMalloc((void**)&dbg, 4 * dbg_per * 8)); CKH(hipMemsetAsync(dbg, 0, 4 * dbg_per * 8, st));
   CKH(hipStreamSynchronize(st));
 
-  auto gemm = [&](int which, const Layer& w, long long* d) {
+  const int gen = getenv("GEN") ? atoi(getenv("GEN")) : 3;
+  const bool warm = !(getenv("WARM") && getenv("WARM")[0] == '0');
+  auto gemm = [&](int which, int l, long long* d) {
+    const Layer& w = L[l];
     SkinnyArgs s;
     s.M = M; s.eps = 1e-6f; s.dbg = d;
     if (which == 0) { s.X = x; s.W = w.wqkv; s.Y = qkv; s.N = 3 * H; s.K = H; s.ldx = H; s.ldw = H; s.ldy = 3 * H; s.flags = SK_NORM; }
     if (which == 1) { s.X = attn; s.W = w.wo; s.Y = x; s.N = H; s.K = H; s.ldx = H; s.ldw = H; s.ldy = H; s.flags = IG_RESIDUAL; }
     if (which == 2) { s.X = x; s.W = w.wgu; s.Y = act; s.N = 2 * I; s.K = H; s.ldx = H; s.ldw = H; s.ldy = I; s.flags = IG_GLU | SK_NORM; }
     if (which == 3) { s.X = act; s.W = w.wdown; s.Y = x; s.N = H; s.K = I; s.ldx = I; s.ldw = I; s.ldy = H; s.flags = IG_RESIDUAL; }
-    const int rc = launch_dgemm(s, BF16, st);
-    if (rc != 0) { fprintf(stderr, "launch_dgemm(%d) -> %d\n", which, rc); exit(1); }
+    if (gen == 3 && warm) {   // the next launch of the chain: o-proj, gate/up, down, q/k/v of the next layer
+      SkinnyArgs n;
+      n.M = M;
+      const Layer& wn = which == 3 ? L[(l + 1) % layers] : w;
+      if (which == 0) { n.W = wn.wo; n.N = H; n.K = H; n.ldw = H; n.flags = IG_RESIDUAL; n.ldy = H; n.Y = x; n.X = attn; n.ldx = H; }
+      if (which == 1) { n.W = wn.wgu; n.N = 2 * I; n.K = H; n.ldw = H; n.flags = IG_GLU | SK_NORM; n.ldy = I; n.Y = act; n.X = x; n.ldx = H; }
+      if (which == 2) { n.W = wn.wdown; n.N = H; n.K = I; n.ldw = I; n.flags = IG_RESIDUAL; n.ldy = H; n.Y = x; n.X = act; n.ldx = I; }
+      if (which == 3) { n.W = wn.wqkv; n.N = 3 * H; n.K = H; n.ldw = H; n.flags = SK_NORM; n.ldy = 3 * H; n.Y = qkv; n.X = x; n.ldx = H; }
+      const int rows = dgemm3_w_rows_per_block(n, BF16);
+      if (rows > 0) { s.next_W = n.W; s.next_tile_bytes = (long)rows * n.K * 2; s.next_tiles = n.N / rows; }
+    }
+    const int rc = gen == 3 ? launch_dgemm3(s, BF16, st) : launch_dgemm(s, BF16, st);
+    if (rc != 0) { fprintf(stderr, "launch (generation %d, GEMM %d) -> %d\n", gen, which, rc); exit(1); }
   };
   int rot = 0;
   auto layer = [&](int l, unsigned mask, bool stream, long long* d) {
-    if (mask & 1) gemm(0, L[l], d ? d + 0 * dbg_per : nullptr);
+    if (mask & 1) gemm(0, l, d ? d + 0 * dbg_per : nullptr);
     if (stream) hipLaunchKernelGGL(stream_nt_kernel, dim3(G), dim3(256), 0, st, kvbuf + (size_t)(rot++ % kv_slots) * G * kv_per_wg, kv_per_wg, sink);
-    if (mask & 2) gemm(1, L[l], d ? d + 1 * dbg_per : nullptr);
-    if (mask & 4) gemm(2, L[l], d ? d + 2 * dbg_per : nullptr);
-    if (mask & 8) gemm(3, L[l], d ? d + 3 * dbg_per : nullptr);
+    if (mask & 2) gemm(1, l, d ? d + 1 * dbg_per : nullptr);
+    if (mask & 4) gemm(2, l, d ? d + 2 * dbg_per : nullptr);
+    if (mask & 8) gemm(3, l, d ? d + 3 * dbg_per : nullptr);
   };
   hipEvent_t e0, e1; CKH(hipEventCreate(&e0)); CKH(hipEventCreate(&e1));
   auto time_chain = [&](unsigned mask, bool stream, int steps) {
@@ -110,6 +125,7 @@ int main(int argc, char** argv) {
   };
   const char* names[4] = {"q/k/v", "o-proj", "gate/up", "down"};
   const float all_s = time_chain(15, true, 8), all = time_chain(15, false, 8), str = time_chain(0, true, 8);
+  printf("generation %d%s, IVG_DG3_FORCE=%s: ", gen, gen == 3 ? (warm ? " + L2 warm-up" : ", no warm-up") : "", getenv("IVG_DG3_FORCE") ? getenv("IVG_DG3_FORCE") : "-");
   printf("%s transformer, M = %d: layer chain %.2f us (4 GEMMs + streamer), streamer alone %.2f, 4 GEMMs alone %.2f us per layer\n",
          medium ? "medium" : "small", M, all_s, str, all);
   for (int k = 0; k < 4; ++k) {
@@ -121,7 +137,7 @@ int main(int argc, char** argv) {
   CKH(hipStreamSynchronize(st));
   std::vector<long long> h(4 * dbg_per);
   CKH(hipMemcpy(h.data(), dbg, 4 * dbg_per * 8, hipMemcpyDeviceToHost));
-  const char* ph[8] = {"entry", "dma issued", "first group", "last group", "mfma done", "barrier 1", "barrier 2", "stores issued"};
+  const char* ph[8] = {"entry", "dma issued", "first line", "last line", "mfma done", gen == 3 ? "parked" : "barrier 1", gen == 3 ? "barrier" : "barrier 2", "stores issued"};
   for (int k = 0; k < 4; ++k) {
     const long long* d = h.data() + k * dbg_per;
     std::vector<int> wgs;
