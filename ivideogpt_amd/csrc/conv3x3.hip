@@ -97,8 +97,9 @@ template <int N> __device__ __forceinline__ void wait_dma_keep() {   // all DMA 
 
 // GNA: GroupNorm(+SiLU) of the input fused into the staging -- the halo chunk is normalised IN PLACE in LDS
 // (y = silu(x * scale[c] + shift[c]), out-of-image padding stays zero) between its arrival and its first tap, piece by piece
-// under the taps of the previous chunk, so the normalised tensor never exists in HBM (measured slower than
-// the separate apply pass, off by default).
+// under the taps of the previous chunk, so the normalised tensor never exists in HBM.  ON by default
+// (tokenizer.cpp: norm_conv; IVG_GN_APPLY_FUSE=0 restores the separate apply pass): -2.2 ms per config-2 step with the
+// rebuilt loop (profiles/r02_gn_apply_fusion_ab.txt; the same fusion cost +2.5 ms while the loop was instruction-bound).
 // TPB2: two (tap, chunk) steps per workgroup barrier -- the weight ring holds two slots of two tiles and is refilled one PAIR of
 // steps ahead, the fragment registers are reused by the second step; 80 KiB of LDS, still two workgroups per CU.
 // (Reading the halo fragments of step s + 1 under the MFMAs of step s was measured: +-0.5 %, removed.)

@@ -105,29 +105,29 @@ __global__ __launch_bounds__(WAVES * 64) void dg3_kernel(const Dg3Dev p) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) dg3_dma16_nt(Ww + (size_t)line * 128, woff[a][h], base + ((MF + a) * 2 + h) * 1024);
   };
+  // ---- residual rows of the fragments this wave will finalise: requested FIRST, consumed after the K reduction.  Register-
+  // destination loads share the counter with the LDS-DMA queue and requests return in order: being the OLDEST entries they never
+  // enter the counted waits below (behind the prologue's lines they would be older than the lines requested later in the loop and
+  // the counts would be wrong for those).  Inline asm: a plain load may be scheduled anywhere by the compiler.
+  V4 res[NFIN];
+  if (res_bf) {
+#pragma unroll
+    for (int i = 0; i < NFIN; ++i) {
+      const int f = min(wave + i * WAVES, NFRAG - 1);
+      const int a = f / MF, b = f - a * MF;
+      const int m = min(m_tile + b * 16 + lr, p.M - 1), n0 = min(n_tile + a * 16 + lg * 4, p.N - 4);
+      const T* src = (const T*)p.Y + (long)m * p.ldy + n0;
+      if constexpr (sizeof(V4) == 8) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(res[i]) : "v"(src) : "memory");
+      else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(res[i]) : "v"(src) : "memory");
+    }
+  }
+
   int issued = 0;
   {
     const int first = min(p.ring, p.klw);
     for (; issued < first; ++issued) issue(issued, issued);
   }
   stamp(1);
-
-  // ---- residual rows of the fragments this wave will finalise: requested behind the operands, consumed after the K reduction.
-  // (register-destination loads share the counter with the LDS-DMA queue: they are YOUNGER than every request above, so the
-  // counted waits below simply allow NFIN more outstanding entries)
-  V4 res[NFIN];
-  if (res_bf) {
-#pragma unroll
-    for (int i = 0; i < NFIN; ++i) {
-      const int f = min(wave + i * WAVES, NFRAG - 1);   // waves without a fragment request one all the same: the counted waits
-      const int a = f / MF, b = f - a * MF;             // below assume exactly NFIN residual loads behind the operand requests
-      const int m = min(m_tile + b * 16 + lr, p.M - 1), n0 = min(n_tile + a * 16 + lg * 4, p.N - 4);
-      const T* src = (const T*)p.Y + (long)m * p.ldy + n0;
-      // inline asm: the request must sit exactly HERE in the queue (a plain load may be scheduled anywhere by the compiler)
-      if constexpr (sizeof(V4) == 8) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(res[i]) : "v"(src) : "memory");
-      else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(res[i]) : "v"(src) : "memory");
-    }
-  }
 
   f32x4 acc[FN][MF];
 #pragma unroll
@@ -139,15 +139,10 @@ __global__ __launch_bounds__(WAVES * 64) void dg3_kernel(const Dg3Dev p) {
   for (int b = 0; b < MF; ++b) ssq[b] = 0.f;
 
   for (int i = 0; i < p.klw; ++i) {
-    // requests return in order: line i has landed once at most (lines issued after it) * PER + (residual loads) are outstanding
+    // requests return in order: line i has landed once at most (lines issued after it) * PER requests are outstanding
     const int younger = issued - 1 - i;
-    if (res_bf) {
-      if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER + NFIN) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NFIN) : "memory");
-    } else {
-      if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (i == 0) stamp(2);
     if (i == p.klw - 1) stamp(3);
     const unsigned char* stage = my + (size_t)(p.ring == 2 ? (i & 1) : 0) * LINE;
@@ -201,8 +196,7 @@ __global__ __launch_bounds__(WAVES * 64) void dg3_kernel(const Dg3Dev p) {
           }
         }
   }
-  stamp(4);
-  if (res_bf) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the residual rows (requested at kernel start: long since here)
+  stamp(4);   // (the last line's wait was vmcnt(0): the residual rows are here as well)
 
   // ---- L2 warm-up of the next launch's weight tiles (this wave's share of the tiles its XCD will read); the requests travel
   // while this launch combines and stores, and are waited for at the very end
@@ -365,12 +359,10 @@ static const Dg3Pick kDg3Picks[] = {
     {1536, 768, 1, 1},     // small: o-proj
     {1536, 6144, 4, 2},    // small: gate/up
     {6144, 768, 1, 1},     // small: down
-    {1536, 16386, 4, 2},   // small: lm_head
     {2048, 3072, 2, 2},    // medium: q/k/v
     {2048, 1024, 1, 1},    // medium: o-proj
     {2048, 8192, 2, 2},    // medium: gate/up
     {8192, 1024, 1, 1},    // medium: down
-    {2048, 16386, 2, 2},   // medium: lm_head
 };
 
 struct Dg3Plan { int mf, fn, waves, klw, ring; unsigned wave_bytes; };
@@ -392,11 +384,10 @@ static bool dg3_plan(const SkinnyArgs& a, DType dtype, Dg3Plan& pl) {
   if (!waves) return false;
   const int mt = cdiv(a.M, 16);
   int MF = mt >= 4 ? 4 : (mt >= 2 ? 2 : 1);
-  int FN = glu ? 2 : 1;
+  int FN = (glu || a.N > 16 * 256) ? 2 : 1;                       // (a function of N only: it decides the coverage below)
   {
     auto wgs = [&](int mf, int fn) { return (long)cdiv(a.M, 16 * mf) * cdiv(a.N, 16 * fn); };
     while (MF > 1 && wgs(MF, FN) < 128) MF >>= 1;                 // narrow GEMMs: split the rows to fill the chip
-    while (FN < 2 && wgs(MF, FN) > 512) FN <<= 1;                 // wide GEMMs (lm_head): fatter W tiles, fewer rounds
   }
   for (const Dg3Pick& k : kDg3Picks) {
     if (k.kbytes != a.K * es || k.N != a.N) continue;
@@ -412,6 +403,10 @@ static bool dg3_plan(const SkinnyArgs& a, DType dtype, Dg3Plan& pl) {
     if (force[1] > 0) FN = force[1];
     if (glu && FN < 2) FN = 2;
   }
+  // one workgroup per CU (the staging fills most of the LDS): a GEMM whose W tiles outnumber the CUs would run in rounds, each
+  // paying the full request latency -- lm_head (513 tiles) stays on the second-generation kernel, whose small workgroups are all
+  // resident at once.  (A function of N and the pick only, like the rest of the coverage.)
+  if (cdiv(a.N, 16 * FN) > 256) return false;
   const int klw = (int)(lines / waves);
   // everything in flight at once needs waves * (MF + FN) * 2 KiB per line of K; over budget: fewer row tiles per workgroup
   while (MF > 1 && waves * (MF + FN) * 2048 > 160 * 1024) MF >>= 1;

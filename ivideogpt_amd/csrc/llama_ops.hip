@@ -339,11 +339,14 @@ int launch_flash_prefill(const void* qkv, const void* kc, const void* vt, void* 
 //   Kp  [B][kv][C]  projected keys of trajectory b (shared by its F frames)
 //   VpT [B][C][kv]  projected values, transposed
 //   out [M][P][C]
-template <int HD>
+template <int HD, int KT, bool PRE = true>   // KT: keys per staged tile (64; 32 for the single-head self-attention of 512 / 768 channels: LDS);
+                                            // PRE: the next tile travels into registers under the current one (off at 768 channels: registers)
 __global__ __launch_bounds__(256) void xattn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ Kp, const bf16_t* __restrict__ VpT,
                                                     bf16_t* __restrict__ out, int P, int kv, int C, int F, int nh, float scale) {
   constexpr int KQ = HD / 32;   // MFMA K-steps of the score product
   constexpr int DO = HD / 16;   // 16-row tiles of V^T / output channels
+  constexpr int SUB = KT / 16;  // 16-key sub-tiles of the score tile
+  constexpr int NPF = KT / 32;  // 32-key P fragments of the P.V product
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, lg = lane >> 4;
   const int qt = blockIdx.x;
   const int mh = blockIdx.y, m = mh / nh, h = mh - m * nh, b = m / F;
@@ -360,14 +363,16 @@ __global__ __launch_bounds__(256) void xattn_kernel(const bf16_t* __restrict__ q
   float mx = -INFINITY, lsum = 0.f;
   constexpr int PK = HD + 16;   // staged K row (elements), read back as 16-byte fragments: 32 bytes of pad are conflict-free for
                                 // ds_read_b128's lane groups (16 bytes cost every read a second cycle: 42 % conflict cycles in round 2)
-  constexpr int PV = 64 + 8;    // staged V^T row, read as 8-byte halves: conflict-free at 16 bytes of pad
-  __shared__ __attribute__((aligned(16))) bf16_t sK[64 * PK];
+  constexpr int PV = KT + 8;    // staged V^T row, read as 8-byte halves: conflict-free at 16 bytes of pad (KT = 64 and 32)
+  __shared__ __attribute__((aligned(16))) bf16_t sK[KT * PK];
   __shared__ __attribute__((aligned(16))) bf16_t sV[HD * PV];
-  constexpr int KC = 64 * HD / 8 / 256;   // 16-byte chunks of the K tile per thread
-  constexpr int VC = HD * 64 / 8 / 256;   // ... of the V^T tile
+  constexpr int KC = KT * HD / 8 / 256;   // 16-byte chunks of the K tile per thread
+  constexpr int VC = HD * KT / 8 / 256;   // ... of the V^T tile
+  constexpr int VCH = KT / 8;             // chunks per V^T row
+  static_assert(KC >= 1 && VC >= 1, "tile too small for 256 threads");
   Chunk16 pk[KC], pvv[VC];
   auto fetch = [&](int kt) {
-    const int k0 = kt * 64;
+    const int k0 = kt * KT;
 #pragma unroll
     for (int i = 0; i < KC; ++i) {
       const int c = i * 256 + tid, row = c / (HD / 8), col = (c % (HD / 8)) * 8;
@@ -375,24 +380,25 @@ __global__ __launch_bounds__(256) void xattn_kernel(const bf16_t* __restrict__ q
     }
 #pragma unroll
     for (int i = 0; i < VC; ++i) {
-      const int c = i * 256 + tid, row = c >> 3, col = (c & 7) * 8;
+      const int c = i * 256 + tid, row = c / VCH, col = (c % VCH) * 8;
       pvv[i] = *(const Chunk16*)(vb + (long)row * kv + k0 + col);
     }
   };
-  const int ntiles = kv >> 6;
-  fetch(0);
+  const int ntiles = kv / KT;
+  if constexpr (PRE) fetch(0);
   for (int kt = 0; kt < ntiles; ++kt) {
     __syncthreads();   // every wave is done with the previous tile
+    if constexpr (!PRE) fetch(kt);
 #pragma unroll
     for (int i = 0; i < KC; ++i) { const int c = i * 256 + tid; *(Chunk16*)(sK + (c / (HD / 8)) * PK + (c % (HD / 8)) * 8) = pk[i]; }
 #pragma unroll
-    for (int i = 0; i < VC; ++i) { const int c = i * 256 + tid; *(Chunk16*)(sV + (c >> 3) * PV + (c & 7) * 8) = pvv[i]; }
+    for (int i = 0; i < VC; ++i) { const int c = i * 256 + tid; *(Chunk16*)(sV + (c / VCH) * PV + (c % VCH) * 8) = pvv[i]; }
     __syncthreads();
-    if (kt + 1 < ntiles) fetch(kt + 1);
-    f32x4 sc[4];
+    if constexpr (PRE) { if (kt + 1 < ntiles) fetch(kt + 1); }
+    f32x4 sc[SUB];
     float mt = -INFINITY;
 #pragma unroll
-    for (int sub = 0; sub < 4; ++sub) {
+    for (int sub = 0; sub < SUB; ++sub) {
       sc[sub] = f32x4{0.f, 0.f, 0.f, 0.f};
       const bf16_t* krow = sK + (sub * 16 + lr) * PK + lg * 8;
 #pragma unroll
@@ -406,9 +412,9 @@ __global__ __launch_bounds__(256) void xattn_kernel(const bf16_t* __restrict__ q
     const float alpha = expf(mx - mn);        // first tile: exp(-inf) = 0
     mx = mn;
     float ps = 0.f;
-    bf16x8 pf[2];
+    bf16x8 pf[NPF];
 #pragma unroll
-    for (int sub = 0; sub < 4; ++sub)
+    for (int sub = 0; sub < SUB; ++sub)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float pe = expf(sc[sub][r] - mn);
@@ -421,7 +427,7 @@ __global__ __launch_bounds__(256) void xattn_kernel(const bf16_t* __restrict__ q
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[d][r] *= alpha;
 #pragma unroll
-      for (int pr = 0; pr < 2; ++pr) {
+      for (int pr = 0; pr < NPF; ++pr) {
         const bf16_t* vrow = sV + (d * 16 + lr) * PV + pr * 32 + lg * 4;
         const bf16x4 v0 = *(const bf16x4*)vrow, v1 = *(const bf16x4*)(vrow + 16);
         const bf16x8 va = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -438,24 +444,30 @@ __global__ __launch_bounds__(256) void xattn_kernel(const bf16_t* __restrict__ q
     *(bf16x4*)(orow + d * 16) = bf16x4{(bf16_t)(o[d][0] * inv), (bf16_t)(o[d][1] * inv), (bf16_t)(o[d][2] * inv), (bf16_t)(o[d][3] * inv)};
 }
 
+// one predicate for the planner and the launcher: which (dtype, shape) the one-pass kernel covers
+bool xattn_covers(int P, int kv, int C, int nh, DType dt) {
+  static const bool off = [] { const char* v = getenv("IVG_FLASH_XATT"); return v && v[0] == '0'; }();
+  if (off || dt != BF16 || nh <= 0 || C % nh != 0 || P % 64 != 0 || kv % 64 != 0 || (C & 7)) return false;
+  const int hd = C / nh;
+  return hd == 32 || hd == 64 || hd == 128 || hd == 192 || hd == 512 || hd == 768;
+}
+
 // -1: shape / dtype not covered (the caller keeps the score GEMM + softmax + P.V GEMM path)
 int launch_xattn(const void* q, const void* Kp, const void* VpT, void* out, int M, int F, int P, int kv, int C, int nh, DType dt, hipStream_t st) {
-  static const bool off = [] { const char* v = getenv("IVG_FLASH_XATT"); return v && v[0] == '0'; }();
-  if (off || dt != BF16 || C % nh != 0 || P % 64 != 0 || kv % 64 != 0 || M <= 0 || F <= 0 || M % F != 0) return -1;
-  if (((uintptr_t)q & 15) || ((uintptr_t)Kp & 15) || ((uintptr_t)VpT & 15) || ((uintptr_t)out & 7) || (C & 7)) return -1;
+  if (!xattn_covers(P, kv, C, nh, dt) || M <= 0 || F <= 0 || M % F != 0) return -1;
+  if (((uintptr_t)q & 15) || ((uintptr_t)Kp & 15) || ((uintptr_t)VpT & 15) || ((uintptr_t)out & 7)) return -1;
   const int hd = C / nh;
   dim3 grid((unsigned)(P / 64), (unsigned)(M * nh));
   const float scale = 1.0f / sqrtf((float)hd);
-  if (hd == 128)
-    hipLaunchKernelGGL(xattn_kernel<128>, grid, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)Kp, (const bf16_t*)VpT, (bf16_t*)out, P, kv, C, F, nh, scale);
-  else if (hd == 192)
-    hipLaunchKernelGGL(xattn_kernel<192>, grid, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)Kp, (const bf16_t*)VpT, (bf16_t*)out, P, kv, C, F, nh, scale);
-  else if (hd == 64)
-    hipLaunchKernelGGL(xattn_kernel<64>, grid, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)Kp, (const bf16_t*)VpT, (bf16_t*)out, P, kv, C, F, nh, scale);
-  else if (hd == 32)
-    hipLaunchKernelGGL(xattn_kernel<32>, grid, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)Kp, (const bf16_t*)VpT, (bf16_t*)out, P, kv, C, F, nh, scale);
-  else
-    return -1;
+#define IVG_XATTN(HDv, KTv, PREv) hipLaunchKernelGGL((xattn_kernel<HDv, KTv, PREv>), grid, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)Kp, (const bf16_t*)VpT, (bf16_t*)out, P, kv, C, F, nh, scale)
+  if (hd == 128) IVG_XATTN(128, 64, true);
+  else if (hd == 192) IVG_XATTN(192, 64, true);
+  else if (hd == 64) IVG_XATTN(64, 64, true);
+  else if (hd == 32) IVG_XATTN(32, 64, true);
+  else if (hd == 512) IVG_XATTN(512, 32, true);   // diffusers Attention of the conditional mid blocks: one head of 512 / 768 channels
+  else if (hd == 768) IVG_XATTN(768, 32, false);
+  else return -1;
+#undef IVG_XATTN
   return (int)hipGetLastError();
 }
 

@@ -68,8 +68,10 @@ int launch_rope_kv(void* qkv, void* kc, void* vc, void* vt, int ldvt, const floa
 // causal prompt attention in one kernel (bf16, head_dim 64); -1 = not covered, use the score GEMM / softmax / P.V path
 int launch_flash_prefill(const void* qkv, const void* kc, const void* vt, void* out, int B, int L, int Lp, int heads, int hd, int Lmax,
                          DType dt, hipStream_t st);
-// tokenizer cross-attention in one pass (bf16, 4 heads of 32 / 64 / 128 / 192 channels); -1 = not covered
+// tokenizer attention in one pass (bf16): cross-attention, 4 heads of 32 / 64 / 128 / 192 channels, and the single-head
+// self-attention of the conditional mid blocks (512 / 768 channels; M frames attending to themselves: F = 1, B = M); -1 = not covered
 int launch_xattn(const void* q, const void* Kp, const void* VpT, void* out, int M, int F, int P, int kv, int C, int nh, DType dt, hipStream_t st);
+bool xattn_covers(int P, int kv, int C, int nh, DType dt);   // pure predicate (shape, dtype): usable while planning the workspace
 // prof (nullable): [IVG_ATTN_PROF_SLOTS][Lmax starts | Lmax ends] wall-clock stamps (100 MHz) of the launch at each cache
 // position; workgroups spread over the slots so the atomics do not serialise on one address
 #define IVG_ATTN_PROF_SLOTS 32

@@ -183,8 +183,11 @@ int Run::self_attention(DType dt, const void* x, int N, int P, int C, const Attn
   void* k = e->ws.alloc(tok * C * esz(dt));
   void* vT = e->ws.alloc(tok * C * esz(dt));
   void* o = e->ws.alloc(tok * C * esz(dt));
-  float* S = (float*)e->ws.alloc((size_t)N * P * P * sizeof(float));
-  void* Pm = e->ws.alloc((size_t)N * P * P * esz(dt));
+  // one pass (bf16: xattn_kernel with one head of C channels, every frame attending to itself) -- no score matrix in HBM; the
+  // predicate is pure (shape, dtype), so the planning walk skips the score workspaces as well
+  const bool fused = xattn_covers(P, P, C, 1, dt);
+  float* S = fused ? nullptr : (float*)e->ws.alloc((size_t)N * P * P * sizeof(float));
+  void* Pm = fused ? nullptr : e->ws.alloc((size_t)N * P * P * esz(dt));
   IVG_TRY(gnorm(dt, x, t, N, P, C, a.gn, 1e-6f, 0, nullptr));
   IVG_TRY(linear(dt, t, tok, a.q, q, nullptr, 0, 0));
   IVG_TRY(linear(dt, t, tok, a.k, k, nullptr, 0, 0));
@@ -197,6 +200,12 @@ int Run::self_attention(DType dt, const void* x, int N, int P, int C, const Attn
     g.nb0 = N; g.sa[0] = 0; g.sw[0] = (long)P * C; g.sy[0] = (long)C * P;
     IVG_TRY(gemm(dt, g, 2.0 * tok * C * (double)C, (double)esz(dt) * (2.0 * tok * C + (double)C * C)));
   }
+  if (fused) {
+    if (!planning) {
+      const int rc = launch_xattn(q, k, vT, o, N, 1, P, P, C, 1, dt, st);
+      if (rc != 0) return e->fail(IVG_ERR_HIP, "one-pass self-attention launch failed: " + std::to_string(rc));
+    }
+  } else {
   {  // S = Q K^T / sqrt(C)
     IgemmArgs g;
     g.X = q; g.W = k; g.Y = S;
@@ -213,6 +222,7 @@ int Run::self_attention(DType dt, const void* x, int N, int P, int C, const Attn
     g.N = C; g.ldw = P; g.c_pix = C; g.c_ch = 1;
     g.nb0 = N; g.sa[0] = (long)P * P; g.sw[0] = (long)C * P; g.sy[0] = (long)P * C;
     IVG_TRY(gemm(dt, g, 2.0 * N * (double)P * P * C, (double)esz(dt) * ((double)N * P * P + 2.0 * tok * C)));
+  }
   }
   IVG_TRY(linear(dt, o, tok, a.o, out, x, 0, 0));
   e->ws.reset(m);
@@ -248,16 +258,18 @@ int Run::cross_attention(DType dt, const void* z, int B, int F, const XAttW& x, 
   void* qn = e->ws.alloc((size_t)M * P * C * esz(dt));
   void* q = e->ws.alloc((size_t)M * P * C * esz(dt));
   void* o = e->ws.alloc((size_t)M * P * C * esz(dt));
-  float* S = (float*)e->ws.alloc((size_t)M * nh * P * kv * sizeof(float));
-  void* Pm = e->ws.alloc((size_t)M * nh * P * kv * esz(dt));
+  // one-pass attention kernel (bf16): no score matrix in HBM -- and, the predicate being pure (shape, dtype), none in the
+  // workspace plan either (1.9 GB of S / P at config 2 were planned and never touched)
+  const bool fused = xattn_covers(P, kv, C, nh, dt);
+  float* S = fused ? nullptr : (float*)e->ws.alloc((size_t)M * nh * P * kv * sizeof(float));
+  void* Pm = fused ? nullptr : e->ws.alloc((size_t)M * nh * P * kv * esz(dt));
   IVG_TRY(gnorm(dt, z, qn, (int)M, P, C, x.qn, 1e-5f, 0, x.q_pos));
   IVG_TRY(linear(dt, qn, M * P, x.q, q, nullptr, 0, 0));
-  int fused = -1;   // one-pass attention kernel (bf16): no score matrix in HBM
-  if (!planning) {
-    fused = launch_xattn(q, Kp, VpT, o, (int)M, F, P, kv, C, nh, dt, st);
-    if (fused > 0) CK(fused);
+  if (fused && !planning) {
+    const int rc = launch_xattn(q, Kp, VpT, o, (int)M, F, P, kv, C, nh, dt, st);
+    if (rc != 0) return e->fail(IVG_ERR_HIP, "one-pass cross-attention launch failed: " + std::to_string(rc));
   }
-  if (fused != 0) {
+  if (!fused) {
   {  // S[b][f][h] = Q_h K_h^T / sqrt(hd)
     IgemmArgs g;
     g.X = q; g.W = Kp; g.Y = S;

@@ -640,10 +640,12 @@ def test_conv3x3_with_fused_input_groupnorm(dt, H, Cin, Cout, res):
 
 
 @pytest.mark.parametrize("C_,nh,P_,ctx,B,Fr", [(512, 4, 256, 2, 2, 3), (768, 4, 256, 2, 1, 2), (512, 4, 1024, 1, 1, 2), (256, 4, 64, 2, 2, 1),
-                                               (128, 4, 64, 1, 1, 2)])
+                                               (128, 4, 64, 1, 1, 2), (512, 1, 256, 1, 5, 1), (768, 1, 256, 1, 3, 1)])
 def test_one_pass_cross_attention(C_, nh, P_, ctx, B, Fr):
-    """The one-pass cross-attention kernel (head dims 128 / 192 of the 64x64 and 256x256 tokenizers, 64 / 32 of the test models)
-    against softmax(q k^T / sqrt(hd)) v in fp64 on the same bf16 inputs (conditional_vae.py:38-55)."""
+    """The one-pass attention kernel (head dims 128 / 192 of the 64x64 and 256x256 tokenizers, 64 / 32 of the test models) against
+    softmax(q k^T / sqrt(hd)) v in fp64 on the same bf16 inputs (conditional_vae.py:38-55); the last two cases are the diffusers
+    Attention of the conditional mid blocks (compressive_vq_model.py:79,136): ONE head of 512 / 768 channels, every
+    frame attending to its own 256 tokens (F = 1, B = frames)."""
     _, l = lib()
     torch.manual_seed(3)
     M, kv, hd = B * Fr, ctx * P_, C_ // nh

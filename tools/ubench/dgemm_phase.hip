@@ -13,6 +13,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <chrono>
+#include <thread>
 
 #include "../../ivideogpt_amd/csrc/dgemm.hip"
 #include "../../ivideogpt_amd/csrc/dgemm3.hip"
@@ -70,7 +72,7 @@ int main(int argc, char** argv) {
   const int heads = H / 64;
   const long kv_per_wg = 2L * 632 * 64 * 2;           // K and V rows of one (trajectory, head) at the mean cache length of config 2
   const int G = M * heads;
-  const int kv_slots = 16;
+  const int kv_slots = 16;   // (x 2 half-size slots in the chains2 mode)
   char* kvbuf; CKH(hipMalloc((void**)&kvbuf, (size_t)kv_slots * G * kv_per_wg)); CKH(hipMemsetAsync(kvbuf, 1, (size_t)kv_slots * G * kv_per_wg, st));
   float* sink; CKH(hipMalloc((void**)&sink, 1 << 20));
   const size_t dbg_per = (size_t)1024 * 16 * 16;       // workgroups x waves x stamps
@@ -109,6 +111,62 @@ int main(int argc, char** argv) {
     if (mask & 4) gemm(2, l, d ? d + 2 * dbg_per : nullptr);
     if (mask & 8) gemm(3, l, d ? d + 3 * dbg_per : nullptr);
   };
+  if (argc > 3 && !strcmp(argv[3], "chains2")) {
+    // Two half-batch chains on CU-MASKED streams (hipExtStreamCreateWithCUMask: each chain owns half of the CUs), launched eagerly by
+    // two host threads: does the HBM-bound attention of one chain run beside the ingest-bound GEMMs of the other?
+    const int Mh = M / 2, Gh = Mh * heads;
+    const int layout = argc > 4 ? atoi(argv[4]) : 0;   // 0: CUs [0,128) | [128,256)   1: even | odd CUs   2: no masks (plain streams)
+    hipStream_t cs[2];
+    for (int c = 0; c < 2; ++c) {
+      uint32_t mask[8];
+      for (int w = 0; w < 8; ++w) mask[w] = layout == 0 ? ((w < 4) == (c == 0) ? 0xffffffffu : 0u) : (c == 0 ? 0x55555555u : 0xaaaaaaaau);
+      if (layout == 2) CKH(hipStreamCreateWithFlags(&cs[c], hipStreamNonBlocking));
+      else CKH(hipExtStreamCreateWithCUMask(&cs[c], 8, mask));
+    }
+    bf16_t* cx[2] = {alloc((long)64 * H, 21, 1.0f), alloc((long)64 * H, 22, 1.0f)};
+    bf16_t* cqkv[2] = {alloc((long)64 * 3 * H, 23, 1.0f), alloc((long)64 * 3 * H, 24, 1.0f)};
+    bf16_t* cattn[2] = {alloc((long)64 * H, 25, 1.0f), alloc((long)64 * H, 26, 1.0f)};
+    bf16_t* cact[2] = {alloc((long)64 * I, 27, 1.0f), alloc((long)64 * I, 28, 1.0f)};
+    CKH(hipStreamSynchronize(st));
+    auto cgemm = [&](int c, int which, int l) {
+      const Layer& w = L[l];
+      SkinnyArgs a;
+      a.M = Mh; a.eps = 1e-6f;
+      if (which == 0) { a.X = cx[c]; a.W = w.wqkv; a.Y = cqkv[c]; a.N = 3 * H; a.K = H; a.ldx = H; a.ldw = H; a.ldy = 3 * H; a.flags = SK_NORM; }
+      if (which == 1) { a.X = cattn[c]; a.W = w.wo; a.Y = cx[c]; a.N = H; a.K = H; a.ldx = H; a.ldw = H; a.ldy = H; a.flags = IG_RESIDUAL; }
+      if (which == 2) { a.X = cx[c]; a.W = w.wgu; a.Y = cact[c]; a.N = 2 * I; a.K = H; a.ldx = H; a.ldw = H; a.ldy = I; a.flags = IG_GLU | SK_NORM; }
+      if (which == 3) { a.X = cact[c]; a.W = w.wdown; a.Y = cx[c]; a.N = H; a.K = I; a.ldx = I; a.ldw = I; a.ldy = H; a.flags = IG_RESIDUAL; }
+      const int rc = gen == 3 ? launch_dgemm3(a, BF16, cs[c]) : launch_dgemm(a, BF16, cs[c]);
+      if (rc != 0) { fprintf(stderr, "chain launch -> %d\n", rc); exit(1); }
+    };
+    auto chain_layer = [&](int c, int l, int r, bool gemms, bool stream) {
+      if (gemms) cgemm(c, 0, l);
+      if (stream) hipLaunchKernelGGL(stream_nt_kernel, dim3(Gh), dim3(256), 0, cs[c], kvbuf + (size_t)((2 * r + c) % (2 * kv_slots)) * Gh * kv_per_wg, kv_per_wg, sink + 1024 * c);
+      if (gemms) { cgemm(c, 1, l); cgemm(c, 2, l); cgemm(c, 3, l); }
+    };
+    auto run = [&](bool two, bool gemms, bool stream, int steps) {
+      auto body = [&](int c) { CKH(hipSetDevice(0)); int r = 0; for (int s = 0; s < steps; ++s) for (int l = 0; l < layers; ++l) chain_layer(c, l, r++, gemms, stream); };
+      body(0); if (two) body(1);                               // warm-up (attributes)
+      CKH(hipDeviceSynchronize());
+      std::vector<double> t;
+      for (int rep = 0; rep < 3; ++rep) {
+        const auto t0 = std::chrono::steady_clock::now();
+        std::thread th0(body, 0);
+        if (two) { std::thread th1(body, 1); th1.join(); }
+        th0.join();
+        CKH(hipDeviceSynchronize());
+        t.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / (steps * layers));
+      }
+      std::sort(t.begin(), t.end());
+      return t[1];
+    };
+    const int steps = 16;
+    printf("chains2 (generation %d, %d rows per chain, CU mask layout %d), us per layer (host wall clock, %d steps x %d layers):\n", gen, Mh, layout, steps, layers);
+    printf("  one chain alone : streamer %.2f | GEMMs %.2f | both %.2f\n", run(false, false, true, steps), run(false, true, false, steps), run(false, true, true, steps));
+    printf("  two chains      : streamers %.2f | GEMMs %.2f | both %.2f   (full batch on one unmasked chain: see the default mode)\n",
+           run(true, false, true, steps), run(true, true, false, steps), run(true, true, true, steps));
+    return 0;
+  }
   hipEvent_t e0, e1; CKH(hipEventCreate(&e0)); CKH(hipEventCreate(&e1));
   auto time_chain = [&](unsigned mask, bool stream, int steps) {
     for (int l = 0; l < layers; ++l) layer(l, mask, stream, nullptr);   // warm-up (attributes, code upload)
