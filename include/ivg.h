@@ -111,6 +111,10 @@ int ivg_encode_context(ivg_engine* e, const void* pixels, int pixel_dtype, int B
  * (cache=...): context frames are then not decoded again (their pixels are copied from the cache). */
 int ivg_detokenize(ivg_engine* e, const int64_t* ids, int B, int F, float* pixels_out, ivg_cache* cache, int cache_mode,
                    ivg_stream stream);
+/* on != 0: ivg_detokenize writes clamp(frames, 0, 1) -- the post-processing every caller of the reference applies to the decoded
+ * clip (inference/predict.py:73, vp/ivideogpt_interface.py:199, train_gpt.py:438) -- from the epilogue of the decoders' last
+ * convolution instead of a separate pass over the clip.  Default off: CompressiveVQModel.detokenize returns the raw output. */
+int ivg_set_output_clamp(ivg_engine* e, int on);
 int ivg_cache_create(ivg_engine* e, int B, ivg_cache** out);
 void ivg_cache_destroy(ivg_engine* e, ivg_cache* c);
 

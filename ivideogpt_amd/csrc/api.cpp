@@ -379,6 +379,12 @@ int ivg_encode_context(ivg_engine* e, const void* pixels, int pixel_dtype, int B
     return r.tokenize(pixels, (DType)pixel_dtype, B, T, ids_out, ids_stride, nullptr, true); });
 }
 
+int ivg_set_output_clamp(ivg_engine* e, int on) {
+  if (!e) return IVG_ERR_INVALID;
+  e->clamp_out = on != 0;
+  return IVG_OK;
+}
+
 int ivg_detokenize(ivg_engine* e, const int64_t* ids, int B, int F, float* pixels_out, ivg_cache* cache, int cache_mode, ivg_stream stream) {
   if (!e) return IVG_ERR_INVALID;
   IVG_TRY(check_tok(e, B, e->ctx + F, "detokenize"));

@@ -67,6 +67,7 @@ struct ivg_engine {
   std::unordered_map<std::string, ivg_tensor> wmap;
   ivg::Arena ws;
   int ctx = 1;  // current context length (set_context_length)
+  bool clamp_out = false;   // detokenize writes clamp(frames, 0, 1) (conv_out epilogue) instead of the raw decoder output (ivg_set_output_clamp)
   ivg::DType enc_dt, dec_dt, llm_dt;
   // tokenizer
   ivg::TrunkW enc, cenc, dec, cdec;

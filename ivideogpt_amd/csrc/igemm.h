@@ -12,6 +12,7 @@ enum IgemmFlags : int {
   IG_GLU = 16,       // weight rows packed [16 gate | 16 up] per 32: out[m][j] = silu(gate) * up, N_out = N/2
   IG_OUT_F32 = 32,   // output is fp32 regardless of T (attention scores, logits, final pixels)
   SK_NORM = 64,      // skinny GEMM only: scale row m by rsqrt(mean_k X[m][k]^2 + eps) (RMSNorm with the weight folded into W)
+  IG_CLAMP01 = 128,  // clamp(., 0, 1) last (the final conv of the decoders when the caller wants displayable frames: predict.py:73)
 };
 
 // Y[z](m, n) = epi( alpha * sum_k A[z](m, k) * W[z][n][k] )

@@ -254,6 +254,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDev p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = silu_t<T>(v[r]);
       }
+      if (flags & IG_CLAMP01) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r], 0.0f), 1.0f);
+      }
       if (flags & IG_OUT_F32) {
         float* Y = (float*)p.Y;
         if (vec_ok && ((o & 3) == 0)) {

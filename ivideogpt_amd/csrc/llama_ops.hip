@@ -553,7 +553,7 @@ template <typename T, bool NT, int HD>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
                                                           T* __restrict__ out, const float* __restrict__ cosT,
                                                           const float* __restrict__ sinT, int heads, int hd_arg, int Lmax,
-                                                          const StepState* __restrict__ state, unsigned long long* prof) {
+                                                          const StepState* __restrict__ state, unsigned long long* prof, int pre2) {
   constexpr int VEC = Traits<T>::VEC;
   const int hd = HD > 0 ? HD : hd_arg;
   constexpr int UNR = 8;   // 16-byte loads in flight per lane: 3 workgroups x 256 lanes x 8 x 16 B = 96 KiB per CU
@@ -657,6 +657,10 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
     }
   }
   if (dbg) dslot[3] = wall_clock64();
+  // the SECOND block of value rows is requested here as well: all 768 workgroups reach the statistics phase below at about the
+  // same time, and with one block per workgroup in flight the memory system ran dry under it (round 2: ~5 us of every launch
+  // were not streaming).  `nxt` is free: the last key rows have been consumed.
+  if (pre2 && step < pos) load_rows(nxt, vb, step);
   if (grp == 0) {
     float d = 0.f;
 #pragma unroll
@@ -690,12 +694,22 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
       if (t < pos) axpy_chunk<T>(of, sc[t], rows[u]);
     }
   };
-  for (int t0 = 0; t0 < pos; t0 += 2 * step) {  // cur holds value rows [t0, t0 + step) (requested during pass A / the last iteration)
-    if (t0 + step < pos) load_rows(nxt, vb, t0 + step);
-    weighted(cur, t0);
-    if (t0 + step >= pos) break;
-    if (t0 + 2 * step < pos) load_rows(cur, vb, t0 + 2 * step);
-    weighted(nxt, t0 + step);
+  if (pre2) {   // two blocks in flight throughout: a buffer is requested again right after it has been consumed (same key order, same sums)
+    for (int t0 = 0; t0 < pos; t0 += 2 * step) {
+      weighted(cur, t0);
+      if (t0 + 2 * step < pos) load_rows(cur, vb, t0 + 2 * step);
+      if (t0 + step >= pos) break;
+      weighted(nxt, t0 + step);
+      if (t0 + 3 * step < pos) load_rows(nxt, vb, t0 + 3 * step);
+    }
+  } else {
+    for (int t0 = 0; t0 < pos; t0 += 2 * step) {  // cur holds value rows [t0, t0 + step) (requested during pass A / the last iteration)
+      if (t0 + step < pos) load_rows(nxt, vb, t0 + step);
+      weighted(cur, t0);
+      if (t0 + step >= pos) break;
+      if (t0 + 2 * step < pos) load_rows(cur, vb, t0 + 2 * step);
+      weighted(nxt, t0 + step);
+    }
   }
   if (dbg) dslot[5] = wall_clock64();
   if (grp == 0) {
@@ -740,7 +754,8 @@ int launch_decode_attn(const void* qkv, void* kc, void* vc, void* out, const flo
   static const bool nt = [] { const char* v = getenv("IVG_ATTN_NT"); return !(v && v[0] == '0'); }();
 #define IVG_DA(T, NTv, HDv)                                                                                                       \
   hipLaunchKernelGGL((decode_attn_kernel<T, NTv, HDv>), g, dim3(256), smem, st, (const T*)qkv, (T*)kc, (T*)vc, (T*)out, cosT, sinT, heads, hd, \
-                     Lmax, state, prof)
+                     Lmax, state, prof, pre2)
+  static const int pre2 = [] { const char* v = getenv("IVG_ATTN_PRE2"); return (v && v[0] == '0') ? 0 : 1; }();   // IVG_ATTN_PRE2=0: one value block ahead (A/B)
   if (dt == BF16 && nt) { if (hd == 64) IVG_DA(bf16_t, true, 64); else IVG_DA(bf16_t, true, 0); }
   else if (dt == BF16) { if (hd == 64) IVG_DA(bf16_t, false, 64); else IVG_DA(bf16_t, false, 0); }
   else { if (hd == 64) IVG_DA(float, false, 64); else IVG_DA(float, false, 0); }

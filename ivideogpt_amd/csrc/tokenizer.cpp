@@ -536,7 +536,7 @@ int Run::decoder_trunk(const TrunkW& w, const void* z, int B, int per, int T_tot
     g.N = 3; g.ldw = 9 * C0;
     g.c_img = 3L * res * res; g.c_pix = 1; g.c_ch = (long)res * res;
     g.c_grp = per; g.c_grp_stride = (long)T_total * 3 * res * res;
-    g.flags = IG_BIAS_N | IG_OUT_F32;
+    g.flags = IG_BIAS_N | IG_OUT_F32 | (e->clamp_out ? IG_CLAMP01 : 0);   // clamp(0, 1) of predict.py:73 in the epilogue
     IVG_TRY(gemm(dt, g, 2.0 * N * side * side * 27.0 * C0, (double)esz(dt) * N * side * side * C0 + 4.0 * N * 3 * side * side));
   }
   e->ws.reset(m);

@@ -67,6 +67,7 @@ class Engine:
         self.max_batch, self.max_frames = int(max_batch), int(max_frames)
         self._stream = torch.cuda.Stream(device=self.device)  # dedicated non-default stream (graph capture needs one)
         self._caches = set()   # live detokenize caches (device memory owned here: released with the engine)
+        self._clamp_out = False
 
     def close(self):
         if getattr(self, "h", None):
@@ -122,7 +123,10 @@ class Engine:
                        "encode_context")
             pixels.record_stream(self._stream); ids.record_stream(self._stream)
 
-    def detokenize(self, ids, F, out, cache=None, cache_mode=0):
+    def detokenize(self, ids, F, out, cache=None, cache_mode=0, clamp=False):
+        if clamp != self._clamp_out:   # clamp(0, 1) in the epilogue of the decoders' last convolution (engine state, rarely toggled)
+            self.check(self.lib.ivg_set_output_clamp(self.h, int(bool(clamp))), "set_output_clamp")
+            self._clamp_out = bool(clamp)
         with self.stream() as s:
             self.check(self.lib.ivg_detokenize(self.h, _ptr(ids), ids.shape[0], int(F), _ptr(out), cache, int(cache_mode), s), "detokenize")
             ids.record_stream(self._stream); out.record_stream(self._stream)

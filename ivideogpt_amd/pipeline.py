@@ -18,7 +18,7 @@ def predict_frames(tokenizer, model, pixel_values, context_length, future_length
                                 uniforms=uniforms)
     else:
         tokens = model.generate(prompt, do_sample=do_sample, top_k=top_k, max_new_tokens=n_new, generator=generator, uniforms=uniforms)
-    frames = tokenizer.detokenize(tokens, context_length).clamp_(0.0, 1.0)
+    frames = tokenizer.detokenize(tokens, context_length, clamp=True)   # clamp(0, 1) in the epilogue of the decoders' last convolution
     return (frames, tokens) if return_tokens else frames
 
 

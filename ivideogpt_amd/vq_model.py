@@ -174,7 +174,9 @@ class CompressiveVQModel:
         return ids
 
     @torch.no_grad()
-    def detokenize(self, indices, context_length=0, cache=None, return_cache=False):
+    def detokenize(self, indices, context_length=0, cache=None, return_cache=False, clamp=False):
+        """``clamp=True`` (not in the reference's signature): the frames come back as ``clamp(0, 1)`` -- the post-processing every
+        caller applies (predict.py:73) -- written by the epilogue of the decoders' last convolution instead of a pass over the clip."""
         assert context_length == self.context_length
         assert (indices.shape[1] + 1 - CTX_TOKENS * context_length) % DYN_TOKENS == 0
         F = (indices.shape[1] + 1 - CTX_TOKENS * context_length) // DYN_TOKENS
@@ -198,7 +200,7 @@ class CompressiveVQModel:
         elif return_cache:
             cache = DetokenizeCache(eng, B)
             handle, mode = cache.handle, 1
-        eng.detokenize(ids, F, out, handle, mode)
+        eng.detokenize(ids, F, out, handle, mode, clamp=clamp)
         return (out, cache) if return_cache else out
 
     # ------------------------------------------------------------------ measurement
