@@ -657,9 +657,8 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
     }
   }
   if (dbg) dslot[3] = wall_clock64();
-  // the SECOND block of value rows is requested here as well: all 768 workgroups reach the statistics phase below at about the
-  // same time, and with one block per workgroup in flight the memory system ran dry under it (round 2: ~5 us of every launch
-  // were not streaming).  `nxt` is free: the last key rows have been consumed.
+  // pre2 (off by default, measured slower: see launch_decode_attn): the SECOND block of value rows requested before the
+  // statistics phase as well (`nxt` is free: the last key rows have been consumed)
   if (pre2 && step < pos) load_rows(nxt, vb, step);
   if (grp == 0) {
     float d = 0.f;
@@ -755,7 +754,10 @@ int launch_decode_attn(const void* qkv, void* kc, void* vc, void* out, const flo
 #define IVG_DA(T, NTv, HDv)                                                                                                       \
   hipLaunchKernelGGL((decode_attn_kernel<T, NTv, HDv>), g, dim3(256), smem, st, (const T*)qkv, (T*)kc, (T*)vc, (T*)out, cosT, sinT, heads, hd, \
                      Lmax, state, prof, pre2)
-  static const int pre2 = [] { const char* v = getenv("IVG_ATTN_PRE2"); return (v && v[0] == '0') ? 0 : 1; }();   // IVG_ATTN_PRE2=0: one value block ahead (A/B)
+  // IVG_ATTN_PRE2=1: two value blocks in flight across the softmax statistics.  Measured (profiles/r03_attn_pre2_ab.txt): 64.3 vs
+  // 61.2 ms per step of attention, rollout 150.4 vs 147.5 ms -- SLOWER: one block per workgroup already keeps 25 MB in flight
+  // chip-wide, the second only deepens the HBM queues every workgroup then waits behind.  Off by default; the path is kept for A/B.
+  static const int pre2 = [] { const char* v = getenv("IVG_ATTN_PRE2"); return (v && v[0] == '1') ? 1 : 0; }();
   if (dt == BF16 && nt) { if (hd == 64) IVG_DA(bf16_t, true, 64); else IVG_DA(bf16_t, true, 0); }
   else if (dt == BF16) { if (hd == 64) IVG_DA(bf16_t, false, 64); else IVG_DA(bf16_t, false, 0); }
   else { if (hd == 64) IVG_DA(float, false, 64); else IVG_DA(float, false, 0); }
