@@ -40,6 +40,58 @@ constexpr int G256_SLAB = 256 * 64;               // bytes of one 256-row x 32-e
 constexpr int G256_STAGE = 2 * G256_SLAB;         // A | W
 constexpr int G256_PITCH = 256 * 2 + 16;          // staged output row (bytes): + 16 spreads the 16 rows of a fragment over banks
 
+// epilogue shared by both kernels: lane holds 4 consecutive columns n of row (wm*64 + b*16 + lr); bias, residual, SiLU, SiLU(gate) * up
+// in registers, then staged through LDS (the ring is free) so that global stores are whole 16-byte runs of an output row
+__device__ __forceinline__ void g256_epilogue(const G256Dev& p, f32x4 (&acc)[4][4], unsigned char* smem, int m0, int n0, int wm, int wn, int lr, int lg,
+                                              int tid) {
+  const int flags = p.flags;
+  const bool glu = flags & IG_GLU;
+  const int out_cols = glu ? 128 : 256;               // columns this tile writes
+  const int out_n0 = glu ? (n0 >> 1) : n0;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int row = wm * 64 + b * 16 + lr;
+    const int m = m0 + row;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      if (glu && (a & 1)) continue;
+      float v4[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v4[r] = acc[a][b][r];
+      const int ncol = wn * 64 + a * 16 + lg * 4;     // column inside the 256-wide tile (of the PACKED weight rows for GLU)
+      if (flags & IG_BIAS_N) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v4[r] += p.bias[n0 + ncol + r];
+      }
+      int ocol = ncol;
+      if (glu) {  // rows [16 gate | 16 up] per 32 packed weight rows: fragment a = gate, a + 1 = up of the same 16 outputs
+        const int a1 = a + 1 < 4 ? a + 1 : a;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v4[r] = silu_t<bf16_t>(v4[r]) * acc[a1][b][r];
+        ocol = (wn * 64 + a * 16) / 2 + lg * 4;
+      }
+      if ((flags & IG_RESIDUAL) && m < p.M) {
+        const bf16x4 rv = *(const bf16x4*)(p.R + (long)m * p.ldy + out_n0 + ocol);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v4[r] += (float)rv[r];
+      }
+      if (flags & IG_SILU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v4[r] = silu_t<bf16_t>(v4[r]);
+      }
+      *(bf16x4*)(smem + row * G256_PITCH + ocol * 2) = bf16x4{(bf16_t)v4[0], (bf16_t)v4[1], (bf16_t)v4[2], (bf16_t)v4[3]};
+    }
+  }
+  __syncthreads();
+  const int cpr = out_cols / 8;                        // 16-byte chunks per output row
+  for (int q = tid; q < 256 * cpr; q += 1024) {
+    const int row = q / cpr, ch = q - row * cpr;
+    if (m0 + row >= p.M) continue;
+    const Chunk16 val = *(const Chunk16*)(smem + row * G256_PITCH + ch * 16);
+    *(Chunk16*)(p.Y + (long)(m0 + row) * p.ldy + out_n0 + ch * 8) = val;
+  }
+}
+
 // PAIR: two K steps per workgroup barrier (the 16-wave barrier is the expensive event of this loop): the ring is used as two
 // double stages, the pair after this one is requested at the top of this pair and waited for at its end.
 template <bool PAIR>
@@ -124,53 +176,88 @@ __global__ __launch_bounds__(1024) void gemm256_kernel(const G256Dev p) {
   }
   }
 
-  // ---- epilogue: lane holds 4 consecutive columns n of row (wm*64 + b*16 + lr)
-  const int flags = p.flags;
-  const bool glu = flags & IG_GLU;
-  const int out_cols = glu ? 128 : 256;               // columns this tile writes
-  const int out_n0 = glu ? (n0 >> 1) : n0;
+  g256_epilogue(p, acc, smem, m0, n0, wm, wn, lr, lg, tid);
+}
+
+// ---- whole-line variant (round 3).  The kernel above requests 64-byte rows (K steps of 32 elements): half a cache line per row and
+// request, the shape the round-2 decode micro-benchmarks measured at 12-16 B/clk/CU out of L2 against 25-49 for whole 128-byte
+// lines -- and 32 KiB per 1,030 MFMA clocks is exactly what this kernel was getting (11 B/clk/CU, MFMA pipe 25-41 % busy).  Here a
+// step is 64 elements of K: every LDS-DMA instruction fetches 8 rows x one whole line, with the source-side chunk permutation of
+// dgemm.hip (slot jj of row r holds source chunk jj ^ ((r >> 1) & 7)): the lane-linear [16 rows][8 chunks] image is read back as
+// MFMA fragments by conflict-free ds_read_b128.  Two stages of 64 KiB (A | W), one barrier per 32 MFMAs per wave; the address
+// is split the way the hardware takes it (scalar base advanced per step + a 32-bit lane offset set up once).
+constexpr int G256L_HALF = 256 * 128;             // one operand of a stage: 256 rows x 128 bytes = 16 tiles of 2 KiB
+constexpr int G256L_STAGE = 2 * G256L_HALF;
+__device__ __forceinline__ void g256l_dma16(const void* sbase, unsigned voff, unsigned lds_wave_base) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_wave_base), "v"(voff), "s"(sbase) : "memory");
+}
+__global__ __launch_bounds__(1024) void gemm256l_kernel(const G256Dev p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int wm = wave & 3, wn = wave >> 2;
+  const int nwg = gridDim.x;
+  int v;
+  {
+    const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int tile_n = v % p.tiles_n, tile_m = v / p.tiles_n;
+  const int m0 = tile_m * 256, n0 = tile_n * 256;
+  const int steps = p.K >> 6;
+  // wave w fills tile w (16 rows) of both operands: two requests of 8 rows x 128 bytes each
+  const int r8 = lane >> 3, jj = lane & 7;
+  unsigned aoff[2], woff[2];
 #pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    const int row = wm * 64 + b * 16 + lr;
-    const int m = m0 + row;
+  for (int h = 0; h < 2; ++h) {
+    const int r = h * 8 + r8;
+    const unsigned sw = (unsigned)(jj ^ ((r >> 1) & 7)) * 16u;
+    aoff[h] = (unsigned)min(m0 + wave * 16 + r, p.M - 1) * (unsigned)(p.ldx * 2) + sw;   // rows beyond M re-read row M - 1 (never stored)
+    woff[h] = (unsigned)(n0 + wave * 16 + r) * (unsigned)(p.ldw * 2) + sw;
+  }
+  const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) const void*)smem;
+  auto issue = [&](int step) {
+    const unsigned base = lds0 + (step & 1) * G256L_STAGE + wave * 2048;
+    const char* xs = (const char*)p.X + (size_t)step * 128;
+    const char* ws = (const char*)p.W + (size_t)step * 128;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      if (glu && (a & 1)) continue;
-      float v4[4];
+    for (int h = 0; h < 2; ++h) g256l_dma16(xs, aoff[h], base + h * 1024);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v4[r] = acc[a][b][r];
-      const int ncol = wn * 64 + a * 16 + lg * 4;     // column inside the 256-wide tile (of the PACKED weight rows for GLU)
-      if (flags & IG_BIAS_N) {
+    for (int h = 0; h < 2; ++h) g256l_dma16(ws, woff[h], base + G256L_HALF + h * 1024);
+  };
+  f32x4 acc[4][4];   // [a: N fragment][b: M fragment]
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v4[r] += p.bias[n0 + ncol + r];
-      }
-      int ocol = ncol;
-      if (glu) {  // rows [16 gate | 16 up] per 32 packed weight rows: fragment a = gate, a + 1 = up of the same 16 outputs
-        const int a1 = a + 1 < 4 ? a + 1 : a;
+  for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v4[r] = silu_t<bf16_t>(v4[r]) * acc[a1][b][r];
-        ocol = (wn * 64 + a * 16) / 2 + lg * 4;
-      }
-      if ((flags & IG_RESIDUAL) && m < p.M) {
-        const bf16x4 rv = *(const bf16x4*)(p.R + (long)m * p.ldy + out_n0 + ocol);
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fslot0 = lr * 8, fkey = (lr >> 1) & 7;
+  issue(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int s = 0; s < steps; ++s) {
+    if (s + 1 < steps) issue(s + 1);   // the other stage: last read in step s - 1, before the barrier that ended it
+    const unsigned char* sa = smem + (s & 1) * G256L_STAGE;
+    const unsigned char* sw_ = sa + G256L_HALF;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v4[r] += (float)rv[r];
-      }
-      if (flags & IG_SILU) {
+    for (int tt = 0; tt < 2; ++tt) {
+      const int slot = fslot0 + ((tt * 4 + lg) ^ fkey);
+      Chunk16 xa[4], wv[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v4[r] = silu_t<bf16_t>(v4[r]);
-      }
-      *(bf16x4*)(smem + row * G256_PITCH + ocol * 2) = bf16x4{(bf16_t)v4[0], (bf16_t)v4[1], (bf16_t)v4[2], (bf16_t)v4[3]};
+      for (int b = 0; b < 4; ++b) xa[b] = *(const Chunk16*)(sa + ((wm * 4 + b) * 128 + slot) * 16);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) wv[a] = *(const Chunk16*)(sw_ + ((wn * 4 + a) * 128 + slot) * 16);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[a]), __builtin_bit_cast(bf16x8, xa[b]),
+                                                              acc[a][b], 0, 0, 0);
     }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
   }
-  __syncthreads();
-  const int cpr = out_cols / 8;                        // 16-byte chunks per output row
-  for (int q = tid; q < 256 * cpr; q += 1024) {
-    const int row = q / cpr, ch = q - row * cpr;
-    if (m0 + row >= p.M) continue;
-    const Chunk16 val = *(const Chunk16*)(smem + row * G256_PITCH + ch * 16);
-    *(Chunk16*)(p.Y + (long)(m0 + row) * p.ldy + out_n0 + ch * 8) = val;
-  }
+  g256_epilogue(p, acc, smem, m0, n0, wm, wn, lr, lg, tid);
 }
 
 static bool gemm256_enabled() {
@@ -207,6 +294,18 @@ int launch_gemm256(const IgemmArgs& a, DType dtype, hipStream_t stream) {
     if (e != hipSuccess) return (int)e;
   }
   const long tiles = (long)cdiv(M, 256) * d.tiles_n;
+  // whole-line requests (K steps of 64 elements) wherever K allows; IVG_G256_LINE=0: the 64-byte-row kernel (A/B, tests)
+  const bool line = [] { const char* v = getenv("IVG_G256_LINE"); return !(v && v[0] == '0'); }();
+  if (line && d.K % 64 == 0 && (long)d.M * d.ldx * 2 < (1L << 31) && (long)d.N * d.ldw * 2 < (1L << 31)) {
+    static unsigned long long attr_l = 0;
+    if (first_time_on_device(attr_l)) {
+      hipError_t e = hipFuncSetAttribute((const void*)gemm256l_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return (int)e;
+    }
+    const int smem_l = 256 * G256_PITCH > 2 * G256L_STAGE ? 256 * G256_PITCH : 2 * G256L_STAGE;
+    hipLaunchKernelGGL(gemm256l_kernel, dim3((unsigned)tiles), dim3(1024), smem_l, stream, d);
+    return (int)hipGetLastError();
+  }
   if (pair) hipLaunchKernelGGL(gemm256_kernel<true>, dim3((unsigned)tiles), dim3(1024), smem, stream, d);
   else hipLaunchKernelGGL(gemm256_kernel<false>, dim3((unsigned)tiles), dim3(1024), smem, stream, d);
   return (int)hipGetLastError();

@@ -438,11 +438,15 @@ def test_decode_gemm_model_shapes(K, N, mode, dt, gen, monkeypatch):
         assert rel_err(Y.float(), ref) < tol, (M, K, N, mode, dt, gen)
 
 
+@pytest.mark.parametrize("line", ["1", "0"])
 @pytest.mark.parametrize("mode", ["plain", "bias_residual_inplace", "glu", "silu", "k_short", "k_odd_steps", "nimg"])
-def test_gemm256_large_dense(mode, monkeypatch):
+def test_gemm256_large_dense(mode, line, monkeypatch):
     """(k_odd_steps also runs the two-steps-per-barrier variant, IVG_G256_PAIR=1, whose last pair is half empty)
     256 x 256-tile GEMM of the prompt pass (bf16, rows not a multiple of 256): every epilogue against fp64, and bit-for-bit
-    agreement is NOT required with the 128 x 128 kernel -- but both must sit inside the same bf16 tolerance."""
+    agreement is NOT required with the 128 x 128 kernel -- but both must sit inside the same bf16 tolerance.
+    line = 1: whole-line requests (K steps of 64 elements, the default where K % 64 == 0; k_odd_steps has K = 160 and stays on
+    the 64-byte-row kernel); line = 0 (IVG_G256_LINE=0): the 64-byte-row kernel everywhere."""
+    monkeypatch.setenv("IVG_G256_LINE", line)
     g = torch.Generator().manual_seed(len(mode))
     if mode == "k_odd_steps":
         monkeypatch.setenv("IVG_G256_PAIR", "1")
