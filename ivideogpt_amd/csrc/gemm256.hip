@@ -13,6 +13,7 @@
 //   * epilogue in registers (bias, residual, SiLU, SiLU(gate) * up on the interleaved weight packing), then staged through
 //     the (now free) ring so that global stores are whole 16-byte runs of an output row;
 //   * XCD-aware block order: the N tiles of one M tile run on one XCD and share its L2 copy of the A slab.
+#include <algorithm>
 #include <cstdlib>
 
 #include "igemm.h"
@@ -24,7 +25,21 @@ struct G256Dev {
   int M, N, K, ldx, ldw, ldy;
   int tiles_n;
   int flags;
+  int tiles_m, gn;   // tile order: groups of gn N tiles, inside a group M outer / N inner (see g256_tile)
 };
+
+// Work item v -> (tile_m, tile_n).  Each XCD walks a contiguous run of items.  N fastest over ALL N tiles (round 2) keeps the A slab of
+// an M tile in the XCD's L2 but streams the whole weight matrix through it once per M tile: gate/up of the prompt pass is 9.4 MB of
+// W against 4 MB of L2 -> 129 x 9.4 MB = 1.2 GB from beyond the L2 per GEMM.  Blocked: the N tiles are taken in groups whose W
+// slabs fit the L2 (gn x 256 rows x K), every M tile is walked inside a group before the next group starts: W is fetched once
+// per XCD and group, A once per group (gate/up: 3-4 x 50 MB instead of 1.2 GB).
+__device__ __forceinline__ void g256_tile(const G256Dev& p, int v, int& tile_m, int& tile_n) {
+  const int per_group = p.gn * p.tiles_m;
+  const int g = v / per_group, rem = v - g * per_group;
+  const int gsize = min(p.gn, p.tiles_n - g * p.gn);
+  tile_m = rem / gsize;
+  tile_n = g * p.gn + (rem - tile_m * gsize);
+}
 
 __device__ __attribute__((aligned(16))) unsigned char g_zero_chunk_g256[16];
 
@@ -106,7 +121,8 @@ __global__ __launch_bounds__(1024) void gemm256_kernel(const G256Dev p) {
     const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
     v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
-  const int tile_n = v % p.tiles_n, tile_m = v / p.tiles_n;
+  int tile_m, tile_n;
+  g256_tile(p, v, tile_m, tile_n);
   const int m0 = tile_m * 256, n0 = tile_n * 256;
   const int steps = p.K >> 5;
 
@@ -203,7 +219,8 @@ __global__ __launch_bounds__(1024) void gemm256l_kernel(const G256Dev p) {
     const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
     v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
-  const int tile_n = v % p.tiles_n, tile_m = v / p.tiles_n;
+  int tile_m, tile_n;
+  g256_tile(p, v, tile_m, tile_n);
   const int m0 = tile_m * 256, n0 = tile_n * 256;
   const int steps = p.K >> 6;
   // wave w fills tile w (16 rows) of both operands: two requests of 8 rows x 128 bytes each
@@ -284,6 +301,13 @@ int launch_gemm256(const IgemmArgs& a, DType dtype, hipStream_t stream) {
   d.M = (int)M; d.N = a.N; d.K = a.Cin; d.ldx = a.ldx; d.ldw = a.ldw; d.ldy = (int)a.c_pix;
   d.tiles_n = a.N / 256;
   d.flags = a.flags;
+  d.tiles_m = cdiv(M, 256);
+  {  // N-tile groups whose weight slabs (gn x 256 rows x K bf16) stay within ~2.5 MB of the 4 MB L2 of an XCD; IVG_G256_GROUP=0: one group
+    const bool grouped = [] { const char* v = getenv("IVG_G256_GROUP"); return !(v && v[0] == '0'); }();
+    const long slab = 256L * d.K * 2;
+    long gn = grouped ? (5L << 19) / slab : d.tiles_n;
+    d.gn = (int)std::max(1L, std::min<long>(gn, d.tiles_n));
+  }
   const int smem = 256 * G256_PITCH > G256_STAGES * G256_STAGE ? 256 * G256_PITCH : G256_STAGES * G256_STAGE;
   // IVG_G256_PAIR=1: two K steps per barrier -- measured, no change (rollout 147.3-147.9 ms either way, profiles/r02_gemm256_pair.txt)
   const bool pair = [] { const char* v = getenv("IVG_G256_PAIR"); return v && v[0] == '1'; }();   // (read per launch: the test flips it)
