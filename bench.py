@@ -125,7 +125,8 @@ KERNEL_NAMES = {
     "conv3x3": "ivg::conv3x3_kernel (LDS-halo 3x3 convolution, MFMA)",
     "igemm": "ivg::gemm256_kernel + ivg::igemm_kernel<128,128,64> (dense GEMMs / implicit-GEMM convs other than 3x3, MFMA)",
 }
-PMC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+TRACE_FILES = ("r03_kernel_trace_classes.json",)
 
 
 def _pmc_traffic(name):
@@ -138,6 +139,20 @@ def _pmc_traffic(name):
                 v = json.load(f)["per_launch_bytes"].get(name)
             if v is not None:
                 return v, "profiles/" + fn
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
+def _trace_mean_us(name):
+    """Mean launch duration of a kernel class on the PROFILER's clock (rocprofv3 --kernel-trace of this command, committed under
+    profiles/; includes the dispatch the kernels' own stamps do not see) -- NOT measured in this run."""
+    for fn in TRACE_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", fn)) as f:
+                v = json.load(f)["classes"].get(name)
+            if v:
+                return v["mean_us"], "profiles/" + fn
         except (OSError, KeyError, ValueError):
             continue
     return None, None
@@ -158,7 +173,12 @@ def rooflines(kstats, a):
         if name in ("decode_attn", "decode_gemm"):
             ach = s["total_bytes"] / sec / 1e9
             r = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
+                 "frac_clock": "launch window stamped by the kernel itself on the 100 MHz wall clock (first workgroup start -> last end; no dispatch)",
                  "algorithmic_bytes_per_launch": s["total_bytes"] / s["launches"]}
+            mean_us, src = _trace_mean_us(name)
+            if mean_us:   # the same bytes over the profiler's mean duration (what profiles/ shows): both clocks, side by side
+                r["frac_rocprof"] = s["total_bytes"] / s["launches"] / (mean_us * 1e-6) / 1e9 / PEAK_HBM_GBS
+                r["frac_rocprof_source"] = src + " (rocprofv3 --kernel-trace mean of this class, committed; not this run)"
         else:
             ach = s["total_flops"] / sec / 1e12
             r = {"bound": "mfma", "achieved": ach, "peak": peak_f, "unit": "TFLOP/s", "frac": ach / peak_f,

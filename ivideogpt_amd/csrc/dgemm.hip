@@ -32,6 +32,8 @@ struct DgDev {
   int nburst;   // bursts of 8 * LG chunks per wave
   unsigned long long* prof; const int* pos; int prof_ld;
   long long* dbg;   // development (tools/ubench/dgemm_phase.hip): per (workgroup, wave) phase stamps, null in production
+  // L2 warm-up of the next launch's weights (same scheme as dgemm3.hip): tile t of pf_tile_bytes is read by XCD t % 8
+  const char* pf_base; unsigned pf_tile_bytes; int pf_tiles; int pf_per_wave;
 };
 
 // LDS-DMA with the address split the way the hardware takes it: wave-uniform 64-bit base (scalar registers, advanced per burst /
@@ -198,6 +200,21 @@ __global__ __launch_bounds__(WMAX * 64) void dgemm_kernel(const DgDev p) {
     }
   }
 
+  // ---- L2 warm-up of the next launch's weight tiles (this wave's share of the tiles its XCD will read): the requests travel
+  // while this launch combines and stores and are waited for at the very end (round 3; see dgemm3.hip)
+  Chunk16 pf_sink = Chunk16{0u, 0u, 0u, 0u};
+  if (p.pf_per_wave > 0) {
+    const int Lb = blockIdx.y * gridDim.x + blockIdx.x, x = Lb & 7, q = Lb >> 3;
+    const unsigned upt = p.pf_tile_bytes >> 10;
+    const unsigned total = (unsigned)((p.pf_tiles - x + 7) >> 3) * upt;
+    unsigned v = ((unsigned)q * (unsigned)waves + (unsigned)wave) * (unsigned)p.pf_per_wave;
+    for (int i = 0; i < p.pf_per_wave; ++i, ++v) {
+      if (v >= total) break;
+      const unsigned j = v / upt, off = v - j * upt;
+      const char* src = p.pf_base + (size_t)(x + 8 * j) * p.pf_tile_bytes + (size_t)off * 1024 + lane * 16;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(pf_sink) : "v"(src) : "memory");
+    }
+  }
   // ---- combine the waves' K slices (fixed order w = 0 .. waves-1); the combine area aliases the staging areas
   stamp(4);
   __syncthreads();
@@ -287,6 +304,10 @@ __global__ __launch_bounds__(WMAX * 64) void dgemm_kernel(const DgDev p) {
     }
   }
   stamp(7);
+  if (p.pf_per_wave > 0) {   // the warm-up requests name a register: it stays reserved until they have all returned
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" ::"v"(pf_sink));
+  }
   if (dbg && lane == 0) dbg[9] = (long long)wall_clock64();
   if (p.prof && tid == 0) {
     unsigned long long* slot = p.prof + (size_t)((blockIdx.x * 7 + blockIdx.y) % IVG_GEMM_PROF_SLOTS) * 2 * p.prof_ld;
@@ -369,6 +390,14 @@ static int launch_dg_t(const DgDev& d, int MF, int FN, int waves, hipStream_t st
   return -1;
 }
 
+// rows of W one workgroup owns for this GEMM (what a predecessor's L2 warm-up mirrors): the pick table, else the default tile
+int dgemm_w_rows_per_block(const SkinnyArgs& a, DType dtype) {
+  const int es = dtype == BF16 ? 2 : 4;
+  if (a.splits > 1 || ((long)a.K * es) % 128 != 0) return 0;
+  for (const DgPick& k : kDgPicks) if (k.kbytes == a.K * es && k.N == a.N) return 16 * k.fn;
+  return 16 * ((a.flags & IG_GLU) ? 2 : 1);
+}
+
 // -1: shape not covered (caller falls back to skinny.hip); otherwise a hipError_t
 int launch_dgemm(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
   {
@@ -432,7 +461,18 @@ int launch_dgemm(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
     nburst = total / lgv;
   }
   while (MF > 1 && waves * lgv * (MF + FN) * 2048 > 160 * 1024) MF >>= 1;
-  DgDev d{a.X, a.W, a.Y, a.M, a.N, a.K, a.ldx, a.ldw, a.ldy, a.flags, a.eps, a.bump, nburst, a.pos ? a.prof : nullptr, a.pos, a.prof_ld, a.dbg};
+  DgDev d{a.X, a.W, a.Y, a.M, a.N, a.K, a.ldx, a.ldw, a.ldy, a.flags, a.eps, a.bump, nburst, a.pos ? a.prof : nullptr, a.pos, a.prof_ld, a.dbg,
+          nullptr, 0u, 0, 0};
+  static const bool pf_off = [] { const char* v = getenv("IVG_DG3_WARM"); return v && v[0] == '0'; }();
+  if (a.next_W && a.next_tile_bytes >= 1024 && a.next_tiles > 0 && !pf_off) {
+    const long grid = (long)cdiv(a.N, 16 * FN) * cdiv(a.M, 16 * MF);
+    const long waves_per_xcd = std::max(1L, grid / 8) * waves;
+    const long units_per_xcd = (long)cdiv(a.next_tiles, 8) * (a.next_tile_bytes >> 10);
+    long per = (units_per_xcd + waves_per_xcd - 1) / waves_per_xcd;
+    static const int cap = [] { const char* v = getenv("IVG_DG3_WARM_CAP"); return v ? atoi(v) : 8; }();
+    if (per > cap) per = cap;
+    d.pf_base = (const char*)a.next_W; d.pf_tile_bytes = (unsigned)a.next_tile_bytes; d.pf_tiles = a.next_tiles; d.pf_per_wave = (int)per;
+  }
   int rc;
   if (dtype == BF16) rc = lgv == 3 ? launch_dg_t<bf16_t, 3>(d, MF, FN, waves, stream) : lgv == 2 ? launch_dg_t<bf16_t, 2>(d, MF, FN, waves, stream)
                                                                                      : launch_dg_t<bf16_t, 1>(d, MF, FN, waves, stream);

@@ -365,6 +365,16 @@ static const Dg3Pick kDg3Picks[] = {
     {8192, 1024, 1, 1},    // medium: down
 };
 
+// GEMMs of the released transformers that measure FASTER on the second-generation kernel inside the layer chain
+// (tools/ubench/dgemm_phase with GENMASK, profiles/r03_dgemm_generation_per_gemm.txt: small 40.03 vs 40.75 us per layer with the
+// o-proj on dgemm.hip; medium 50.98 vs 53.54 with o-proj and gate/up there): keyed by (K bytes, N) like every other decision
+struct Dg3Skip { int kbytes, N; };
+static const Dg3Skip kDg3Skip[] = {
+    {1536, 768},     // small: o-proj (a 1.2 MB GEMM: 4 waves x 3 lines beat 12 waves x 1 line)
+    {2048, 1024},    // medium: o-proj
+    {2048, 8192},    // medium: gate/up (does not fit one round of workgroups with everything in flight: 16 waves x 12 KiB)
+};
+
 struct Dg3Plan { int mf, fn, waves, klw, ring; unsigned wave_bytes; };
 
 // shape -> launch plan; false: not covered (the caller falls back to dgemm.hip / skinny.hip).  Coverage and the K partition
@@ -379,6 +389,9 @@ static bool dg3_plan(const SkinnyArgs& a, DType dtype, Dg3Plan& pl) {
   if (glu && a.N % 32 != 0) return false;
   if (a.N < 4) return false;
   if ((a.flags & IG_RESIDUAL) && !(a.flags & IG_OUT_F32) && ((a.ldy & 3) != 0 || ((uintptr_t)a.Y & (4 * es - 1)) || (a.N & 3))) return false;
+  static const bool no_skip = [] { const char* v = getenv("IVG_DG3_ALL"); return v && v[0] == '1'; }();   // IVG_DG3_ALL=1: ignore kDg3Skip (A/B)
+  if (!no_skip)
+    for (const Dg3Skip& k : kDg3Skip) if (k.kbytes == a.K * es && k.N == a.N) return false;
   const long lines = (long)a.K * es / 128;
   int waves = dg3_waves(lines);
   if (!waves) return false;

@@ -90,5 +90,6 @@ int launch_dgemm(const SkinnyArgs& a, DType dtype, hipStream_t stream);
 // dgemm3.hip: third generation (K over up to 16 waves, one barrier, L2 warm-up of the next launch's weights); -1 when not covered
 int launch_dgemm3(const SkinnyArgs& a, DType dtype, hipStream_t stream);
 int dgemm3_w_rows_per_block(const SkinnyArgs& a, DType dtype);   // rows of W per workgroup of that plan (0: not covered)
+int dgemm_w_rows_per_block(const SkinnyArgs& a, DType dtype);    // the same for the second-generation kernel (0: not covered)
 
 }  // namespace ivg

@@ -549,11 +549,15 @@ __device__ unsigned long long g_attn_dbg[2][8];
 // NT: non-temporal loads of the cache rows (streamed once per step: keep them from evicting the weights)
 // HD: head dimension as a compile-time value (64 for the released transformers; 0 = generic, read from the argument) -- with it
 // the lane-group reductions, the group counts and the row strides are constants instead of chains of scalar branches per chunk
-template <typename T, bool NT, int HD>
+// PRE2: two value blocks in flight across the softmax statistics (measured slower, see launch_decode_attn) -- a template
+// parameter, not a runtime switch: as a runtime branch the second path raised the kernel from 106 to 156 registers, one
+// workgroup per CU less for the 1,024 (trajectory, head) pairs of the medium transformer (config 5 rollout 753 -> 800 ms).
+template <typename T, bool NT, int HD, bool PRE2>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
                                                           T* __restrict__ out, const float* __restrict__ cosT,
                                                           const float* __restrict__ sinT, int heads, int hd_arg, int Lmax,
-                                                          const StepState* __restrict__ state, unsigned long long* prof, int pre2) {
+                                                          const StepState* __restrict__ state, unsigned long long* prof) {
+  constexpr bool pre2 = PRE2;
   constexpr int VEC = Traits<T>::VEC;
   const int hd = HD > 0 ? HD : hd_arg;
   constexpr int UNR = 8;   // 16-byte loads in flight per lane: 3 workgroups x 256 lanes x 8 x 16 B = 96 KiB per CU
@@ -752,8 +756,10 @@ int launch_decode_attn(const void* qkv, void* kc, void* vc, void* out, const flo
   // non-temporal cache-row loads: 5.57 -> 6.28 TB/s on a pure stream, 203 -> 191 ms per rollout (IVG_ATTN_NT=0: plain loads, A/B)
   static const bool nt = [] { const char* v = getenv("IVG_ATTN_NT"); return !(v && v[0] == '0'); }();
 #define IVG_DA(T, NTv, HDv)                                                                                                       \
-  hipLaunchKernelGGL((decode_attn_kernel<T, NTv, HDv>), g, dim3(256), smem, st, (const T*)qkv, (T*)kc, (T*)vc, (T*)out, cosT, sinT, heads, hd, \
-                     Lmax, state, prof, pre2)
+  do {                                                                                                                            \
+    if (pre2) hipLaunchKernelGGL((decode_attn_kernel<T, NTv, HDv, true>), g, dim3(256), smem, st, (const T*)qkv, (T*)kc, (T*)vc, (T*)out, cosT, sinT, heads, hd, Lmax, state, prof); \
+    else hipLaunchKernelGGL((decode_attn_kernel<T, NTv, HDv, false>), g, dim3(256), smem, st, (const T*)qkv, (T*)kc, (T*)vc, (T*)out, cosT, sinT, heads, hd, Lmax, state, prof); \
+  } while (0)
   // IVG_ATTN_PRE2=1: two value blocks in flight across the softmax statistics.  Measured (profiles/r03_attn_pre2_ab.txt): 64.3 vs
   // 61.2 ms per step of attention, rollout 150.4 vs 147.5 ms -- SLOWER: one block per workgroup already keeps 25 MB in flight
   // chip-wide, the second only deepens the HBM queues every workgroup then waits behind.  Off by default; the path is kept for A/B.

@@ -224,7 +224,8 @@ static int step_chain(ivg_engine* e, hipStream_t st, const GenBuf& g, int chain,
   // every launch also pulls the weight tiles of the NEXT launch of the chain into the XCD-local L2s (dgemm3.hip): the dependent
   // GEMM then starts on L2 hits instead of a cold HBM stream
   auto link_next = [&](SkinnyArgs& cur, const SkinnyArgs& nxt) {
-    const int rows = dgemm3_w_rows_per_block(nxt, dt);
+    int rows = dgemm3_w_rows_per_block(nxt, dt);
+    if (rows <= 0) rows = dgemm_w_rows_per_block(nxt, dt);   // the next launch runs on the second-generation kernel
     if (rows <= 0 || nxt.ldw != nxt.K) return;
     cur.next_W = nxt.W; cur.next_tile_bytes = (long)rows * nxt.K * (long)es; cur.next_tiles = nxt.N / rows;
   };

@@ -89,7 +89,7 @@ int main(int argc, char** argv) {
     if (which == 1) { s.X = attn; s.W = w.wo; s.Y = x; s.N = H; s.K = H; s.ldx = H; s.ldw = H; s.ldy = H; s.flags = IG_RESIDUAL; }
     if (which == 2) { s.X = x; s.W = w.wgu; s.Y = act; s.N = 2 * I; s.K = H; s.ldx = H; s.ldw = H; s.ldy = I; s.flags = IG_GLU | SK_NORM; }
     if (which == 3) { s.X = act; s.W = w.wdown; s.Y = x; s.N = H; s.K = I; s.ldx = I; s.ldw = I; s.ldy = H; s.flags = IG_RESIDUAL; }
-    if (gen == 3 && warm) {   // the next launch of the chain: o-proj, gate/up, down, q/k/v of the next layer
+    if (warm) {   // the next launch of the chain: o-proj, gate/up, down, q/k/v of the next layer
       SkinnyArgs n;
       n.M = M;
       const Layer& wn = which == 3 ? L[(l + 1) % layers] : w;
@@ -97,11 +97,15 @@ int main(int argc, char** argv) {
       if (which == 1) { n.W = wn.wgu; n.N = 2 * I; n.K = H; n.ldw = H; n.flags = IG_GLU | SK_NORM; n.ldy = I; n.Y = act; n.X = x; n.ldx = H; }
       if (which == 2) { n.W = wn.wdown; n.N = H; n.K = I; n.ldw = I; n.flags = IG_RESIDUAL; n.ldy = H; n.Y = x; n.X = act; n.ldx = I; }
       if (which == 3) { n.W = wn.wqkv; n.N = 3 * H; n.K = H; n.ldw = H; n.flags = SK_NORM; n.ldy = 3 * H; n.Y = qkv; n.X = x; n.ldx = H; }
-      const int rows = dgemm3_w_rows_per_block(n, BF16);
+      int rows = dgemm3_w_rows_per_block(n, BF16);
+      if (rows <= 0) rows = dgemm_w_rows_per_block(n, BF16);
       if (rows > 0) { s.next_W = n.W; s.next_tile_bytes = (long)rows * n.K * 2; s.next_tiles = n.N / rows; }
     }
-    const int rc = gen == 3 ? launch_dgemm3(s, BF16, st) : launch_dgemm(s, BF16, st);
-    if (rc != 0) { fprintf(stderr, "launch (generation %d, GEMM %d) -> %d\n", gen, which, rc); exit(1); }
+    const char* gm = getenv("GENMASK");   // per-GEMM generation, e.g. GENMASK=3323: gate/up on the second-generation kernel
+    const int g_this = gm && strlen(gm) == 4 ? gm[which] - '0' : gen;
+    int rc = g_this == 3 ? launch_dgemm3(s, BF16, st) : -1;   // (-1: not covered / on the skip list -> second generation, as launch_skinny does)
+    if (rc == -1) rc = launch_dgemm(s, BF16, st);
+    if (rc != 0) { fprintf(stderr, "launch (generation %d, GEMM %d) -> %d\n", g_this, which, rc); exit(1); }
   };
   int rot = 0;
   auto layer = [&](int l, unsigned mask, bool stream, long long* d) {
@@ -136,7 +140,8 @@ int main(int argc, char** argv) {
       if (which == 1) { a.X = cattn[c]; a.W = w.wo; a.Y = cx[c]; a.N = H; a.K = H; a.ldx = H; a.ldw = H; a.ldy = H; a.flags = IG_RESIDUAL; }
       if (which == 2) { a.X = cx[c]; a.W = w.wgu; a.Y = cact[c]; a.N = 2 * I; a.K = H; a.ldx = H; a.ldw = H; a.ldy = I; a.flags = IG_GLU | SK_NORM; }
       if (which == 3) { a.X = cact[c]; a.W = w.wdown; a.Y = cx[c]; a.N = H; a.K = I; a.ldx = I; a.ldw = I; a.ldy = H; a.flags = IG_RESIDUAL; }
-      const int rc = gen == 3 ? launch_dgemm3(a, BF16, cs[c]) : launch_dgemm(a, BF16, cs[c]);
+      int rc = gen == 3 ? launch_dgemm3(a, BF16, cs[c]) : -1;
+      if (rc == -1) rc = launch_dgemm(a, BF16, cs[c]);
       if (rc != 0) { fprintf(stderr, "chain launch -> %d\n", rc); exit(1); }
     };
     auto chain_layer = [&](int c, int l, int r, bool gemms, bool stream) {
@@ -183,7 +188,7 @@ int main(int argc, char** argv) {
   };
   const char* names[4] = {"q/k/v", "o-proj", "gate/up", "down"};
   const float all_s = time_chain(15, true, 8), all = time_chain(15, false, 8), str = time_chain(0, true, 8);
-  printf("generation %d%s, IVG_DG3_FORCE=%s: ", gen, gen == 3 ? (warm ? " + L2 warm-up" : ", no warm-up") : "", getenv("IVG_DG3_FORCE") ? getenv("IVG_DG3_FORCE") : "-");
+  printf("GENMASK=%s generation %d%s, IVG_DG3_FORCE=%s: ", getenv("GENMASK") ? getenv("GENMASK") : "-", gen, gen == 3 ? (warm ? " + L2 warm-up" : ", no warm-up") : "", getenv("IVG_DG3_FORCE") ? getenv("IVG_DG3_FORCE") : "-");
   printf("%s transformer, M = %d: layer chain %.2f us (4 GEMMs + streamer), streamer alone %.2f, 4 GEMMs alone %.2f us per layer\n",
          medium ? "medium" : "small", M, all_s, str, all);
   for (int k = 0; k < 4; ++k) {
