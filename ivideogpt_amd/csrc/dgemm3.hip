@@ -366,11 +366,11 @@ static const Dg3Pick kDg3Picks[] = {
 };
 
 // GEMMs of the released transformers that measure FASTER on the second-generation kernel inside the layer chain
-// (tools/ubench/dgemm_phase with GENMASK, profiles/r03_dgemm_generation_per_gemm.txt: small 40.03 vs 40.75 us per layer with the
-// o-proj on dgemm.hip; medium 50.98 vs 53.54 with o-proj and gate/up there): keyed by (K bytes, N) like every other decision
+// (tools/ubench/dgemm_phase with GENMASK, profiles/r03_dgemm_generation_per_gemm.txt: medium 50.98 vs 53.54 us per layer with
+// o-proj and gate/up on dgemm.hip; the small transformer's o-proj measured 40.03 vs 40.75 there in the harness but 51.6 vs 49.6 ms
+// of decode-GEMM time per step in the engine -- it stays on this kernel): keyed by (K bytes, N) like every other decision
 struct Dg3Skip { int kbytes, N; };
 static const Dg3Skip kDg3Skip[] = {
-    {1536, 768},     // small: o-proj (a 1.2 MB GEMM: 4 waves x 3 lines beat 12 waves x 1 line)
     {2048, 1024},    // medium: o-proj
     {2048, 8192},    // medium: gate/up (does not fit one round of workgroups with everything in flight: 16 waves x 12 KiB)
 };
