@@ -32,7 +32,7 @@ struct DgDev {
   int nburst;   // bursts of 8 * LG chunks per wave
   unsigned long long* prof; const int* pos; int prof_ld;
   long long* dbg;   // development (tools/ubench/dgemm_phase.hip): per (workgroup, wave) phase stamps, null in production
-  // L2 warm-up of the next launch's weights (same scheme as dgemm3.hip): tile t of pf_tile_bytes is read by XCD t % 8
+  // cache warm-up of the next launch's weights (same scheme as dgemm3.hip): tile t of pf_tile_bytes is read by XCD t % 8
   const char* pf_base; unsigned pf_tile_bytes; int pf_tiles; int pf_per_wave;
 };
 
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(WMAX * 64) void dgemm_kernel(const DgDev p) {
     }
   }
 
-  // ---- L2 warm-up of the next launch's weight tiles (this wave's share of the tiles its XCD will read): the requests travel
+  // ---- cache warm-up of the next launch's weight tiles (this wave's share of the tiles its XCD will read): the requests travel
   // while this launch combines and stores and are waited for at the very end (round 3; see dgemm3.hip)
   Chunk16 pf_sink = Chunk16{0u, 0u, 0u, 0u};
   if (p.pf_per_wave > 0) {
@@ -390,7 +390,7 @@ static int launch_dg_t(const DgDev& d, int MF, int FN, int waves, hipStream_t st
   return -1;
 }
 
-// rows of W one workgroup owns for this GEMM (what a predecessor's L2 warm-up mirrors): the pick table, else the default tile
+// rows of W one workgroup owns for this GEMM (what a predecessor's cache warm-up mirrors): the pick table, else the default tile
 int dgemm_w_rows_per_block(const SkinnyArgs& a, DType dtype) {
   const int es = dtype == BF16 ? 2 : 4;
   if (a.splits > 1 || ((long)a.K * es) % 128 != 0) return 0;

@@ -11,10 +11,15 @@
 //     own fragment reads have left the slot (no workgroup barrier, the request queue never drains);
 //   * ONE barrier: a wave parks its partial tile in its own (now idle) staging region, fixed-order combine fully unrolled,
 //     RMSNorm partial sums ride along as plain LDS rows (no cross-lane shuffles), 1/K comes from the host;
-//   * the weight tiles of the NEXT launch of the chain are pulled into the XCD-local L2 while this launch is busy with its
-//     own combine / epilogue (block b -> XCD b % 8 as observed; a wrong guess only loses the benefit): the dependent launch then
-//     starts on L2 hits instead of cold HBM (profiles/r03_l2warm.txt: 9.4 MB of weights 3.7 -> 2.4 us, also across the
-//     124 MB non-temporal KV stream of the attention in between).
+//   * cache warm-up: the weight tiles of the NEXT launch of the chain are requested while this launch is busy with its own
+//     combine / epilogue, each tile by a workgroup of the XCD that will consume it (block b -> XCD b % 8: verified on every launch
+//     with HW_REG_XCC_ID, tools/ubench/dgemm_phase).  The dependent launch then starts on cache hits instead of a cold HBM stream
+//     (consume-only micro-benchmark, profiles/r03_l2warm.txt: 9.4 MB of weights 3.7 -> 2.4 us, also across the 124 MB non-temporal
+//     KV stream of the attention in between; layer chain 41.3 -> 40.1 us).  WHICH cache: the PMC pass (profiles/r03_warmup_pmc.txt)
+//     shows the consumer's FETCH_SIZE unchanged -- its requests still leave the L2, with non-temporal and default-policy loads
+//     alike -- so the lines do not survive the kernel boundary in the XCD's L2; what the consumer hits is the memory-side
+//     Infinity Cache.  The counter therefore shows every weight byte twice (2.4 x the algorithmic bytes of the class): once
+//     from HBM under the predecessor, once from the Infinity Cache on the critical path.
 // Same contracts as dgemm.hip: fixed K partition per (K bytes, N) -- never per batch --, fixed-order sums, epilogues RMSNorm row
 // scale (weight folded into W), in-place residual, SiLU(gate)*up, fp32 out, step-counter advance; whole-line LDS-DMA operands
 // with the source-side chunk permutation that makes the lane-linear LDS image conflict-free to read back as MFMA fragments.
@@ -35,10 +40,11 @@ struct Dg3Dev {
   int ring;                 // slots of the wave's staging ring (1: klw == 1 or no room; 2: continuous stream)
   unsigned wave_bytes;      // LDS bytes per wave (ring * line bytes)
   int flags;
+  int w_nt;                  // weights by non-temporal requests (streamed once per step) or default-policy ones
   float inv_k, eps;
   int* bump;
   unsigned long long* prof; const int* pos; int prof_ld;
-  // L2 warm-up of the next launch's weights: [tile][rows][K] contiguous tiles of pf_tile_bytes, tile t is read by XCD t % 8
+  // cache warm-up of the next launch's weights: [tile][rows][K] contiguous tiles of pf_tile_bytes, tile t is read by XCD t % 8
   const char* pf_base; unsigned pf_tile_bytes; int pf_tiles; int pf_per_wave;
   long long* dbg;
 };
@@ -70,7 +76,10 @@ __global__ __launch_bounds__(WAVES * 64) void dg3_kernel(const Dg3Dev p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   long long* dbg = p.dbg ? p.dbg + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + wave) * 16 : nullptr;
   auto stamp = [&](int i) { if (dbg && lane == 0) dbg[i] = (long long)__builtin_readcyclecounter(); };
-  if (dbg && lane == 0) dbg[8] = (long long)wall_clock64();
+  if (dbg && lane == 0) {
+    dbg[8] = (long long)wall_clock64();
+    dbg[10] = (long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7);   // HW_REG_XCC_ID: the XCD this workgroup really runs on
+  }
   stamp(0);
   const int lr = lane & 15, lg = lane >> 4;
   const int n_tile = blockIdx.x * 16 * FN, m_tile = blockIdx.y * 16 * MF;
@@ -100,10 +109,17 @@ __global__ __launch_bounds__(WAVES * 64) void dg3_kernel(const Dg3Dev p) {
     for (int b = 0; b < MF; ++b)
 #pragma unroll
       for (int h = 0; h < 2; ++h) dg3_dma16(Xw + (size_t)line * 128, xoff[b][h], base + (b * 2 + h) * 1024);
+    if (p.w_nt) {
 #pragma unroll
-    for (int a = 0; a < FN; ++a)
+      for (int a = 0; a < FN; ++a)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) dg3_dma16_nt(Ww + (size_t)line * 128, woff[a][h], base + ((MF + a) * 2 + h) * 1024);
+        for (int h = 0; h < 2; ++h) dg3_dma16_nt(Ww + (size_t)line * 128, woff[a][h], base + ((MF + a) * 2 + h) * 1024);
+    } else {
+#pragma unroll
+      for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) dg3_dma16(Ww + (size_t)line * 128, woff[a][h], base + ((MF + a) * 2 + h) * 1024);
+    }
   };
   // ---- residual rows of the fragments this wave will finalise: requested FIRST, consumed after the K reduction.  Register-
   // destination loads share the counter with the LDS-DMA queue and requests return in order: being the OLDEST entries they never
@@ -198,7 +214,7 @@ __global__ __launch_bounds__(WAVES * 64) void dg3_kernel(const Dg3Dev p) {
   }
   stamp(4);   // (the last line's wait was vmcnt(0): the residual rows are here as well)
 
-  // ---- L2 warm-up of the next launch's weight tiles (this wave's share of the tiles its XCD will read); the requests travel
+  // ---- cache warm-up of the next launch's weight tiles (this wave's share of the tiles its XCD will read); the requests travel
   // while this launch combines and stores, and are waited for at the very end
   Chunk16 pf_sink = Chunk16{0u, 0u, 0u, 0u};
   if (p.pf_per_wave > 0) {
@@ -450,6 +466,8 @@ int launch_dgemm3(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
   d.ldxb = (unsigned)a.ldx * es; d.ldwb = (unsigned)a.ldw * es; d.ldy = a.ldy;
   d.klw = pl.klw; d.ring = pl.ring; d.wave_bytes = pl.wave_bytes; d.flags = a.flags;
   d.inv_k = 1.0f / (float)a.K; d.eps = a.eps; d.bump = a.bump;
+  static const int w_nt = [] { const char* v = getenv("IVG_DG3_NT"); return (v && v[0] == '0') ? 0 : 1; }();   // IVG_DG3_NT=0: default-policy weight requests (A/B)
+  d.w_nt = w_nt;
   d.prof = a.pos ? a.prof : nullptr; d.pos = a.pos; d.prof_ld = a.prof_ld;
   d.dbg = a.dbg;
   static const bool pf_off = [] { const char* v = getenv("IVG_DG3_WARM"); return v && v[0] == '0'; }();   // IVG_DG3_WARM=0: no L2 warm-up (A/B runs)

@@ -77,7 +77,7 @@ struct SkinnyArgs {
   const int* pos = nullptr;
   int prof_ld = 0;
   long long* dbg = nullptr;   // development: phase stamps of the second / third-generation kernel (tools/ubench/dgemm_phase.hip)
-  // L2 warm-up (dgemm3.hip): the weight matrix the NEXT launch of the chain streams, as next_tiles contiguous tiles of
+  // cache warm-up (dgemm3.hip): the weight matrix the NEXT launch of the chain streams, as next_tiles contiguous tiles of
   // next_tile_bytes (= rows one workgroup of that launch owns x K bytes); tile t is pulled by a workgroup of XCD t % 8
   const void* next_W = nullptr;
   long next_tile_bytes = 0;
@@ -87,7 +87,7 @@ struct SkinnyArgs {
 int launch_skinny(const SkinnyArgs& a, DType dtype, hipStream_t stream);
 // dgemm.hip: the same contract with the activations staged as whole cache lines; -1 when the shape is not covered
 int launch_dgemm(const SkinnyArgs& a, DType dtype, hipStream_t stream);
-// dgemm3.hip: third generation (K over up to 16 waves, one barrier, L2 warm-up of the next launch's weights); -1 when not covered
+// dgemm3.hip: third generation (K over up to 16 waves, one barrier, cache warm-up of the next launch's weights); -1 when not covered
 int launch_dgemm3(const SkinnyArgs& a, DType dtype, hipStream_t stream);
 int dgemm3_w_rows_per_block(const SkinnyArgs& a, DType dtype);   // rows of W per workgroup of that plan (0: not covered)
 int dgemm_w_rows_per_block(const SkinnyArgs& a, DType dtype);    // the same for the second-generation kernel (0: not covered)

@@ -221,8 +221,8 @@ static int step_chain(ivg_engine* e, hipStream_t st, const GenBuf& g, int chain,
     if (!e->gemm_prof_on || !e->gemm_prof) return;
     a.prof = e->gemm_prof + (size_t)idx * gp_ld; a.pos = (const int*)state; a.prof_ld = e->Lmax;
   };
-  // every launch also pulls the weight tiles of the NEXT launch of the chain into the XCD-local L2s (dgemm3.hip): the dependent
-  // GEMM then starts on L2 hits instead of a cold HBM stream
+  // every launch also pulls the weight tiles of the NEXT launch of the chain toward the CUs that will consume them (dgemm3.hip): the
+  // dependent GEMM then starts on (Infinity-)cache hits instead of a cold HBM stream
   auto link_next = [&](SkinnyArgs& cur, const SkinnyArgs& nxt) {
     int rows = dgemm3_w_rows_per_block(nxt, dt);
     if (rows <= 0) rows = dgemm_w_rows_per_block(nxt, dt);   // the next launch runs on the second-generation kernel

@@ -214,6 +214,11 @@ int main(int argc, char** argv) {
     }
     printf("%s: %zu workgroups x %d waves; launch window %.2f us (first start -> last end), starts spread %.2f us, ends spread %.2f us\n", names[k], wgs.size(),
            maxw, (w1 - w0) * 0.01, (s_last - w0) * 0.01, (w1 - e_first) * 0.01);
+    {   // does block b run on XCD b % 8 (what the L2 warm-up assumes)?  dbg[10] = HW_REG_XCC_ID (third generation only)
+      int match = 0, seen = 0;
+      for (int wg : wgs) { const long long* r = d + ((size_t)wg * 16) * 16; if (r[8]) { ++seen; match += (int)(r[10] == (wg & 7)); } }
+      printf("    workgroups whose XCC_ID equals block %% 8: %d of %d\n", match, seen);
+    }
     printf("    cycles from the wave's entry (min / median / max over workgroups and waves):\n");
     for (int i = 1; i < 8; ++i) {
       std::vector<long long> v;
