@@ -100,14 +100,14 @@ template <int N> __device__ __forceinline__ void wait_dma_keep() {   // all DMA 
 // under the taps of the previous chunk, so the normalised tensor never exists in HBM.  ON by default
 // (tokenizer.cpp: norm_conv; IVG_GN_APPLY_FUSE=0 restores the separate apply pass): -2.2 ms per config-2 step with the
 // rebuilt loop (profiles/r02_gn_apply_fusion_ab.txt; the same fusion cost +2.5 ms while the loop was instruction-bound).
+// Round 3 measured two re-arrangements of the transform and kept neither: pair-by-pair / recomputed lane maps to get rid of
+// the five spilled registers of the bf16 x 128-channel instances (the compiler spills elsewhere: 20 -> 20 / 272 bytes), and a
+// schedule staggered over the taps and the two waves of a SIMD (waves 0-3 at taps 2, 4, 6, waves 4-7 at 3, 5, 7: 39.4-39.9 vs
+// 38.6 ms of conv3x3 per step, profiles/r03_conv3x3_stagger_ab.txt).
 // TPB2: two (tap, chunk) steps per workgroup barrier -- the weight ring holds two slots of two tiles and is refilled one PAIR of
 // steps ahead, the fragment registers are reused by the second step; 80 KiB of LDS, still two workgroups per CU.
 // (Reading the halo fragments of step s + 1 under the MFMAs of step s was measured: +-0.5 %, removed.)
-// STG (GNA only): the in-place normalisation of the next chunk's halo pieces is STAGGERED over the taps and the two waves of a
-// SIMD -- waves 0-3 transform piece i at tap 2 + 2 i, waves 4-7 at tap 3 + 2 i -- instead of all eight waves at taps 4 .. 4 + HI - 1:
-// ~200 vector instructions per piece and wave (two transcendentals per element) then sit beside the partner wave's MFMAs
-// instead of stalling both matrix feeders of every SIMD at the same time.
-template <typename T, int BN, bool UPS, int TW, bool GNA, bool TPB2, bool STG = false>
+template <typename T, int BN, bool UPS, int TW, bool GNA, bool TPB2>
 __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
   constexpr int VEC = Traits<T>::VEC;
   constexpr int CK = 4 * VEC;              // channels per chunk: one 64-byte LDS row per halo pixel (one MFMA K-step)
@@ -315,18 +315,9 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
       if constexpr (GNA) {
         if (more) {
           if (tap == 0) issued += load_coef(chunk + 1);
-          // piece `it` of the next chunk was requested at tap `it` and has landed by the end of tap `it + 1` (so have the
-          // coefficients requested at tap 0): normalise it at tap 4 + it -- or, staggered, at tap 2 + 2 it (+ 1 for waves 4-7) --
-          // visible to everyone after that step's barrier, before the chunk's first tap
-          if constexpr (STG) {
-            static_assert(HI <= 3, "stagger schedule: piece i at tap 2 + 2 i + group <= 7");
-            if (tap >= 2 && tap <= 7) {
-              const int sg = (tap - 2) & 1, sit = (tap - 2) >> 1;   // (constants after unrolling)
-              if (sit < HI && (wave >> 2) == sg) transform_piece(chunk + 1, sit, hb_next);
-            }
-          } else {
-            if (tap >= 4 && tap - 4 < HI) transform_piece(chunk + 1, tap - 4, hb_next);
-          }
+          // piece `it` of the next chunk was requested at tap `it` and has landed by the end of tap `it + 1`: normalise it at
+          // tap 4 + it (visible to everyone after that step's barrier, long before the chunk's first tap)
+          if (tap >= 4 && tap - 4 < HI) transform_piece(chunk + 1, tap - 4, hb_next);
         }
       }
       if (!GNA && !early) issue_dma();
@@ -543,7 +534,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
   }
 }
 
-template <typename T, int BN, bool UPS, int TW, bool GNA, bool TPB2, bool STG = false>
+template <typename T, int BN, bool UPS, int TW, bool GNA, bool TPB2>
 static int launch_c3(const Conv3Dev& d, int nimg, hipStream_t stream) {
   constexpr int TH = 256 / TW;
   constexpr int HROWS = (UPS ? TH / 2 + 2 : TH + 2) * (UPS ? TW / 2 + 2 : TW + 2);
@@ -559,7 +550,7 @@ static int launch_c3(const Conv3Dev& d, int nimg, hipStream_t stream) {
   if (d.gn_part) { dd.gn_off = dd.stage_ok ? ((stage + 15) & ~15) : 0; smem = std::max(smem, dd.gn_off + 2 * 4 * BN * 4); }
   if constexpr (GNA) { dd.coef_off = (smem + 15) & ~15; smem = dd.coef_off + 2 * (4 * Traits<T>::VEC) * 8; }
   static unsigned long long attr_set = 0;
-  auto kfn = conv3x3_kernel<T, BN, UPS, TW, GNA, TPB2, STG>;
+  auto kfn = conv3x3_kernel<T, BN, UPS, TW, GNA, TPB2>;
   if (first_time_on_device(attr_set)) {
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
@@ -616,14 +607,7 @@ int launch_conv3x3(const IgemmArgs& a, DType dtype, hipStream_t stream) {
   if (tpb < 0) { const char* e = getenv("IVG_C3_TPB"); tpb = e ? atoi(e) : 2; }
 #define IVG_C3_TW(T, BNv, U, G, PR) (TW == 16 ? launch_c3<T, BNv, U, 16, G, PR>(d, a.Nimg, stream) : launch_c3<T, BNv, U, 32, G, PR>(d, a.Nimg, stream))
 #define IVG_C3_BN(T, U, G, PR) (bn == 128 ? IVG_C3_TW(T, 128, U, G, PR) : IVG_C3_TW(T, 64, U, G, PR))
-  if (gna) {
-    // IVG_C3_STAGGER=1: staggered in-place GroupNorm transform (bf16 instances; A/B)
-    static const bool stg = [] { const char* e = getenv("IVG_C3_STAGGER"); return e && e[0] == '1'; }();
-#define IVG_C3_TWS(T, BNv) (TW == 16 ? launch_c3<T, BNv, false, 16, true, false, true>(d, a.Nimg, stream) : launch_c3<T, BNv, false, 32, true, false, true>(d, a.Nimg, stream))
-    if (stg && dtype == BF16) return bn == 128 ? IVG_C3_TWS(bf16_t, 128) : IVG_C3_TWS(bf16_t, 64);
-#undef IVG_C3_TWS
-    return dtype == BF16 ? IVG_C3_BN(bf16_t, false, true, false) : IVG_C3_BN(float, false, true, false);
-  }
+  if (gna) return dtype == BF16 ? IVG_C3_BN(bf16_t, false, true, false) : IVG_C3_BN(float, false, true, false);
   // (measured per shape, profiles/r02_conv3x3_tpb.txt: +2 ... +3.5 % on the plain convolutions, -0.8 % on the upsampling ones,
   // whose 32-pixel-row instance also spills registers in the two-step form: those keep one step per barrier)
   if (tpb == 2 && dtype == BF16 && !a.ups) return IVG_C3_BN(bf16_t, false, false, true);
