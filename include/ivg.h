@@ -129,6 +129,12 @@ void ivg_cache_destroy(ivg_engine* e, ivg_cache* c);
 int ivg_generate(ivg_engine* e, const int64_t* prompt, int64_t prompt_stride, int B, int L0, int n_new, const float* actions,
                  int act_T, int ctx, const float* uniforms, int top_k, int64_t* ids_out, float* reward_out, ivg_stream stream);
 
+/* HeadModelWithAction.generate_without_action (action_model.py:123-152; no caller in the reference): 16 sampled tokens per future
+ * frame, then the forced sdf separator -- ivg_generate's action-conditioned schedule without any action embedding.  Same
+ * arguments as ivg_generate minus actions / reward. */
+int ivg_generate_forced_sdf(ivg_engine* e, const int64_t* prompt, int64_t prompt_stride, int B, int L0, int n_new, int ctx, const float* uniforms,
+                            int top_k, int64_t* ids_out, ivg_stream stream);
+
 /* Step-wise rollout (mbrl/video_predictor.py:286-317 calls generate once per environment step on a prompt that grew by the 17
  * tokens of the previous step): same contract as ivg_generate with actions != NULL, but the engine's KV cache is taken to
  * hold positions [0, L0 - 1) of these B trajectories from the previous ivg_generate / ivg_generate_continue call, so only

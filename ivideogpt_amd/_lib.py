@@ -65,6 +65,8 @@ EXPORTS = {
     "ivg_cache_destroy": (None, [C.c_void_p, C.c_void_p]),
     "ivg_generate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ivg_generate_forced_sdf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                         C.c_void_p]),
     "ivg_generate_continue": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                         C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ivg_embed_tokens": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

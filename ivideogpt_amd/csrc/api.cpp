@@ -445,6 +445,16 @@ int ivg_generate(ivg_engine* e, const int64_t* prompt, int64_t prompt_stride, in
     return r.generate(prompt, prompt_stride, B, L0, n_new, actions, act_T, ctx, uniforms, top_k, ids_out, reward_out); });
 }
 
+int ivg_generate_forced_sdf(ivg_engine* e, const int64_t* prompt, int64_t prompt_stride, int B, int L0, int n_new, int ctx, const float* uniforms,
+                            int top_k, int64_t* ids_out, ivg_stream stream) {
+  if (!e) return IVG_ERR_INVALID;
+  if (e->cfg.num_layers <= 0) return e->fail(IVG_ERR_INVALID, "generate: engine was created without a transformer");
+  if (B <= 0 || n_new < 1 || L0 < 1 || L0 + n_new > e->Lmax)
+    return e->fail(IVG_ERR_CAPACITY, "generate: sequence of " + std::to_string(L0 + n_new) + " tokens exceeds the KV cache (" + std::to_string(e->Lmax) + ")");
+  return plan_then_run(e, (hipStream_t)stream, [&](Run& r) {
+    return r.generate(prompt, prompt_stride, B, L0, n_new, nullptr, 0, ctx, uniforms, top_k, ids_out, nullptr, false, nullptr, nullptr, nullptr, true); });
+}
+
 int ivg_generate_continue(ivg_engine* e, const int64_t* prompt, int64_t prompt_stride, int B, int L0, int n_new, const float* actions,
                           int act_T, int ctx, const float* uniforms, int top_k, int64_t* ids_out, float* reward_out, ivg_stream stream) {
   if (!e) return IVG_ERR_INVALID;

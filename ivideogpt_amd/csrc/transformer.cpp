@@ -297,7 +297,7 @@ static int step_body(ivg_engine* e, hipStream_t st, const GenBuf& g, int B, int 
 
 int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, int n_new, const float* actions, int act_T, int ctx,
                   const float* uniforms, int top_k, int64_t* ids_out, float* reward_out, bool reuse_kv, const void* embeds,
-                  int64_t* new_ids_out, void* hidden_out) {
+                  int64_t* new_ids_out, void* hidden_out, bool force_sdf) {
   const ivg_config& c = e->cfg;
   const DType dt = e->llm_dt;
   const int H = c.hidden_size, V = c.vocab_size;
@@ -358,7 +358,7 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
     sa.uniforms = uniforms ? g.uni : nullptr; sa.n_uni = g.ids_ld;
     sa.top_k = top_k;
     sa.ids_out = g.ids; sa.ids_stride = g.ids_ld; sa.L0 = L0;
-    sa.forced_period = actions ? 17 : 0; sa.forced_token = V - 1;
+    sa.forced_period = (actions || force_sdf) ? 17 : 0; sa.forced_token = V - 1;   // (no action embedding is added without actions: sa.act == null)
     sa.E = e->embed; sa.x = g.x; sa.H = H;
     sa.act = actions ? g.act_emb : nullptr; sa.act_T = act_T; sa.ctx = ctx;
     sa.slot0 = actions ? (L0 - 257 * ctx) / 17 : 0;  // a prompt that already holds t generated frames (MBRL step-wise rollout)

@@ -153,6 +153,15 @@ class Engine:
                 if t is not None:
                     t.record_stream(self._stream)
 
+    def generate_forced_sdf(self, prompt, n_new, out, ctx=1, uniforms=None, top_k=100):
+        B, L0 = prompt.shape
+        with self.stream() as s:
+            self.check(self.lib.ivg_generate_forced_sdf(self.h, _ptr(prompt), prompt.stride(0), B, L0, int(n_new), int(ctx), _ptr(uniforms),
+                                                        int(top_k), _ptr(out), s), "generate_forced_sdf")
+            for t in (prompt, out, uniforms):
+                if t is not None:
+                    t.record_stream(self._stream)
+
     def embed_tokens(self, ids, out):
         B, L = ids.shape
         with self.stream() as s:

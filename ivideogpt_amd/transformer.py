@@ -291,6 +291,22 @@ class HeadModelWithAction:
         return (out, reward) if return_reward else out
 
     @torch.no_grad()
+    def generate_without_action(self, inputs_token, do_sample=True, temperature=1.0, top_k=100, max_new_tokens=None, generator=None,
+                                uniforms=None):
+        """action_model.py:123-152 (no caller in the reference): per future frame 16 sampled tokens, then the forced ``sdf`` -- the
+        schedule of ``generate`` without any action embedding; the last forced ``sdf`` is dropped.  -> int64 (B, L0 + max_new_tokens).
+        One prefill + cached steps instead of the reference's per-frame re-prefill (token-identical: same argument as ``generate``)."""
+        assert temperature == 1.0
+        llm = self.llm
+        ids = inputs_token.to(device=llm.device, dtype=torch.int64).contiguous()
+        B, L0 = ids.shape
+        assert (max_new_tokens + 1) % (self.segment_length - self.context) == 0, "max_new_tokens must be (tokens_per_dyna + 1) * frames - 1"
+        out = torch.empty(B, L0 + max_new_tokens, dtype=torch.int64, device=llm.device)
+        u = uniforms if uniforms is not None else llm._uniforms(B, max_new_tokens, do_sample, generator)
+        llm._ensure(B).generate_forced_sdf(ids, max_new_tokens, out, ctx=self.context, uniforms=u, top_k=top_k or llm._cfg["vocab_size"])
+        return out
+
+    @torch.no_grad()
     def __call__(self, input_ids=None, attention_mask=None, labels=None, position_ids=None, action=None):
         """``HeadModelWithAction.forward`` (action_model.py:154-205) as the eval loop calls it (train_gpt.py:356-376):
         ``x.loss`` = HF shifted cross-entropy (+ ``action_recon`` * MSE of the reconstructed actions, :187-196); with

@@ -210,3 +210,35 @@ def test_sampled_rollouts_many_rows_match_oracle(seed):
     ref = generate_cached(oracle_llama(cfg, sd, prefix="llm.model."), prompt, n_new, top_k=100, uniforms=u, action_embeds=ae, ctx=ctx,
                           sdf_token=cfg["vocab_size"] - 1)
     assert torch.equal(out, ref), f"action-conditioned: {(out != ref).sum().item()} tokens differ"
+
+
+def test_generate_without_action_matches_the_reference_loop():
+    """``HeadModelWithAction.generate_without_action`` (action_model.py:123-152, dead code in the reference but part of its class):
+    per future frame 16 sampled tokens from a FRESH prefill of the grown prompt, then the forced ``sdf``; the engine runs it as one
+    prefill + cached steps.  Oracle = the reference's loop restated with per-frame re-prefill; uniform column j - 1 drives new token j
+    (the columns of the forced slots are not consumed)."""
+    from oracle.llama import generate_cached
+    from ivideogpt_amd import HeadModelWithAction, LlamaForCausalLM
+    cfg, sd, fx = llama_fixture("llama_tiny_ctx1_act.npz")
+    ctx, adim = int(fx["ctx"]), int(fx["action_dim"])
+    F_ = 4
+    head = HeadModelWithAction(LlamaForCausalLM(cfg, None, dtype="fp32"), adim, 257 * ctx - 1, 16, ctx, ctx + F_)
+    head.load_state_dict(sd, strict=True)
+    head.to(DEV)
+    g = torch.Generator().manual_seed(321)
+    sdf = cfg["vocab_size"] - 1
+    prompt = torch.randint(0, 8192, (5, 257 * ctx), generator=g)
+    prompt[:, -1] = sdf
+    n_new = 17 * F_ - 1
+    u = torch.rand(5, n_new, generator=g)
+    out = head.generate_without_action(prompt.to(DEV), do_sample=True, top_k=100, max_new_tokens=n_new, uniforms=u.to(DEV)).cpu()
+    ora = oracle_llama(cfg, sd, prefix="llm.model.")
+    toks = prompt
+    for i in range(F_):
+        toks = generate_cached(ora, toks, 16, top_k=100, uniforms=u[:, 17 * i:17 * i + 16])
+        toks = torch.cat([toks, torch.full((5, 1), sdf, dtype=toks.dtype)], 1)
+    ref = toks[:, :-1]
+    assert out.shape == ref.shape and torch.equal(out, ref), f"{(out != ref).sum().item()} tokens differ"
+    assert bool((out[:, 257 * ctx + 16::17] == sdf).all())
+    with pytest.raises(ValueError):                                   # the gpt2 branch of the reference (action_model.py:30-33) is not a Llama: refused
+        HeadModelWithAction(LlamaForCausalLM(cfg, None, dtype="fp32"), adim, 257 * ctx - 1, 16, ctx, ctx + F_, model_type="gpt2")
