@@ -36,6 +36,7 @@ struct Dg3Dev {
   int M, N;
   unsigned ldxb, ldwb;      // row strides in bytes
   int ldy;                  // elements
+  int wr;                   // rows of W one workgroup owns (<= 16 FN; a multiple of 4): the W tile pitch along N
   int klw;                  // 128-byte lines of K per wave
   int ring;                 // slots of the wave's staging ring (1: klw == 1 or no room; 2: continuous stream)
   unsigned wave_bytes;      // LDS bytes per wave (ring * line bytes)
@@ -62,9 +63,13 @@ template <> struct Vec4T3<bf16_t> { typedef bf16x4 type; };
 template <> struct Vec4T3<float> { typedef f32x4 type; };
 
 // MF: 16-row tiles of X per workgroup, FN: 16-row tiles of W, WAVES: waves splitting K
-template <typename T, int MF, int FN, int WAVES>
+// WSKIP: trailing 8-row halves of the W tiles that are never requested -- a workgroup owns p.wr <= 16 FN rows of W (q/k/v: 20 of
+// 32, o-proj / down: 12 of 16), so that the N tiles x M tiles of a GEMM come out at ~256 workgroups: every CU takes part and
+// ingests fewer weight rows next to its activation rows (98 -> 80 KB per CU for q/k/v, 196 -> 172 for down).  Rows beyond wr are
+// neither requested (lanes masked off; a half tile with no valid row is not issued at all: WSKIP) nor stored.
+template <typename T, int MF, int FN, int WAVES, int WSKIP>
 __global__ __launch_bounds__(WAVES * 64) void dg3_kernel(const Dg3Dev p) {
-  constexpr int PER = 2 * (MF + FN);             // LDS-DMA requests per line (two 8-row halves per 16-row tile)
+  constexpr int PER = 2 * (MF + FN) - WSKIP;     // LDS-DMA requests per line (two 8-row halves per 16-row tile)
   constexpr int NFRAG = FN * MF;
   constexpr int LINE = (MF + FN) * 2048;         // staged bytes of one 128-byte line of K: [MF activation tiles | FN weight tiles] x 2 KiB
   constexpr int NFIN = (NFRAG + WAVES - 1) / WAVES;   // output fragments a wave finalises
@@ -82,7 +87,7 @@ __global__ __launch_bounds__(WAVES * 64) void dg3_kernel(const Dg3Dev p) {
   }
   stamp(0);
   const int lr = lane & 15, lg = lane >> 4;
-  const int n_tile = blockIdx.x * 16 * FN, m_tile = blockIdx.y * 16 * MF;
+  const int n_tile = blockIdx.x * p.wr, m_tile = blockIdx.y * 16 * MF;
   unsigned char* my = smem + (size_t)wave * p.wave_bytes;
   const unsigned my_lds = dg3_lds_addr(my);
   const bool glu = p.flags & IG_GLU;
@@ -92,6 +97,7 @@ __global__ __launch_bounds__(WAVES * 64) void dg3_kernel(const Dg3Dev p) {
   // ---- per-lane source offsets (32-bit: the launcher checks that the operands are smaller than 2 GiB)
   const int r8 = lane >> 3, jj = lane & 7;
   unsigned xoff[MF][2], woff[FN][2];
+  bool wreq[FN][2];   // this lane's row of the half tile is one of the wr rows the workgroup owns
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int r = h * 8 + r8;
@@ -99,7 +105,10 @@ __global__ __launch_bounds__(WAVES * 64) void dg3_kernel(const Dg3Dev p) {
 #pragma unroll
     for (int b = 0; b < MF; ++b) xoff[b][h] = (unsigned)min(m_tile + b * 16 + r, p.M - 1) * p.ldxb + sw;
 #pragma unroll
-    for (int a = 0; a < FN; ++a) woff[a][h] = (unsigned)min(n_tile + a * 16 + r, p.N - 1) * p.ldwb + sw;
+    for (int a = 0; a < FN; ++a) {
+      woff[a][h] = (unsigned)min(n_tile + a * 16 + r, p.N - 1) * p.ldwb + sw;   // (rows beyond N re-read row N - 1: never stored)
+      wreq[a][h] = a * 16 + r < p.wr;
+    }
   }
   const char* Xw = (const char*)p.X + (size_t)wave * p.klw * 128;   // this wave's K slice
   const char* Ww = (const char*)p.W + (size_t)wave * p.klw * 128;
@@ -109,17 +118,18 @@ __global__ __launch_bounds__(WAVES * 64) void dg3_kernel(const Dg3Dev p) {
     for (int b = 0; b < MF; ++b)
 #pragma unroll
       for (int h = 0; h < 2; ++h) dg3_dma16(Xw + (size_t)line * 128, xoff[b][h], base + (b * 2 + h) * 1024);
-    if (p.w_nt) {
+    // (every issued half tile has at least one valid row -- 16 FN - 8 WSKIP - 8 < wr by construction -- so the request count per
+    // line is exactly PER in every wave: the counted waits below depend on it)
 #pragma unroll
-      for (int a = 0; a < FN; ++a)
+    for (int a = 0; a < FN; ++a)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) dg3_dma16_nt(Ww + (size_t)line * 128, woff[a][h], base + ((MF + a) * 2 + h) * 1024);
-    } else {
-#pragma unroll
-      for (int a = 0; a < FN; ++a)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) dg3_dma16(Ww + (size_t)line * 128, woff[a][h], base + ((MF + a) * 2 + h) * 1024);
-    }
+      for (int h = 0; h < 2; ++h) {
+        if (a * 2 + h >= 2 * FN - WSKIP) continue;
+        if (wreq[a][h]) {
+          if (p.w_nt) dg3_dma16_nt(Ww + (size_t)line * 128, woff[a][h], base + ((MF + a) * 2 + h) * 1024);
+          else dg3_dma16(Ww + (size_t)line * 128, woff[a][h], base + ((MF + a) * 2 + h) * 1024);
+        }
+      }
   };
   // ---- residual rows of the fragments this wave will finalise: requested FIRST, consumed after the K reduction.  Register-
   // destination loads share the counter with the LDS-DMA queue and requests return in order: being the OLDEST entries they never
@@ -263,6 +273,7 @@ __global__ __launch_bounds__(WAVES * 64) void dg3_kernel(const Dg3Dev p) {
     for (int w = 1; w < WAVES; ++w) v += part[w];
     const int m = m_tile + b * 16 + lr;
     int n0 = n_tile + a * 16 + lg * 4;
+    const bool owned = a * 16 + lg * 4 < p.wr;   // (wr is a multiple of 4: a lane's four columns are owned together)
     float rs = 1.0f;
     if (do_norm) {
       const unsigned char* sb = smem + NFRAG * 1024 + (b * 16 + lr) * 16;
@@ -289,7 +300,7 @@ __global__ __launch_bounds__(WAVES * 64) void dg3_kernel(const Dg3Dev p) {
       n0 = (n_tile >> 1) + (a >> 1) * 16 + lg * 4;
       nlim = p.N >> 1;
     }
-    if (m >= p.M || n0 >= nlim) continue;
+    if (m >= p.M || n0 >= nlim || !owned) continue;
     if (f32out) {
       float* Y = (float*)p.Y + (long)m * p.ldy + n0;
       if (n0 + 3 < nlim && ((p.ldy & 3) == 0)) *(f32x4*)Y = v;
@@ -337,26 +348,28 @@ __global__ __launch_bounds__(WAVES * 64) void dg3_kernel(const Dg3Dev p) {
   if (p.bump && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { p.bump[0] += 1; p.bump[1] += 1; }
 }
 
-template <typename T, int MF, int FN, int WAVES>
+template <typename T, int MF, int FN, int WAVES, int WSKIP>
 static int launch_dg3(const Dg3Dev& d, hipStream_t stream) {
   const int smem = (int)d.wave_bytes * WAVES;
   if (smem > 160 * 1024) return -1;
   static unsigned long long attr_set = 0;
-  auto kfn = dg3_kernel<T, MF, FN, WAVES>;
+  auto kfn = dg3_kernel<T, MF, FN, WAVES, WSKIP>;
   if (first_time_on_device(attr_set)) {
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
   }
-  dim3 grid((unsigned)cdiv(d.N, 16 * FN), (unsigned)cdiv(d.M, 16 * MF), 1);
+  dim3 grid((unsigned)cdiv(d.N, d.wr), (unsigned)cdiv(d.M, 16 * MF), 1);
   hipLaunchKernelGGL(kfn, grid, dim3(WAVES * 64), smem, stream, d);
   return (int)hipGetLastError();
 }
 
 template <typename T, int WAVES>
 static int launch_dg3_w(const Dg3Dev& d, int MF, int FN, hipStream_t st) {
-#define IVG_DG3(mf, fn) if (MF == mf && FN == fn) return launch_dg3<T, mf, fn, WAVES>(d, st)
-  IVG_DG3(1, 1); IVG_DG3(2, 1); IVG_DG3(4, 1);
-  IVG_DG3(1, 2); IVG_DG3(2, 2); IVG_DG3(4, 2);
+  const int wskip = (16 * FN - d.wr) / 8;   // whole 8-row halves beyond the owned rows (0, or 1 with two W tiles)
+#define IVG_DG3(mf, fn) if (MF == mf && FN == fn) { if (wskip == 0) return launch_dg3<T, mf, fn, WAVES, 0>(d, st); \
+                                                    if constexpr (fn == 2) { if (wskip == 1) return launch_dg3<T, mf, fn, WAVES, 1>(d, st); } return -1; }
+  IVG_DG3(1, 1) IVG_DG3(2, 1) IVG_DG3(4, 1)
+  IVG_DG3(1, 2) IVG_DG3(2, 2) IVG_DG3(4, 2)
 #undef IVG_DG3
   return -1;
 }
@@ -369,16 +382,16 @@ static int dg3_waves(long lines) {
 
 // Measured picks (tools/ubench/dgemm_phase, profiles/r03_dgemm3_sweep.txt) for the GEMMs of the released transformers, keyed by
 // (K bytes, N) -- never by the batch.  mf caps the row tiles per workgroup.
-struct Dg3Pick { int kbytes, N, mf, fn; };
+struct Dg3Pick { int kbytes, N, mf, fn, wr; };   // wr: rows of W per workgroup (0: the full 16 fn)
 static const Dg3Pick kDg3Picks[] = {
-    {1536, 2304, 2, 2},    // small: q/k/v
-    {1536, 768, 1, 1},     // small: o-proj
-    {1536, 6144, 4, 2},    // small: gate/up
-    {6144, 768, 1, 1},     // small: down
-    {2048, 3072, 2, 2},    // medium: q/k/v
-    {2048, 1024, 1, 1},    // medium: o-proj
-    {2048, 8192, 2, 2},    // medium: gate/up
-    {8192, 1024, 1, 1},    // medium: down
+    {1536, 2304, 2, 2, 20},   // small: q/k/v      116 N tiles x 2 row halves = 232 workgroups, 49 + 31 KB each (32 rows: 144 x 98 KB)
+    {1536, 768, 1, 1, 12},    // small: o-proj      64 x 4 = 256 workgroups, 25 + 18 KB (16 rows: 192 x 49 KB)
+    {1536, 6144, 4, 2, 0},    // small: gate/up    the [16 gate | 16 up] packing keeps the 32-row tile
+    {6144, 768, 1, 1, 12},    // small: down        64 x 4 = 256 workgroups, 98 + 74 KB (16 rows: 192 x 196 KB)
+    {2048, 3072, 2, 2, 24},   // medium: q/k/v     128 x 2 = 256 workgroups
+    {2048, 1024, 1, 1, 0},    // medium: o-proj    (on the skip list)
+    {2048, 8192, 2, 2, 0},    // medium: gate/up   (on the skip list)
+    {8192, 1024, 1, 1, 0},    // medium: down      64 x 4 = 256 workgroups already
 };
 
 // GEMMs of the released transformers that measure FASTER on the second-generation kernel inside the layer chain
@@ -391,7 +404,7 @@ static const Dg3Skip kDg3Skip[] = {
     {2048, 8192},    // medium: gate/up (does not fit one round of workgroups with everything in flight: 16 waves x 12 KiB)
 };
 
-struct Dg3Plan { int mf, fn, waves, klw, ring; unsigned wave_bytes; };
+struct Dg3Plan { int mf, fn, waves, klw, ring; unsigned wave_bytes; int wr; };
 
 // shape -> launch plan; false: not covered (the caller falls back to dgemm.hip / skinny.hip).  Coverage and the K partition
 // depend on (K, N, dtype, flags) only; the batch size only picks MF (which rows share a workgroup -- never a sum order).
@@ -418,10 +431,13 @@ static bool dg3_plan(const SkinnyArgs& a, DType dtype, Dg3Plan& pl) {
     auto wgs = [&](int mf, int fn) { return (long)cdiv(a.M, 16 * mf) * cdiv(a.N, 16 * fn); };
     while (MF > 1 && wgs(MF, FN) < 128) MF >>= 1;                 // narrow GEMMs: split the rows to fill the chip
   }
+  int WR = 0;
+  static const bool full_tiles = [] { const char* v = getenv("IVG_DG3_WR"); return v && v[0] == '0'; }();   // IVG_DG3_WR=0: 16 FN rows per workgroup (A/B)
   for (const Dg3Pick& k : kDg3Picks) {
     if (k.kbytes != a.K * es || k.N != a.N) continue;
     MF = std::min(k.mf, mt >= 4 ? 4 : (mt >= 2 ? 2 : 1));
     FN = k.fn;
+    if (!glu && !full_tiles && k.wr % 4 == 0 && k.wr > 16 * FN - 8 && k.wr <= 16 * FN) WR = k.wr;
     break;
   }
   static int force[4];   // development: IVG_DG3_FORCE=MF,FN,RING,WAVES (0 = automatic) for every launch (tools/ubench/dgemm_phase); read once
@@ -435,21 +451,22 @@ static bool dg3_plan(const SkinnyArgs& a, DType dtype, Dg3Plan& pl) {
   // one workgroup per CU (the staging fills most of the LDS): a GEMM whose W tiles outnumber the CUs would run in rounds, each
   // paying the full request latency -- lm_head (513 tiles) stays on the second-generation kernel, whose small workgroups are all
   // resident at once.  (A function of N and the pick only, like the rest of the coverage.)
-  if (cdiv(a.N, 16 * FN) > 256) return false;
+  if (WR == 0 || forced) WR = 16 * FN;
+  if (cdiv(a.N, WR) > 256) return false;
   const int klw = (int)(lines / waves);
   // everything in flight at once needs waves * (MF + FN) * 2 KiB per line of K; over budget: fewer row tiles per workgroup
   while (MF > 1 && waves * (MF + FN) * 2048 > 160 * 1024) MF >>= 1;
   if (waves * (MF + FN) * 2048 > 160 * 1024) return false;
   int ring = klw >= 2 && waves * 2 * (MF + FN) * 2048 <= 160 * 1024 ? 2 : 1;
   if (forced && force[2] > 0 && force[2] <= ring) ring = force[2];
-  pl = Dg3Plan{MF, FN, waves, klw, ring, (unsigned)(ring * (MF + FN) * 2048)};
+  pl = Dg3Plan{MF, FN, waves, klw, ring, (unsigned)(ring * (MF + FN) * 2048), WR};
   return true;
 }
 
 // rows of W one workgroup of the plan for this GEMM owns (the L2 warm-up of a predecessor launch mirrors that tiling); 0: not covered
 int dgemm3_w_rows_per_block(const SkinnyArgs& a, DType dtype) {
   Dg3Plan pl;
-  return dg3_plan(a, dtype, pl) ? 16 * pl.fn : 0;
+  return dg3_plan(a, dtype, pl) ? pl.wr : 0;
 }
 
 // -1: shape not covered; otherwise a hipError_t
@@ -464,7 +481,7 @@ int launch_dgemm3(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
   Dg3Dev d{};
   d.X = a.X; d.W = a.W; d.Y = a.Y; d.M = a.M; d.N = a.N;
   d.ldxb = (unsigned)a.ldx * es; d.ldwb = (unsigned)a.ldw * es; d.ldy = a.ldy;
-  d.klw = pl.klw; d.ring = pl.ring; d.wave_bytes = pl.wave_bytes; d.flags = a.flags;
+  d.wr = pl.wr; d.klw = pl.klw; d.ring = pl.ring; d.wave_bytes = pl.wave_bytes; d.flags = a.flags;
   d.inv_k = 1.0f / (float)a.K; d.eps = a.eps; d.bump = a.bump;
   static const int w_nt = [] { const char* v = getenv("IVG_DG3_NT"); return (v && v[0] == '0') ? 0 : 1; }();   // IVG_DG3_NT=0: default-policy weight requests (A/B)
   d.w_nt = w_nt;
@@ -472,7 +489,7 @@ int launch_dgemm3(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
   d.dbg = a.dbg;
   static const bool pf_off = [] { const char* v = getenv("IVG_DG3_WARM"); return v && v[0] == '0'; }();   // IVG_DG3_WARM=0: no L2 warm-up (A/B runs)
   if (a.next_W && a.next_tile_bytes >= 1024 && a.next_tiles > 0 && !pf_off) {
-    const long grid = (long)cdiv(a.N, 16 * pl.fn) * cdiv(a.M, 16 * pl.mf);
+    const long grid = (long)cdiv(a.N, pl.wr) * cdiv(a.M, 16 * pl.mf);
     const long waves_per_xcd = std::max(1L, grid / 8) * pl.waves;
     const long units_per_xcd = (long)cdiv(a.next_tiles, 8) * (a.next_tile_bytes >> 10);
     long per = (units_per_xcd + waves_per_xcd - 1) / waves_per_xcd;
