@@ -9,6 +9,9 @@ from . import _lib
 from .packing import dtype_code
 
 
+_WS = {}   # device -> scratch tensor of ivg_frame_metrics (partial sums of the metric tiles)
+
+
 @torch.no_grad()
 def frame_metric_rows(video_gt, video_pred, gt_t0=0, pred_t0=0, frames=None):
     """video_gt (B, T, 3, H, W) float32 / bfloat16 on the GPU; video_pred float32 (t * B, T', 3, H, W), sample k of trajectory b
@@ -24,7 +27,9 @@ def frame_metric_rows(video_gt, video_pred, gt_t0=0, pred_t0=0, frames=None):
     T = frames if frames is not None else min(Tg - gt_t0, Tp - pred_t0)
     rows = torch.empty(B, 3, dtype=torch.float32, device=gt.device)
     nbytes = lib.ivg_frame_metrics_ws_bytes(n, T, H, W)
-    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=gt.device)
+    ws = _WS.get(gt.device)              # kept per device: no allocation on the hot path (a serving loop calls this every step)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = _WS[gt.device] = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=gt.device)
     st = C.c_void_p(torch.cuda.current_stream(gt.device).cuda_stream)
     _lib.check(lib.ivg_frame_metrics(C.c_void_p(gt.data_ptr()), dtype_code(gt.dtype), B, Tg, gt_t0, C.c_void_p(pred.data_ptr()), n, Tp, pred_t0,
                                      T, H, W, C.c_void_p(rows.data_ptr()), C.c_void_p(ws.data_ptr()), nbytes, st), None, "frame_metrics")
