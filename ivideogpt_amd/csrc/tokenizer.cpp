@@ -128,7 +128,10 @@ int Run::norm_conv(DType dt, const void* x, int N, int H, int W, const NormW& n,
   void* coef = e->ws.alloc((size_t)N * C * sizeof(float) * 2);
   int rc = 0;
   if (!planning) {
-    const bool fuse = gn_apply_fuse_enabled() && c.k == 3;
+    // every N tile (128 output channels) of the fused kernel normalises the whole input halo again: with 2-4 N tiles the in-place
+    // transform is done 2-4 times.  IVG_GN_APPLY_FUSE_MAXN=n: fuse only up to n N tiles, separate apply pass beyond (A/B; default: always)
+    static const int fuse_maxn = [] { const char* v = getenv("IVG_GN_APPLY_FUSE_MAXN"); return v ? atoi(v) : 1 << 30; }();
+    const bool fuse = gn_apply_fuse_enabled() && c.k == 3 && (c.cout + 127) / 128 <= fuse_maxn;
     const void* st_part = x_stats && x_stats->chunks > 0 ? x_stats->part : nullptr;
     int chunks = st_part ? x_stats->chunks : 0;
     if (!st_part) {   // x has no statistics from its producer: one pass over it
