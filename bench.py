@@ -8,6 +8,10 @@ A step = one pass of the hot path over one batch of synthetic clips already resi
     encode the context frames -> autoregressive rollout (17*F - 1 tokens) -> decode all T frames -> clamp(0, 1)
 (BASELINE.json configs[1]: ivideogpt-oxe-64-act-free shapes, synthetic 64x64 bf16 pixels, 64 trajectories per GPU,
 2 context + 14 predicted frames; seeded random weights of the real architecture -- no checkpoints exist offline).
+Two batches are kept in flight per GPU by default (``--lanes 2``: two engine instances, each with its own KV cache, workspace, HIP
+stream and host thread; the K timed steps are dealt round-robin to the lanes): the MFMA-bound convolutions of one batch's encode /
+decode run beside the latency- and HBM-bound rollout of the other.  ``value`` counts the frames of exactly K steps over the wall
+clock; ``single_lane`` in the line is the same pipeline with one batch in flight (``--lanes 1``; the latency of a batch).
 Multi-GPU: independent trajectories shard by batch rows (weak scaling: 64 per GPU), no data-path collective; the
 per-sample metric rows are all-gathered over RCCL once per step (the reference's accelerator.gather, train_gpt.py:476-479).
 
@@ -232,6 +236,65 @@ def measure(tok, model, pixels, actions, ctx, F, greedy, gen, steps, warmup):
     return time.perf_counter() - t0, frames, rows, step
 
 
+OFFSET_MS = float(os.environ.get("IVG_LANE_OFFSET_MS", "0"))
+
+
+def measure_lanes(lanes, ctx, F, greedy, steps, warmup):
+    """Several batches in flight on one GPU: lane i = its own engines (KV cache, workspace), its own resident batch, its own HIP
+    stream and host thread; the `steps` timed steps are dealt round-robin to the lanes (step g -> lane g % L) and run concurrently --
+    the MFMA-bound convolutions of one batch's encode / decode fill the matrix pipes the latency- and HBM-bound rollout of the other
+    leaves idle.  The metric all-gathers are issued in global step order on every rank (parallel.Turnstile).
+    -> (seconds for exactly `steps` steps: barrier + synchronize on both sides, last frames per lane, last rows per lane)."""
+    import threading
+    L = len(lanes)
+    turn = parallel.Turnstile()
+    last = [None] * L
+    errors = []
+
+    def lane_step(i, g):
+        ln = lanes[i]
+        frames = predict_frames(ln["tok"], ln["model"], ln["pixels"], ctx, F, actions=ln["actions"], do_sample=not greedy, top_k=100, generator=ln["gen"])
+        rows = frame_metrics(frames, ln["pixels"], first_frame=ctx)
+        rows = turn.run(g, lambda: parallel.gather_metric_rows_even(rows))
+        last[i] = (frames, rows)
+
+    def lane_body(i, first, n):
+        try:
+            with torch.cuda.stream(lanes[i]["stream"]):
+                if OFFSET_MS > 0 and i > 0:
+                    time.sleep(i * OFFSET_MS * 1e-3)   # development (IVG_LANE_OFFSET_MS): start the lanes out of phase
+                for k in range(n):
+                    lane_step(i, first + k * L)
+        except Exception as e:   # surface in the main thread (a dead lane would also leave the turnstile waiting)
+            errors.append(e)
+            turn.reset(1 << 60)
+
+    def run(n_steps):
+        turn.reset(0)
+        ths = [threading.Thread(target=lane_body, args=(i, i, len(range(i, n_steps, L)))) for i in range(L)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        if errors:
+            raise errors[0]
+
+    for i in range(L):            # warm-up lane by lane on the main thread (engine build, one-time attribute setup), then together
+        for _ in range(max(1, warmup)):
+            with torch.cuda.stream(lanes[i]["stream"]):
+                turn.reset(0)
+                lane_step(i, 0)
+    torch.cuda.synchronize()
+    run(L)
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    return time.perf_counter() - t0, [x[0] for x in last], [x[1] for x in last]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -255,6 +318,8 @@ def main():
     ap.add_argument("--greedy", action="store_true")
     ap.add_argument("--action-dim", type=int, default=0, help=">0: action-conditioned HeadModelWithAction (BASELINE config 3: 4)")
     ap.add_argument("--ctx", type=int, default=0, help="context frames (0: the tokenizer's pretrained context_length)")
+    ap.add_argument("--lanes", type=int, default=2, help="batches in flight per GPU: engine instances on their own HIP streams and host threads "
+                                                         "(1: one batch at a time, the per-batch latency case)")
     a = ap.parse_args()
     if a.config:
         for k, v in CONFIGS[a.config].items():
@@ -293,7 +358,26 @@ def main():
     actions = torch.randn(B, T, a.action_dim, device=dev, generator=g) if a.action_dim else None
 
     # ---- the measurement: clean loop, no hooks
-    my_elapsed, frames, rows, step = measure(tok, model, pixels, actions, ctx, F, a.greedy, sample_gen, a.steps, a.warmup)
+    single = None
+    if a.lanes > 1:
+        lanes = [dict(tok=tok, model=model, pixels=pixels, actions=actions, gen=sample_gen, stream=torch.cuda.Stream(device=dev))]
+        for i in range(1, a.lanes):   # further lanes: their own engines (same weights: seeded) and their own resident batch
+            _, _, _, _, tok_i, model_i = build_models(dev, a.res, a.medium, a.encode_dtype, a.decode_dtype, a.llm_dtype, a.action_dim, a.ctx or None, a.frames)
+            gi = torch.Generator(device=dev).manual_seed(1000 + rank + 7919 * i)
+            lanes.append(dict(tok=tok_i, model=model_i, pixels=torch.rand(B, T, 3, a.res, a.res, device=dev, generator=gi).to(torch.bfloat16),
+                              actions=torch.randn(B, T, a.action_dim, device=dev, generator=gi) if a.action_dim else None,
+                              gen=torch.Generator(device=dev).manual_seed(2000 + rank + 7919 * i), stream=torch.cuda.Stream(device=dev)))
+        my_elapsed, lane_frames, lane_rows = measure_lanes(lanes, ctx, F, a.greedy, a.steps, a.warmup)
+        for fr, rw in zip(lane_frames, lane_rows):
+            assert torch.isfinite(fr).all() and rw.shape == (global_b, 3) and torch.isfinite(rw).all()
+        # the one-batch-at-a-time figure next to it (per-batch latency), same engines, lane 0 alone
+        n1 = max(1, min(3, a.steps))
+        e1, frames, rows, step = measure(tok, model, pixels, actions, ctx, F, a.greedy, sample_gen, n1, 1)
+        e1 = parallel.max_over_ranks(e1, dev)
+        single = {"value": global_b * F * n1 / e1, "unit": "predicted frames/s", "ms_per_step": e1 / n1 * 1e3, "steps": n1,
+                  "note": "one batch in flight (lane 0 alone): the latency of a batch through encode -> rollout -> decode"}
+    else:
+        my_elapsed, frames, rows, step = measure(tok, model, pixels, actions, ctx, F, a.greedy, sample_gen, a.steps, a.warmup)
     assert torch.isfinite(frames).all() and rows.shape == (global_b, 3) and torch.isfinite(rows).all()
     elapsed = parallel.max_over_ranks(my_elapsed, dev)
     per_rank = parallel.gather_metric_rows_even(torch.tensor([[B * F * a.steps / my_elapsed]], device=dev, dtype=torch.float32)).flatten().tolist()
@@ -386,11 +470,16 @@ def main():
                                    f"top-k 100 sampling, seeded random weights",
                        "global_batch": global_b, "frames": T, "resolution": a.res,
                        "arith": {"encode": a.encode_dtype, "rollout": a.llm_dtype, "decode": a.decode_dtype},
-                       "parallelism": f"batch-shard x{world} (no data-path collective; 1 RCCL all-gather of [B,3] metric rows (mse, psnr, ssim) per step)"},
+                       "parallelism": f"batch-shard x{world} (no data-path collective; 1 RCCL all-gather of [B,3] metric rows (mse, psnr, ssim) per step)"
+                                      + (f"; {a.lanes} batches in flight per GPU (engine instances on their own HIP streams and host threads: steps dealt "
+                                         f"round-robin, a step = one batch through encode -> rollout -> decode)" if a.lanes > 1 else ""),
+                       "lanes": a.lanes},
             "per_rank_frames_per_s": per_rank,
             "roofline": rl[0], "roofline_other": rl[1:],
             "stage_ms": stage,
         }
+        if single:
+            out["single_lane"] = single
         if fp32_mode:
             out["fp32_mode"] = fp32_mode
         if world == 1 and not a.no_cpu_baseline:

@@ -3,6 +3,7 @@ weights are replicated, and the ONLY collective is one all-gather of the per-sam
 (mirrors ``accelerator.gather`` of mse/psnr/ssim/lpips at /root/reference/train_gpt.py:476-479).
 One process per GPU; ``torch.distributed`` backend "nccl" is RCCL on ROCm (xGMI), "gloo" in the CPU tests."""
 import os
+import threading
 
 import torch
 import torch.distributed as dist
@@ -125,3 +126,29 @@ class LocalAccelerator:
 
     def log(self, values, step=None):
         self.logged.append((step, dict(values)))
+
+
+class Turnstile:
+    """Issues work in ticket order, whatever thread it comes from: with several batches in flight per GPU (one host thread and one
+    HIP stream per lane) the metric all-gathers of the lanes must reach RCCL in the SAME order on every rank -- collectives of one
+    process group are matched by issue order.  Ticket = global step index; a lane's gather waits until all earlier steps' gathers
+    have been issued (they are tiny and asynchronous on the device, so the wait is only for the other lane to REACH its gather)."""
+
+    def __init__(self):
+        self._cv = threading.Condition()
+        self._turn = 0
+
+    def run(self, ticket, fn):
+        with self._cv:
+            self._cv.wait_for(lambda: self._turn == ticket)
+        try:
+            return fn()
+        finally:
+            with self._cv:
+                self._turn += 1
+                self._cv.notify_all()
+
+    def reset(self, turn=0):
+        with self._cv:
+            self._turn = turn
+            self._cv.notify_all()

@@ -100,3 +100,54 @@ def test_eval_cli_runs_full_width_with_forced_collectives():
     import json
     logs = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert math.isfinite(logs["eval/eval_loss"]) and 0 < logs["eval/ssim"] <= 1 and logs["eval/psnr"] > 0
+
+
+def test_two_engines_in_flight_equal_sequential_runs():
+    """bench.py --lanes 2 keeps two batches in flight on one GPU: two engine sets, two host threads, two HIP streams.  libivg has no
+    global mutable state on the data path (an engine handle is not thread-safe, two handles are independent): the frames and tokens
+    of two pipelines running CONCURRENTLY must equal, bit for bit, those of the same pipelines run one after the other."""
+    import threading
+    from ivideogpt_amd import CompressiveVQModel, LlamaForCausalLM, weights as W
+    from ivideogpt_amd.pipeline import predict_frames
+    tcfg = W.tokenizer_config(**TOK_CFG)
+    tsd = W.random_tokenizer_state_dict(tcfg, 91, codebook_std=0.4)
+    lsd = W.random_llama_state_dict(LLM_CFG, 92)
+    ctx, F_ = 2, 4
+    g = torch.Generator().manual_seed(93)
+    sets = []
+    for i in range(2):
+        tok = CompressiveVQModel(tcfg, tsd, encode_dtype="fp32", decode_dtype="bf16").to(DEV)
+        llm = LlamaForCausalLM(dict(LLM_CFG), lsd, dtype="bf16").to(DEV)
+        px = torch.rand(6, ctx + F_, 3, 64, 64, generator=g).to(DEV)
+        u = torch.rand(6, 17 * F_ - 1, generator=g).to(DEV)
+        sets.append((tok, llm, px, u, torch.cuda.Stream(device=DEV)))
+
+    def run(i, out):
+        tok, llm, px, u, st = sets[i]
+        with torch.cuda.stream(st):
+            for _ in range(3):
+                frames, tokens = predict_frames(tok, llm, px, ctx, F_, uniforms=u, return_tokens=True)
+            st.synchronize()
+        out[i] = (frames.clone(), tokens.clone())
+
+    seq, par = {}, {}
+    for i in range(2):
+        run(i, seq)
+    ths = [threading.Thread(target=run, args=(i, par)) for i in range(2)]
+    [t.start() for t in ths]; [t.join() for t in ths]
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert torch.equal(par[i][1], seq[i][1]), f"lane {i}: tokens differ between concurrent and sequential runs"
+        assert torch.equal(par[i][0], seq[i][0]), f"lane {i}: frames differ between concurrent and sequential runs"
+
+
+def test_bench_two_lanes_small_run():
+    """``bench.py --lanes 2`` end to end at a small shape: one JSON line with both figures (two batches in flight / one)."""
+    import json
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--lanes", "2", "--batch", "4", "--frames", "6", "--steps", "4", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-fp32-mode", "--no-profile"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["lanes"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["single_lane"]["value"] > 0
+    assert abs(d["value"] - 4 * 4 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]      # frames of exactly 4 steps over the wall clock

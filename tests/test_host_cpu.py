@@ -245,3 +245,42 @@ def test_lds_swizzle_keys_are_conflict_free_for_their_access_shapes():
             a = hx * 64 + ((lg ^ L.key_ups(hx)) << 4)
             b = (hx + 8) * 64 + ((lg ^ L.key_ups(hx + 8)) << 4)
             assert ((a + 512) ^ 16) == b
+
+
+LANES_WORKER = r"""
+import os, sys, threading, time, random, torch
+sys.path.insert(0, sys.argv[1])
+from ivideogpt_amd import parallel
+rank, world, local = parallel.init_from_env("gloo")
+L, steps = 2, 9
+turn = parallel.Turnstile()
+seen = {}
+def lane(i):
+    for g in range(i, steps, L):
+        time.sleep(random.random() * 0.02 * (1 + (rank + i) % 2))        # lanes and ranks drift apart
+        rows = torch.full((3, 2), float(100 * g + rank))
+        out = turn.run(g, lambda: parallel.gather_metric_rows_even(rows))  # issued in global step order on every rank
+        seen[g] = out
+ths = [threading.Thread(target=lane, args=(i,)) for i in range(L)]
+[t.start() for t in ths]; [t.join() for t in ths]
+for g in range(steps):
+    want = torch.cat([torch.full((3, 2), float(100 * g + r)) for r in range(world)], 0)
+    assert torch.equal(seen[g], want), (rank, g, seen[g])
+parallel.barrier()
+print("LANES-OK", rank)
+"""
+
+
+def test_two_lanes_issue_their_gathers_in_step_order_world2_gloo(tmp_path):
+    """bench.py --lanes 2: two batches in flight per GPU, one host thread per lane; the per-step metric all-gathers of the two lanes
+    must reach the process group in the same order on every rank (parallel.Turnstile, ticket = global step index)."""
+    script = tmp_path / "lanes.py"
+    script.write_text(LANES_WORKER)
+    port = 27000 + (os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "LANES-OK 0" in outs[0] and "LANES-OK 1" in outs[1]
