@@ -12,12 +12,6 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def current_stream(device):
-    """A non-default stream handle for the engine (hipGraph capture is not allowed on the legacy stream)."""
-    s = torch.cuda.current_stream(device)
-    return s
-
-
 class Engine:
     def __init__(self, device, tensors, tok_cfg=None, llm_cfg=None, action_dim=0, reward_head=False,
                  encode_dtype="fp32", decode_dtype="bf16", llm_dtype="bf16", max_batch=1, max_frames=16, max_seq=0):
@@ -68,6 +62,7 @@ class Engine:
         self._stream = torch.cuda.Stream(device=self.device)  # dedicated non-default stream (graph capture needs one)
         self._caches = set()   # live detokenize caches (device memory owned here: released with the engine)
         self._clamp_out = False
+        self._run = None       # the stream of the last call (the dedicated one, or the caller's own)
 
     def close(self):
         if getattr(self, "h", None):
@@ -83,19 +78,28 @@ class Engine:
         except Exception:
             pass
 
-    # ---- stream plumbing: run on our stream, ordered after the caller's current stream and before its future work
+    # ---- stream plumbing.  A caller that made a stream of its own current (`with torch.cuda.stream(s):`, one per batch in flight) gets
+    # the launches on THAT stream, like any PyTorch op; under the legacy default stream the engine runs on its dedicated stream,
+    # ordered after the caller's current stream and before its future work.  The engine's workspace belongs to one stream at a time:
+    # a call on another stream than the previous call's first waits for it.
     class _On:
         def __init__(self, eng):
             self.eng = eng
 
         def __enter__(self):
-            cur = torch.cuda.current_stream(self.eng.device)
-            self.eng._stream.wait_stream(cur)
-            self.cur = cur
-            return C.c_void_p(self.eng._stream.cuda_stream)
+            eng = self.eng
+            cur = torch.cuda.current_stream(eng.device)
+            run = eng._stream if cur == torch.cuda.default_stream(eng.device) else cur
+            if eng._run is not None and eng._run != run:
+                run.wait_stream(eng._run)
+            if run != cur:
+                run.wait_stream(cur)
+            eng._run, self.cur = run, cur
+            return C.c_void_p(run.cuda_stream)
 
         def __exit__(self, *exc):
-            self.cur.wait_stream(self.eng._stream)
+            if self.eng._run != self.cur:
+                self.cur.wait_stream(self.eng._run)
             return False
 
     def stream(self):
@@ -114,14 +118,14 @@ class Engine:
             self.check(self.lib.ivg_tokenize(self.h, _ptr(pixels), dtype_code(pixels.dtype), B, T, _ptr(ids), _ptr(labels), s), "tokenize")
             for t in (pixels, ids, labels):
                 if t is not None:
-                    t.record_stream(self._stream)
+                    t.record_stream(self._run)
 
     def encode_context(self, pixels, ids):
         B, T = pixels.shape[:2]
         with self.stream() as s:
             self.check(self.lib.ivg_encode_context(self.h, _ptr(pixels), dtype_code(pixels.dtype), B, T, _ptr(ids), ids.stride(0), s),
                        "encode_context")
-            pixels.record_stream(self._stream); ids.record_stream(self._stream)
+            pixels.record_stream(self._run); ids.record_stream(self._run)
 
     def detokenize(self, ids, F, out, cache=None, cache_mode=0, clamp=False):
         if clamp != self._clamp_out:   # clamp(0, 1) in the epilogue of the decoders' last convolution (engine state, rarely toggled)
@@ -129,7 +133,7 @@ class Engine:
             self._clamp_out = bool(clamp)
         with self.stream() as s:
             self.check(self.lib.ivg_detokenize(self.h, _ptr(ids), ids.shape[0], int(F), _ptr(out), cache, int(cache_mode), s), "detokenize")
-            ids.record_stream(self._stream); out.record_stream(self._stream)
+            ids.record_stream(self._run); out.record_stream(self._run)
 
     def cache_create(self, B):
         h = C.c_void_p()
@@ -151,7 +155,7 @@ class Engine:
                                              _ptr(uniforms), int(top_k), _ptr(out), _ptr(reward), s), "generate")
             for t in (prompt, out, actions, uniforms, reward):
                 if t is not None:
-                    t.record_stream(self._stream)
+                    t.record_stream(self._run)
 
     def generate_forced_sdf(self, prompt, n_new, out, ctx=1, uniforms=None, top_k=100):
         B, L0 = prompt.shape
@@ -160,23 +164,23 @@ class Engine:
                                                         int(top_k), _ptr(out), s), "generate_forced_sdf")
             for t in (prompt, out, uniforms):
                 if t is not None:
-                    t.record_stream(self._stream)
+                    t.record_stream(self._run)
 
     def embed_tokens(self, ids, out):
         B, L = ids.shape
         with self.stream() as s:
             self.check(self.lib.ivg_embed_tokens(self.h, _ptr(ids), ids.stride(0), B, L, _ptr(out), s), "embed_tokens")
-            ids.record_stream(self._stream); out.record_stream(self._stream)
+            ids.record_stream(self._run); out.record_stream(self._run)
 
     def action_linear(self, actions, out):
         with self.stream() as s:
             self.check(self.lib.ivg_action_linear(self.h, _ptr(actions), actions.numel() // actions.shape[-1], _ptr(out), s), "action_linear")
-            actions.record_stream(self._stream); out.record_stream(self._stream)
+            actions.record_stream(self._run); out.record_stream(self._run)
 
     def reward_linear(self, hidden, out):
         with self.stream() as s:
             self.check(self.lib.ivg_reward_linear(self.h, _ptr(hidden), hidden.numel() // hidden.shape[-1], _ptr(out), s), "reward_linear")
-            hidden.record_stream(self._stream); out.record_stream(self._stream)
+            hidden.record_stream(self._run); out.record_stream(self._run)
 
     def generate_embeds(self, embeds, n_new, out, hidden=None, uniforms=None, top_k=100, allow_reuse=True):
         """-> True when the kept KV cache was reused (only the last row of ``embeds`` was fed)."""
@@ -187,7 +191,7 @@ class Engine:
                                                     _ptr(hidden), int(bool(allow_reuse)), C.byref(reused), s), "generate_embeds")
             for t in (embeds, out, hidden, uniforms):
                 if t is not None:
-                    t.record_stream(self._stream)
+                    t.record_stream(self._run)
         return bool(reused.value)
 
     def logits(self, ids, out, actions=None, ctx=1):
@@ -197,7 +201,7 @@ class Engine:
             self.check(self.lib.ivg_logits(self.h, _ptr(ids), B, L, _ptr(actions), act_T, int(ctx), _ptr(out), s), "logits")
             for t in (ids, out, actions):
                 if t is not None:
-                    t.record_stream(self._stream)
+                    t.record_stream(self._run)
 
     def eval_forward(self, ids, labels, token_nll, loss_rows, actions=None, ctx=1, hidden=None):
         B, L = ids.shape
@@ -207,7 +211,7 @@ class Engine:
                                                  _ptr(loss_rows), _ptr(hidden), s), "eval_forward")
             for t in (ids, labels, token_nll, loss_rows, actions, hidden):
                 if t is not None:
-                    t.record_stream(self._stream)
+                    t.record_stream(self._run)
 
     def action_recon_sqerr(self, hidden, actions, ctx, prelude, out):
         B, L = hidden.shape[:2]
@@ -215,7 +219,7 @@ class Engine:
             self.check(self.lib.ivg_action_recon_sqerr(self.h, _ptr(hidden), _ptr(actions), B, L, actions.shape[1], int(ctx), int(prelude),
                                                        _ptr(out), s), "action_recon_sqerr")
             for t in (hidden, actions, out):
-                t.record_stream(self._stream)
+                t.record_stream(self._run)
 
     def profile_enable(self, kclass, on=True):
         self.check(self.lib.ivg_profile_enable(self.h, kclass, int(on)), "profile_enable")

@@ -151,3 +151,27 @@ def test_bench_two_lanes_small_run():
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert d["config"]["lanes"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["single_lane"]["value"] > 0
     assert abs(d["value"] - 4 * 4 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]      # frames of exactly 4 steps over the wall clock
+
+
+def test_engine_runs_on_the_callers_stream_and_orders_a_switch_of_streams():
+    """engine.Engine._On: under a stream the caller made current the launches go to THAT stream; a call on another stream than the
+    previous call's waits for it (the engine's workspace belongs to one stream at a time).  Same ids on every route."""
+    from ivideogpt_amd import CompressiveVQModel, weights as W
+    tcfg = W.tokenizer_config(**TOK_CFG)
+    tok = CompressiveVQModel(tcfg, W.random_tokenizer_state_dict(tcfg, 95, codebook_std=0.4), encode_dtype="fp32", decode_dtype="bf16").to(DEV)
+    ctx = tok.context_length
+    px = torch.rand(8, ctx + 5, 3, 64, 64, generator=torch.Generator().manual_seed(96)).to(DEV)
+    ref = tok.tokenize(px, ctx)[0].clone()                       # legacy default stream -> the engine's dedicated stream
+    torch.cuda.synchronize()
+    A, B = torch.cuda.Stream(device=DEV), torch.cuda.Stream(device=DEV)
+    got = []
+    for s in (A, B, A, None, B):                                 # back-to-back on different streams, no synchronisation in between
+        if s is None:
+            got.append(tok.tokenize(px, ctx)[0])
+        else:
+            with torch.cuda.stream(s):
+                got.append(tok.tokenize(px, ctx)[0])
+                assert tok._engine._run == s
+    torch.cuda.synchronize()
+    for i, g in enumerate(got):
+        assert torch.equal(g, ref), f"call {i}"
