@@ -236,9 +236,6 @@ def measure(tok, model, pixels, actions, ctx, F, greedy, gen, steps, warmup):
     return time.perf_counter() - t0, frames, rows, step
 
 
-OFFSET_MS = float(os.environ.get("IVG_LANE_OFFSET_MS", "0"))
-
-
 def measure_lanes(lanes, ctx, F, greedy, steps, warmup):
     """Several batches in flight on one GPU: lane i = its own engines (KV cache, workspace), its own resident batch, its own HIP
     stream and host thread; the `steps` timed steps are dealt round-robin to the lanes (step g -> lane g % L) and run concurrently --
@@ -261,8 +258,6 @@ def measure_lanes(lanes, ctx, F, greedy, steps, warmup):
     def lane_body(i, first, n):
         try:
             with torch.cuda.stream(lanes[i]["stream"]):
-                if OFFSET_MS > 0 and i > 0:
-                    time.sleep(i * OFFSET_MS * 1e-3)   # development (IVG_LANE_OFFSET_MS): start the lanes out of phase
                 for k in range(n):
                     lane_step(i, first + k * L)
         except Exception as e:   # surface in the main thread (a dead lane would also leave the turnstile waiting)
