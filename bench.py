@@ -257,6 +257,7 @@ def measure_lanes(lanes, ctx, F, greedy, steps, warmup):
 
     def lane_body(i, first, n):
         try:
+            torch.cuda.set_device(lanes[i]["stream"].device)   # a new host thread starts on device 0: this rank's GPU, explicitly
             with torch.cuda.stream(lanes[i]["stream"]):
                 for k in range(n):
                     lane_step(i, first + k * L)
@@ -484,7 +485,7 @@ def main():
                 out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     parallel.barrier()
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -175,3 +175,17 @@ def test_engine_runs_on_the_callers_stream_and_orders_a_switch_of_streams():
     torch.cuda.synchronize()
     for i, g in enumerate(got):
         assert torch.equal(g, ref), f"call {i}"
+
+
+def test_bench_two_lanes_gathers_through_rccl():
+    """The N-GPU run of ``bench.py`` issues its per-step all-gathers from the two lane threads of every rank, in ticket order
+    (parallel.Turnstile).  What a 1-GPU lease can execute of that: a 1-rank ``nccl`` group with IVG_FORCE_COLLECTIVE=1 -- the collectives
+    are really issued (RCCL), from two host threads with different current streams."""
+    import json
+    env = dict(os.environ, IVG_FORCE_COLLECTIVE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29633", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--lanes", "2", "--batch", "4", "--frames", "6", "--steps", "6",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-fp32-mode", "--no-profile"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["lanes"] == 2 and d["steps"] == 6 and d["value"] > 0
