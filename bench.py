@@ -261,9 +261,9 @@ def measure_lanes(lanes, ctx, F, greedy, steps, warmup):
             with torch.cuda.stream(lanes[i]["stream"]):
                 for k in range(n):
                     lane_step(i, first + k * L)
-        except Exception as e:   # surface in the main thread (a dead lane would also leave the turnstile waiting)
+        except Exception as e:   # surface in the main thread; the other lanes must not wait for this lane's tickets
             errors.append(e)
-            turn.reset(1 << 60)
+            turn.abort()
 
     def run(n_steps):
         turn.reset(0)
@@ -294,7 +294,7 @@ def measure_lanes(lanes, ctx, F, greedy, steps, warmup):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5], help="BASELINE.json config preset (per-GPU shapes); 0: the flags below")
     ap.add_argument("--batch", type=int, default=64, help="trajectories per GPU (weak scaling) / in total (--scaling strong)")

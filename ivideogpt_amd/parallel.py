@@ -137,10 +137,13 @@ class Turnstile:
     def __init__(self):
         self._cv = threading.Condition()
         self._turn = 0
+        self._aborted = False
 
     def run(self, ticket, fn):
         with self._cv:
-            self._cv.wait_for(lambda: self._turn == ticket)
+            self._cv.wait_for(lambda: self._turn == ticket or self._aborted)
+            if self._aborted:
+                raise RuntimeError("turnstile aborted: another lane failed before its turn")
         try:
             return fn()
         finally:
@@ -150,5 +153,11 @@ class Turnstile:
 
     def reset(self, turn=0):
         with self._cv:
-            self._turn = turn
+            self._turn, self._aborted = turn, False
+            self._cv.notify_all()
+
+    def abort(self):
+        """A lane died: release every waiter (their run() raises) instead of leaving them waiting for a ticket that never comes."""
+        with self._cv:
+            self._aborted = True
             self._cv.notify_all()

@@ -284,3 +284,25 @@ def test_two_lanes_issue_their_gathers_in_step_order_world2_gloo(tmp_path):
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "LANES-OK 0" in outs[0] and "LANES-OK 1" in outs[1]
+
+
+def test_turnstile_orders_tickets_and_releases_waiters_when_a_lane_dies():
+    import threading, time
+    from ivideogpt_amd import parallel
+    turn, order, errs = parallel.Turnstile(), [], []
+
+    def lane(tickets, delay):
+        try:
+            for t in tickets:
+                time.sleep(delay)
+                turn.run(t, lambda: order.append(t))
+        except RuntimeError as e:
+            errs.append(str(e))
+
+    ths = [threading.Thread(target=lane, args=([0, 2, 4], 0.02)), threading.Thread(target=lane, args=([1, 3, 5], 0.0))]   # the odd lane is the fast one
+    [t.start() for t in ths]; [t.join(10) for t in ths]
+    assert order == [0, 1, 2, 3, 4, 5] and not errs
+    turn.reset(0)
+    waiter = threading.Thread(target=lane, args=([1], 0.0))   # ticket 0 never comes: its lane "died"
+    waiter.start(); time.sleep(0.05); turn.abort(); waiter.join(10)
+    assert not waiter.is_alive() and errs and "aborted" in errs[0]
