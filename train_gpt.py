@@ -27,49 +27,62 @@ if ROOT not in sys.path:
 
 
 def get_tokenizer(args):
-    """train_gpt.py:128-149 (``ctx_vqgan`` only, as the reference: the plain ``vqgan`` branch raises there too)."""
+    """train_gpt.py:128-149 (``ctx_vqgan`` only, as the reference: the plain ``vqgan`` branch raises there too).
+    -> (tokenizer, size of the transformer's vocabulary: static + dynamic codes, + 2 with the frame-separator tokens)."""
     from ivideogpt_amd import CompressiveVQModel
     if args.vqgan_type != "ctx_vqgan":
-        raise NotImplementedError
-    vq_model = CompressiveVQModel.from_pretrained(args.pretrained_model_name_or_path, subfolder=None, low_cpu_mem_usage=False).eval()
-    if args.context_length != vq_model.context_length:
-        print(f"[Warning] pretrained context length of vq_model mismatch, change from {vq_model.context_length} to {args.context_length}")
-        vq_model.set_context_length(args.context_length)
-    vocab_size = vq_model.num_vq_embeddings + vq_model.num_dyn_embeddings
-    if args.special_token:
-        vocab_size += 2
-    return vq_model, vocab_size
+        raise NotImplementedError(f"vqgan_type {args.vqgan_type!r}: only the compressive tokenizer is on the path")
+    tok = CompressiveVQModel.from_pretrained(args.pretrained_model_name_or_path, subfolder=None, low_cpu_mem_usage=False).eval()
+    had = tok.context_length
+    if had != args.context_length:
+        print(f"[Warning] pretrained context length of vq_model mismatch, change from {had} to {args.context_length}")
+        tok.set_context_length(args.context_length)
+    n_codes = tok.num_vq_embeddings + tok.num_dyn_embeddings
+    return tok, n_codes + (2 if args.special_token else 0)
 
 
 def generate_multiple_times(gen_times, accelerator, model, gen_input, actions, gen_kwargs, max_batch_size=None, verbose=False,
                             reward_prediction=False):
-    """train_gpt.py:152-191: ``gen_times`` samples of every prompt row, ``max_batch_size // B`` repeats per ``generate`` call.
-    -> tokens [t * B, L] with sample k of trajectory b at row k * B + b (what ``Evaluator`` expects)."""
-    max_batch_size = max_batch_size or gen_input.shape[0]
-    assert max_batch_size % gen_input.shape[0] == 0
-    repeat_times = max_batch_size // gen_input.shape[0]
-    assert gen_times % (max_batch_size // gen_input.shape[0]) == 0
-    repeat_iters = gen_times // (max_batch_size // gen_input.shape[0])
-    results, rewards = [], []
-    m = accelerator.unwrap_model(model)
-    for _ in range(repeat_iters):
-        kw = dict(gen_kwargs)
-        if actions is not None:
-            kw["action"] = actions.repeat(repeat_times, 1, 1)
-        if reward_prediction:
-            generated_tokens, reward = m.generate(gen_input.repeat(repeat_times, 1), **kw, pad_token_id=50256, return_reward=True)
-            rewards.append(reward)
-        else:
-            generated_tokens = m.generate(gen_input.repeat(repeat_times, 1), **kw, pad_token_id=50256)
-        results.append(generated_tokens)
+    """train_gpt.py:152-191: ``gen_times`` samples of every prompt row; one ``generate`` call carries ``max_batch_size // B`` copies
+    of the B prompts (``max_batch_size`` None: one copy), so ``gen_times`` must be a multiple of that and ``max_batch_size`` of B
+    (AssertionError otherwise, as the reference).  -> tokens [t * B, L], sample k of trajectory b at row k * B + b (the layout
+    ``Evaluator`` expects); with ``reward_prediction`` also the rewards, concatenated the same way."""
+    B = gen_input.shape[0]
+    cap = B if max_batch_size is None or max_batch_size == 0 else max_batch_size
+    copies, rest = divmod(cap, B)
+    assert rest == 0, f"max_batch_size {cap} is not a multiple of the batch {B}"
+    calls, rest = divmod(gen_times, copies)
+    assert rest == 0, f"gen_times {gen_times} is not a multiple of the {copies} copies one call carries"
+    net = accelerator.unwrap_model(model)
+    prompts = gen_input.repeat(copies, 1)
+    extra = dict(gen_kwargs, pad_token_id=50256)
+    if actions is not None:
+        extra["action"] = actions.repeat(copies, 1, 1)
     if reward_prediction:
-        return torch.cat(results, dim=0), torch.cat(rewards, dim=0)
-    return torch.cat(results, dim=0)   # [t*B, ...] where t means number of generation times
+        extra["return_reward"] = True
+    tokens, rewards = [], []
+    for _ in range(calls):
+        out = net.generate(prompts, **extra)
+        if reward_prediction:
+            tokens.append(out[0]); rewards.append(out[1])
+        else:
+            tokens.append(out)
+    tokens = torch.cat(tokens, dim=0)
+    return (tokens, torch.cat(rewards, dim=0)) if reward_prediction else tokens
 
 
 def batch_forward(batch_size, input, forward, verbose=False):
-    """train_gpt.py:194-195."""
-    return torch.cat([forward(input[i: i + batch_size]) for i in range(0, input.shape[0], batch_size)], dim=0)
+    """train_gpt.py:194-195: ``forward`` over consecutive slices of ``batch_size`` rows, results concatenated."""
+    pieces = [forward(input[lo: lo + batch_size]) for lo in range(0, input.shape[0], batch_size)]
+    return torch.cat(pieces, dim=0)
+
+
+def _prompt_and_budget(args, tokens):
+    """The context part of a tokenized clip and the number of tokens a rollout adds (train_gpt.py:392-403): 256 tokens per context
+    frame and 16 per predicted frame, one more of each with the frame-separator tokens (the last separator is not generated)."""
+    sep = 1 if args.special_token else 0
+    n_future = args.segment_length - args.context_length
+    return tokens[:, :args.context_length * (256 + sep)], (16 + sep) * n_future - sep
 
 
 @torch.no_grad()
@@ -78,76 +91,62 @@ def evaluate(args, accelerator, tokenizer, model, eval_dataloader, evaluator, co
     when ``args.action_conditioned``).  Returns the eval logs on the main process, None elsewhere."""
     if getattr(args, "use_fvd", False):
         raise NotImplementedError("FVD needs the I3D detector weights, which do not ship with the reference (out of scope)")
-    losses = []
-    mse_values, psnr_values, ssim_values, lpips_values = [], [], [], []
-    tok, mdl = accelerator.unwrap_model(tokenizer), accelerator.unwrap_model(model)
+    tok, net = accelerator.unwrap_model(tokenizer), accelerator.unwrap_model(model)
+    dev, ctx = accelerator.device, args.context_length
+    rows = {k: [] for k in ("loss", "mse", "psnr", "ssim", "lpips")}   # per-sample values, gathered over the ranks batch by batch
 
-    for i, batch in enumerate(eval_dataloader):
-        if i == args.max_eval_iters:
+    def keep(name, value, n):
+        rows[name].append(accelerator.gather(value.repeat(n)))
+
+    for it, batch in enumerate(eval_dataloader):
+        if it == args.max_eval_iters:
             break
-        if args.action_conditioned:
-            pixel_values, actions = batch
-            actions = actions.to(accelerator.device, non_blocking=True)
-            pixel_values = pixel_values.to(accelerator.device, non_blocking=True)
-        else:
-            pixel_values, actions = batch.to(accelerator.device, non_blocking=True), None
-        batch_size = pixel_values.shape[0]
+        frames, actions = batch if args.action_conditioned else (batch, None)
+        frames = frames.to(dev, non_blocking=True)
+        actions = actions.to(dev, non_blocking=True) if actions is not None else None
+        n = frames.shape[0]
 
-        tokens, labels = tok.tokenize(pixel_values, args.context_length)
-        model_input = {"input_ids": tokens, "labels": labels}
-        if args.action_conditioned:
-            model_input["action"] = actions
-        if args.reward_prediction:
-            outputs, rewards = mdl(**model_input)
-        else:
-            outputs = mdl(**model_input)
-        loss = outputs.loss
-        losses.append(accelerator.gather(loss.repeat(batch_size)))
+        # teacher-forced loss over the whole clip (:356-376)
+        tokens, labels = tok.tokenize(frames, ctx)
+        fwd = dict(input_ids=tokens, labels=labels)
+        if actions is not None:
+            fwd["action"] = actions
+        out = net(**fwd)
+        keep("loss", (out[0] if args.reward_prediction else out).loss, n)
 
-        # predict next frames
-        recon_output = None
-        if (i % args.log_gif_interval == 0 and accelerator.is_main_process) or args.use_frame_metrics:
-            if args.special_token:
-                gen_input = tokens[:, :args.context_length * (256 + 1)]
-                max_new_tokens = (1 + 16) * (args.segment_length - args.context_length) - 1
-            else:
-                gen_input = tokens[:, :args.context_length * 256]
-                max_new_tokens = 16 * (args.segment_length - args.context_length)
-            gen_kwargs = {"do_sample": True, "temperature": 1.0, "top_k": 100, "max_new_tokens": max_new_tokens}
-            out = generate_multiple_times(args.eval_generate_times, accelerator, model, gen_input, actions if args.action_conditioned else None,
-                                          gen_kwargs=gen_kwargs, max_batch_size=args.max_generate_batchsize, verbose=False,
-                                          reward_prediction=args.reward_prediction)
-            generated_tokens = out[0] if args.reward_prediction else out
-            if args.max_decode_batchsize is not None and generated_tokens.shape[0] > args.max_decode_batchsize:
-                recon_output = batch_forward(args.max_decode_batchsize, generated_tokens, lambda x: tok.detokenize(x, args.context_length))
-            else:
-                recon_output = tok.detokenize(generated_tokens, args.context_length)   # generated_tokens include gen_input
-            recon_output = recon_output.clamp(0.0, 1.0)
-
-        if i % args.log_gif_interval == 0 and accelerator.is_main_process and not args.use_frame_metrics:
-            assert pixel_values.shape[0] == recon_output.shape[0]
-            mse_values.append(torch.mean((pixel_values.float() - recon_output) ** 2).repeat(batch_size))
+        # rollout from the context frames, t samples per trajectory, decoded back to pixels (:390-430)
+        show = it % args.log_gif_interval == 0 and accelerator.is_main_process
+        recon = None
+        if show or args.use_frame_metrics:
+            prompt, budget = _prompt_and_budget(args, tokens)
+            sampled = generate_multiple_times(args.eval_generate_times, accelerator, model, prompt, actions,
+                                              gen_kwargs=dict(do_sample=True, temperature=1.0, top_k=100, max_new_tokens=budget),
+                                              max_batch_size=args.max_generate_batchsize, reward_prediction=args.reward_prediction)
+            sampled = sampled[0] if args.reward_prediction else sampled       # prompt included
+            decode = lambda ids: tok.detokenize(ids, ctx)
+            chunk = args.max_decode_batchsize
+            recon = batch_forward(chunk, sampled, decode) if chunk is not None and sampled.shape[0] > chunk else decode(sampled)
+            recon = recon.clamp(0.0, 1.0)
 
         if args.use_frame_metrics:
-            # pixel_values can be 1.0000001192092896 numerically (train_gpt.py:470-471)
-            mse_value, psnr_value, ssim_value, lpips_value = evaluator(pixel_values.clamp(0.0, 1.0), recon_output)
-            mse_values.append(accelerator.gather(mse_value.repeat(batch_size)))
-            psnr_values.append(accelerator.gather(psnr_value.repeat(batch_size)))
-            ssim_values.append(accelerator.gather(ssim_value.repeat(batch_size)))
-            lpips_values.append(accelerator.gather(lpips_value.repeat(batch_size)))
+            # the ground truth is clamped too: resized frames overshoot 1.0 by an ulp (:470-471)
+            for name, value in zip(("mse", "psnr", "ssim", "lpips"), evaluator(frames.clamp(0.0, 1.0), recon)):
+                keep(name, value, n)
+        elif show:   # no metric pass: the plain pixel MSE of the shown batch stands in for eval/mse (:447-449), not gathered
+            assert recon.shape[0] == n, "the fallback compares one sample per trajectory"
+            rows["mse"].append(((frames.float() - recon) ** 2).mean().repeat(n))
 
     if not accelerator.is_main_process:
         return None
-    eval_loss = torch.cat(losses, 0).mean().item()
+    mean = lambda name: torch.cat(rows[name], 0).mean().item() if rows[name] else float("nan")
+    eval_loss = mean("loss")
     try:
         perplexity = math.exp(eval_loss)
     except OverflowError:
         perplexity = float("inf")
-    eval_logs = {"eval/eval_loss": eval_loss, "eval/perplexity": perplexity,
-                 "eval/mse": torch.cat(mse_values, 0).mean().item() if mse_values else float("nan")}
+    eval_logs = {"eval/eval_loss": eval_loss, "eval/perplexity": perplexity, "eval/mse": mean("mse")}
     if args.use_frame_metrics:
-        eval_logs.update({"eval/psnr": torch.cat(psnr_values, 0).mean().item(), "eval/ssim": torch.cat(ssim_values, 0).mean().item(),
-                          "eval/lpips": torch.cat(lpips_values, 0).mean().item()})
+        eval_logs.update({f"eval/{k}": mean(k) for k in ("psnr", "ssim", "lpips")})
     accelerator.log(eval_logs, step=completed_steps)
     return eval_logs
 
