@@ -357,8 +357,12 @@ def main():
     single = None
     if a.lanes > 1:
         lanes = [dict(tok=tok, model=model, pixels=pixels, actions=actions, gen=sample_gen, stream=torch.cuda.Stream(device=dev))]
-        for i in range(1, a.lanes):   # further lanes: their own engines (same weights: seeded) and their own resident batch
-            _, _, _, _, tok_i, model_i = build_models(dev, a.res, a.medium, a.encode_dtype, a.decode_dtype, a.llm_dtype, a.action_dim, a.ctx or None, a.frames)
+        share = os.environ.get("IVG_LANE_SHARE", "1") != "0"   # (0: every lane packs a copy of the weights of its own -- A/B)
+        for i in range(1, a.lanes):   # further lanes: their own engines over the SAME weights in HBM, and their own resident batch
+            if share:
+                tok_i, model_i = tok.replica(), model.replica()
+            else:
+                _, _, _, _, tok_i, model_i = build_models(dev, a.res, a.medium, a.encode_dtype, a.decode_dtype, a.llm_dtype, a.action_dim, a.ctx or None, a.frames)
             gi = torch.Generator(device=dev).manual_seed(1000 + rank + 7919 * i)
             lanes.append(dict(tok=tok_i, model=model_i, pixels=torch.rand(B, T, 3, a.res, a.res, device=dev, generator=gi).to(torch.bfloat16),
                               actions=torch.randn(B, T, a.action_dim, device=dev, generator=gi) if a.action_dim else None,

@@ -84,6 +84,27 @@ class LlamaForCausalLM:
         self.torch_dtype = torch_dtype(dtype_code(dtype))
         self.device = torch.device("cpu")
         self._engine = None
+        self._packed, self._packed_key = None, None   # the packed weights in HBM, kept across engine rebuilds and shared by replicas
+
+    def _pack_key(self):
+        return (id(self._sd), self._prefix, str(self.device), self.dtype)
+
+    def _packed_weights(self):
+        if self._packed is None or self._packed_key != self._pack_key():
+            self._packed = pack_llama(self._sd, self._cfg, self.device, dtype_code(self.dtype), prefix=self._prefix)
+            self._packed_key = self._pack_key()
+        return self._packed
+
+    def replica(self):
+        """A second model object over the SAME weights in HBM (the engine only reads them): its own engine -- KV cache, workspace --
+        for a second batch in flight on another stream / host thread (bench.py --lanes; INTEGRATION.md, streams)."""
+        if self.device.type != "cuda":
+            raise RuntimeError("replica(): call .to('cuda') first")
+        r = LlamaForCausalLM(self._cfg, self._sd, dtype=self.dtype, prefix=self._prefix, action_dim=self._action_dim,
+                             reward_prediction=self._reward)
+        r.device = self.device
+        r._packed, r._packed_key = self._packed_weights(), self._pack_key()
+        return r
 
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, subfolder="transformer", low_cpu_mem_usage=False, dtype="bf16",
@@ -143,8 +164,7 @@ class LlamaForCausalLM:
         cap_b = max(B, e.max_batch if e else 0)
         cap_t = max(frames, e.max_frames if e else 0)
         self._drop_engine()
-        tensors = pack_llama(self._sd, self._cfg, self.device, dtype_code(self.dtype), prefix=self._prefix)
-        self._engine = Engine(self.device, tensors, llm_cfg=self._cfg, action_dim=self._action_dim or 0,
+        self._engine = Engine(self.device, self._packed_weights(), llm_cfg=self._cfg, action_dim=self._action_dim or 0,
                               reward_head=self._reward, llm_dtype=self.dtype, max_batch=cap_b, max_frames=cap_t)
         return self._engine
 
@@ -251,6 +271,15 @@ class HeadModelWithAction:
     def get_input_embeddings(self, input_ids):
         """action_model.py:47-54."""
         return self.llm.get_input_embeddings()(input_ids)
+
+    def replica(self):
+        """As LlamaForCausalLM.replica: a second wrapper (own engine) over the same weights in HBM."""
+        llm = self.llm.replica()
+        packed, key = llm._packed, llm._packed_key
+        r = HeadModelWithAction(llm, self.action_dim, self.prelude_tokens_num, self.tokens_num_per_dyna, self.context, self.segment_length,
+                                model_type=self.model_type, reward_prediction=self.reward_prediction, action_recon=self.action_recon)
+        llm._packed, llm._packed_key = packed, key
+        return r
 
     def load_state_dict(self, sd, strict=True):
         if strict:

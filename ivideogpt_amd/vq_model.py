@@ -53,7 +53,32 @@ class CompressiveVQModel:
         self.encode_dtype, self.decode_dtype = encode_dtype, decode_dtype
         self.device = torch.device("cpu")
         self._engine = None
+        self._packed, self._packed_key = None, None   # the packed weights in HBM, kept across engine rebuilds and shared by replicas
         self.training = False
+
+    def _pack_key(self):
+        return (id(self._sd), str(self.device), self.encode_dtype, self.decode_dtype, self._pretrained_context)
+
+    def _packed_weights(self, cfg):
+        from .packing import dtype_code
+        if self._packed is None or self._packed_key != self._pack_key():
+            self._packed = pack_tokenizer(self._sd, cfg, self.device, dtype_code(self.encode_dtype), dtype_code(self.decode_dtype))
+            self._packed_key = self._pack_key()
+        return self._packed
+
+    def replica(self):
+        """A second tokenizer object over the SAME weights in HBM (the engine only reads them), with its own engine (workspace,
+        detokenize caches): a second batch in flight on another stream / host thread (bench.py --lanes)."""
+        if self.device.type != "cuda":
+            raise RuntimeError("replica(): call .to('cuda') first")
+        cfg = dict(self.config)
+        cfg["context_length"] = self._pretrained_context
+        r = CompressiveVQModel(cfg, self._sd, encode_dtype=self.encode_dtype, decode_dtype=self.decode_dtype)
+        r.device = self.device
+        r._packed, r._packed_key = self._packed_weights(cfg), self._pack_key()
+        if self.context_length != self._pretrained_context:
+            r.set_context_length(self.context_length)
+        return r
 
     # ------------------------------------------------------------------ construction / plumbing
     @classmethod
@@ -120,9 +145,7 @@ class CompressiveVQModel:
         self._drop_engine()
         cfg = dict(self.config)
         cfg["context_length"] = self._pretrained_context
-        from .packing import dtype_code
-        tensors = pack_tokenizer(self._sd, cfg, self.device, dtype_code(self.encode_dtype), dtype_code(self.decode_dtype))
-        self._engine = Engine(self.device, tensors, tok_cfg=cfg, encode_dtype=self.encode_dtype, decode_dtype=self.decode_dtype,
+        self._engine = Engine(self.device, self._packed_weights(cfg), tok_cfg=cfg, encode_dtype=self.encode_dtype, decode_dtype=self.decode_dtype,
                               max_batch=cap_b, max_frames=cap_t)
         if self.context_length != self._pretrained_context:
             self._engine.set_context_length(self.context_length)

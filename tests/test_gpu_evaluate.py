@@ -189,3 +189,24 @@ def test_bench_two_lanes_gathers_through_rccl():
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert d["config"]["lanes"] == 2 and d["steps"] == 6 and d["value"] > 0
+
+
+def test_replica_shares_the_weights_and_reproduces_the_original():
+    """``replica()``: a second model object with its own engine over the SAME packed weights in HBM (what bench.py's second lane
+    runs on) -- same tokens and frames as the original, bit for bit, and no second copy of the weights."""
+    from ivideogpt_amd import CompressiveVQModel, LlamaForCausalLM, weights as W
+    from ivideogpt_amd.pipeline import predict_frames
+    tcfg = W.tokenizer_config(**TOK_CFG)
+    tok = CompressiveVQModel(tcfg, W.random_tokenizer_state_dict(tcfg, 97, codebook_std=0.4), encode_dtype="fp32", decode_dtype="bf16").to(DEV)
+    llm = LlamaForCausalLM(dict(LLM_CFG), W.random_llama_state_dict(LLM_CFG, 98), dtype="bf16").to(DEV)
+    ctx, F_ = 2, 3
+    g = torch.Generator().manual_seed(99)
+    px = torch.rand(5, ctx + F_, 3, 64, 64, generator=g).to(DEV)
+    u = torch.rand(5, 17 * F_ - 1, generator=g).to(DEV)
+    f0, t0 = predict_frames(tok, llm, px, ctx, F_, uniforms=u, return_tokens=True)
+    tok2, llm2 = tok.replica(), llm.replica()
+    f1, t1 = predict_frames(tok2, llm2, px, ctx, F_, uniforms=u, return_tokens=True)
+    torch.cuda.synchronize()
+    assert torch.equal(t0, t1) and torch.equal(f0, f1)
+    assert llm2._engine is not llm._engine and llm2._engine.tensors is llm._engine.tensors
+    assert tok2._engine is not tok._engine and tok2._engine.tensors is tok._engine.tensors
