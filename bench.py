@@ -8,8 +8,8 @@ A step = one pass of the hot path over one batch of synthetic clips already resi
     encode the context frames -> autoregressive rollout (17*F - 1 tokens) -> decode all T frames -> clamp(0, 1)
 (BASELINE.json configs[1]: ivideogpt-oxe-64-act-free shapes, synthetic 64x64 bf16 pixels, 64 trajectories per GPU,
 2 context + 14 predicted frames; seeded random weights of the real architecture -- no checkpoints exist offline).
-Two batches are kept in flight per GPU by default (``--lanes 2``: two engine instances, each with its own KV cache, workspace, HIP
-stream and host thread; the K timed steps are dealt round-robin to the lanes): the MFMA-bound convolutions of one batch's encode /
+Two batches are kept in flight per GPU by default (``--lanes 2``: two engine instances over one copy of the weights, each with its own
+KV cache, workspace, HIP stream and host thread; the K timed steps are dealt round-robin to the lanes): the MFMA-bound convolutions of one batch's encode /
 decode run beside the latency- and HBM-bound rollout of the other.  ``value`` counts the frames of exactly K steps over the wall
 clock; ``single_lane`` in the line is the same pipeline with one batch in flight (``--lanes 1``; the latency of a batch).
 Multi-GPU: independent trajectories shard by batch rows (weak scaling: 64 per GPU), no data-path collective; the
