@@ -90,6 +90,15 @@ void ivg_destroy(ivg_engine* e);
 const char* ivg_last_error(const ivg_engine* e);   /* e may be NULL: error of the last failed ivg_create */
 const char* ivg_version(void);
 
+/* The run-time switches (IVG_* environment variables, listed in ivideogpt_amd/csrc/switches.h) are read when the library is
+ * loaded and at every ivg_create; a process that changes one afterwards (the A/B tests do) calls this to publish the change. */
+void ivg_reload_switches(void);
+
+/* `temperature` of every generate call of the reference (HF generate(..., temperature=...): inference/predict.py:61,
+ * ivideogpt/transformer/action_model.py:61,89,104,128,143): the logits are divided by it before the top-k filter
+ * (TemperatureLogitsWarper).  Engine state, default 1.0; IVG_ERR_INVALID unless strictly positive and finite (HF raises). */
+int ivg_set_temperature(ivg_engine* e, float temperature);
+
 /* CompressiveVQModel.set_context_length (compressive_vq_model.py:154-158): keeps the LAST k frames of kv_pos_emb. */
 int ivg_set_context_length(ivg_engine* e, int context_length);
 
@@ -261,8 +270,9 @@ int ivg_op_add_rmsnorm(void* x, const float* part, int splits, const float* w, v
 int ivg_op_conv_in(const void* video, int video_dtype, const float* w, const float* bias, void* Y, int dtype, int N, int per,
                    int T_total, int t0, int H, int W, int C0, ivg_stream stream);
 /* one top-k draw per logits row [B][V] fp32 with the rollout's sampler (uniforms [B] in [0,1), or NULL = greedy): HF
- * TopKLogitsWarper + softmax + draw as restated by oracle/llama.py sample_from_logits */
-int ivg_op_sample(const float* logits, int B, int V, int top_k, const float* uniforms, int64_t* out, ivg_stream stream);
+ * TemperatureLogitsWarper (logits / temperature, > 0) + TopKLogitsWarper + softmax + draw as restated by oracle/llama.py
+ * sample_from_logits */
+int ivg_op_sample(const float* logits, int B, int V, int top_k, float temperature, const float* uniforms, int64_t* out, ivg_stream stream);
 
 #ifdef __cplusplus
 }

@@ -56,6 +56,8 @@ EXPORTS = {
     "ivg_last_error": (C.c_char_p, [C.c_void_p]),
     "ivg_create": (C.c_int, [C.POINTER(IvgConfig), C.POINTER(IvgTensor), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "ivg_destroy": (None, [C.c_void_p]),
+    "ivg_reload_switches": (None, []),
+    "ivg_set_temperature": (C.c_int, [C.c_void_p, C.c_float]),
     "ivg_set_context_length": (C.c_int, [C.c_void_p, C.c_int]),
     "ivg_tokenize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ivg_encode_context": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -98,7 +100,7 @@ EXPORTS = {
     "ivg_op_add_rmsnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
                                      C.c_int, C.c_void_p]),
     "ivg_op_conv_in": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]),
-    "ivg_op_sample": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ivg_op_sample": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None
@@ -119,6 +121,12 @@ def load():
         fn.restype, fn.argtypes = res, args
     _lib = lib
     return lib
+
+
+def reload_switches():
+    """Publish the current IVG_* environment variables to the library (csrc/switches.h): read at load and at every ivg_create;
+    a test that flips one between two op-level calls calls this."""
+    load().ivg_reload_switches()
 
 
 def last_error(handle=None):

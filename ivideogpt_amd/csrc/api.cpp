@@ -5,6 +5,7 @@
 
 #include <cstdio>
 #include "engine_impl.h"
+#include "switches.h"
 
 using namespace ivg;
 
@@ -262,8 +263,6 @@ void ivg_destroy(ivg_engine* e) {
   (void)hipSetDevice(e->device);
   (void)hipDeviceSynchronize();
   for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
-  if (e->fork_ev) (void)hipEventDestroy(e->fork_ev);
-  for (int i = 0; i < 7; ++i) { if (e->join_ev[i]) (void)hipEventDestroy(e->join_ev[i]); if (e->side[i]) (void)hipStreamDestroy(e->side[i]); }
   for (int k = 0; k < IVG_K_COUNT; ++k) {
     for (auto& s : e->prof[k].used) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     for (auto& s : e->prof[k].pool) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
@@ -288,13 +287,12 @@ int ivg_create(const ivg_config* cfg, const ivg_tensor* weights, int n_weights, 
   e->cfg = *cfg; e->device = device;
   auto bail = [&](int code) { g_create_err = e->err; ivg_destroy(e); return code; };
   if (hipSetDevice(device) != hipSuccess) { e->err = "hipSetDevice failed (no MI355X visible?)"; return bail(IVG_ERR_HIP); }
+  reload_switches();   // the one place the environment is read (switches.h)
   // Decode steps are launched eagerly by default: on ROCm 7.2 a replayed hipGraph leaves ~1 us MORE between two dependent kernel
   // nodes than the same kernels launched one by one on the stream (config-2 rollout: 166 ms replayed, 149 ms eager; the host
   // issues a launch in ~4 us against ~10 us of device time per kernel, so it stays ahead).  IVG_GRAPH=1 captures the step into
-  // a hipGraph (8 steps per launch) for callers that need the host thread back early; IVG_NO_GRAPH=1 wins over it.
-  const char* ng = getenv("IVG_NO_GRAPH");
-  const char* yg = getenv("IVG_GRAPH");
-  e->use_graph = (yg && yg[0] == '1') && !(ng && ng[0] == '1');
+  // a hipGraph (8 steps per launch) for callers that need the host thread back early.
+  e->use_graph = sw().graph != 0;
   e->enc_dt = (DType)cfg->encode_dtype; e->dec_dt = (DType)cfg->decode_dtype; e->llm_dt = (DType)cfg->llm_dtype;
   e->ctx = cfg->context_length > 0 ? cfg->context_length : 1;
   for (int i = 0; i < n_weights; ++i) e->wmap[weights[i].name] = weights[i];
@@ -331,15 +329,6 @@ int ivg_create(const ivg_config* cfg, const ivg_tensor* weights, int n_weights, 
     (void)hipMemset(e->attn_prof, 0, (size_t)cfg->num_layers * IVG_ATTN_PROF_SLOTS * 2 * e->Lmax * 8);
     (void)hipMemset(e->vt, 0, vtb);
     (void)hipMemset(e->gen_buf, 0, e->gen_bytes);
-    {
-      const char* ch = getenv("IVG_CHAINS");
-      if (ch) e->chains = std::max(1, std::min(8, atoi(ch)));
-      bool ok = hipEventCreateWithFlags(&e->fork_ev, hipEventDisableTiming) == hipSuccess;
-      for (int i = 0; i < 7 && ok; ++i)
-        ok = hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking) == hipSuccess &&
-             hipEventCreateWithFlags(&e->join_ev[i], hipEventDisableTiming) == hipSuccess;
-      if (!ok) { e->err = "could not create the side streams of the decode step"; return bail(IVG_ERR_HIP); }
-    }
   }
   int rc = plan_and_allocate(e);
   if (rc) return bail(rc);
@@ -377,6 +366,15 @@ int ivg_encode_context(ivg_engine* e, const void* pixels, int pixel_dtype, int B
   if (T < e->ctx || ids_stride < 257L * e->ctx) return e->fail(IVG_ERR_INVALID, "encode_context: T < context_length or ids_stride < 257*ctx");
   return plan_then_run(e, (hipStream_t)stream, [&](Run& r) {
     return r.tokenize(pixels, (DType)pixel_dtype, B, T, ids_out, ids_stride, nullptr, true); });
+}
+
+void ivg_reload_switches(void) { reload_switches(); }
+
+int ivg_set_temperature(ivg_engine* e, float temperature) {
+  if (!e) return IVG_ERR_INVALID;
+  if (!(temperature > 0.0f) || !std::isfinite(temperature)) return e->fail(IVG_ERR_INVALID, "temperature must be a strictly positive float");   // HF raises the same
+  e->temperature = temperature;
+  return IVG_OK;
 }
 
 int ivg_set_output_clamp(ivg_engine* e, int on) {
@@ -620,7 +618,6 @@ int ivg_profile_read(ivg_engine* e, int k, ivg_profile_stats* out) {
     // single launches): last ivg_generate call only; bytes = K and V rows read per launch
     out->launches = 0; out->total_ms = 0; out->total_flops = 0; out->total_bytes = 0;
     if (!e->attn_prof) return IVG_OK;
-    if (getenv("IVG_ATTN_DEBUG")) attn_debug_dump();
     const int L = e->Lmax, nl = e->cfg.num_layers, NS = IVG_ATTN_PROF_SLOTS;
     std::vector<unsigned long long> h((size_t)nl * NS * 2 * L);
     API_CK(hipMemcpy(h.data(), e->attn_prof, h.size() * 8, hipMemcpyDeviceToHost));
@@ -784,7 +781,8 @@ int ivg_op_conv_in(const void* video, int video_dtype, const float* w, const flo
   return launch_conv_in(video, (DType)video_dtype, w, bias, Y, (DType)dtype, N, per, T_total, t0, H, W, C0, (hipStream_t)stream) ? IVG_ERR_HIP : IVG_OK;
 }
 
-int ivg_op_sample(const float* logits, int B, int V, int top_k, const float* uniforms, int64_t* out, ivg_stream stream) {
+int ivg_op_sample(const float* logits, int B, int V, int top_k, float temperature, const float* uniforms, int64_t* out, ivg_stream stream) {
+  if (!(temperature > 0.0f)) return IVG_ERR_INVALID;
   // one draw per row through the rollout's sampler kernel (token j = 1 of a prompt of length 0; no embedding: H = 0)
   StepState* state = nullptr;
   if (hipMalloc((void**)&state, sizeof(StepState)) != hipSuccess) return IVG_ERR_HIP;
@@ -794,18 +792,9 @@ int ivg_op_sample(const float* logits, int B, int V, int top_k, const float* uni
   sa.logits = logits; sa.V = V; sa.uniforms = uniforms; sa.n_uni = 1; sa.top_k = top_k;
   sa.ids_out = out; sa.ids_stride = 1; sa.L0 = 0; sa.forced_period = 0; sa.forced_token = 0;
   sa.E = logits; sa.x = out; sa.H = 0; sa.act = nullptr; sa.act_T = 0; sa.ctx = 1; sa.slot0 = 0; sa.state = state;
-  long long* dbg = nullptr;
-  if (getenv("IVG_SAMPLE_DEBUG")) { (void)hipMalloc((void**)&dbg, 32 * 8); (void)hipMemset(dbg, 0, 32 * 8); }
-  sa.dbg = dbg;
+  sa.temperature = temperature;
   if (!rc) rc = launch_sample_embed(sa, B, F32, st);
   (void)hipStreamSynchronize(st);
-  if (dbg) {
-    long long h[32]; (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
-    fprintf(stderr, "[sample dbg] %d stamps, cycles between:", (int)h[31]);
-    for (int i = 1; i < (int)h[31] && i < 31; ++i) fprintf(stderr, " %lld", h[i] - h[i - 1]);
-    fprintf(stderr, "\n");
-    (void)hipFree(dbg);
-  }
   (void)hipFree(state);
   return rc ? IVG_ERR_HIP : IVG_OK;
 }

@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <mutex>
+
 namespace ivg {
 
 typedef __bf16 bf16_t;
@@ -72,15 +75,21 @@ __device__ __forceinline__ float row16_sum(float d) {
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
-// One-time per-DEVICE guard for hipFuncSetAttribute (the attribute is per device; a process may hold engines on several GPUs):
-// true the first time it is called for `mask` on the current device.
-static inline bool first_time_on_device(unsigned long long& mask) {
+// One-time per-DEVICE hipFuncSetAttribute(MaxDynamicSharedMemorySize) of a kernel (the attribute is per device; a process may
+// hold engines on several GPUs and drive them from several host threads: bench.py --lanes, replica()).  The device's bit is
+// published only AFTER the attribute call has returned, and late arrivals wait on the mutex -- a second thread can never launch
+// a > 64 KiB dynamic-LDS kernel between another thread's "first time" test and its attribute call.
+struct DynLdsOnce { std::atomic<unsigned long long> done{0}; std::mutex mu; };
+static inline hipError_t ensure_dyn_lds(DynLdsOnce& g, const void* fn, int bytes) {
   int d = 0;
   (void)hipGetDevice(&d);
   const unsigned long long bit = 1ull << (d & 63);
-  if (mask & bit) return false;
-  mask |= bit;
-  return true;
+  if (g.done.load(std::memory_order_acquire) & bit) return hipSuccess;
+  std::lock_guard<std::mutex> lk(g.mu);
+  if (g.done.load(std::memory_order_relaxed) & bit) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) g.done.fetch_or(bit, std::memory_order_release);
+  return e;
 }
 
 }  // namespace ivg

@@ -35,6 +35,7 @@
 #include <type_traits>
 
 #include "igemm.h"
+#include "switches.h"
 
 namespace ivg {
 
@@ -549,12 +550,14 @@ static int launch_c3(const Conv3Dev& d, int nimg, hipStream_t stream) {
   // the statistics partials of the epilogue sit behind the staging tile (the main-loop buffers are dead by then)
   if (d.gn_part) { dd.gn_off = dd.stage_ok ? ((stage + 15) & ~15) : 0; smem = std::max(smem, dd.gn_off + 2 * 4 * BN * 4); }
   if constexpr (GNA) { dd.coef_off = (smem + 15) & ~15; smem = dd.coef_off + 2 * (4 * Traits<T>::VEC) * 8; }
-  static unsigned long long attr_set = 0;
+  // IVG_CONV_CAP=1: ONE workgroup per CU -- the request is padded past half of a CU's 160 KiB, so a second workgroup of this grid
+  // never fits beside the first and half of the LDS, of the wave slots (8 of 16 per SIMD pair) and of the registers stay free for the
+  // short kernels of ANOTHER batch in flight (decode attention, decode GEMMs planned under IVG_DECODE_LDS_KB): MFMA-bound waves
+  // beside HBM- / latency-bound ones instead of a grid that holds every CU until it drains.
+  if (sw().conv_cap) smem = std::max(smem, 82 * 1024);
+  static DynLdsOnce once;
   auto kfn = conv3x3_kernel<T, BN, UPS, TW, GNA, TPB2>;
-  if (first_time_on_device(attr_set)) {
-    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-  }
+  if (hipError_t e = ensure_dyn_lds(once, (const void*)kfn, 160 * 1024); e != hipSuccess) return (int)e;
   const long blocks = (long)nimg * d.tiles_per_img * d.tiles_n;
   hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(512), smem, stream, dd);
   return (int)hipGetLastError();
@@ -562,11 +565,7 @@ static int launch_c3(const Conv3Dev& d, int nimg, hipStream_t stream) {
 
 int conv3x3_gn_chunks_bound(int Hout, int Wout, int N) { return cdiv((long)Hout * Wout, 256) * cdiv(N, 64); }
 
-bool conv3x3_enabled() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("IVG_CONV3X3"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v == 1;
-}
+bool conv3x3_enabled() { return sw().conv3x3 != 0; }
 
 // Returns -1 when the shape is not covered (caller falls back to the generic implicit GEMM).
 int launch_conv3x3(const IgemmArgs& a, DType dtype, hipStream_t stream) {
@@ -602,15 +601,12 @@ int launch_conv3x3(const IgemmArgs& a, DType dtype, hipStream_t stream) {
     d.gn_part = (double2*)a.gn_part; d.gn_groups = a.gn_groups;
     a.gn_chunks = d.tiles_per_img * d.tiles_n;
   }
-  // IVG_C3_TPB=1: one step per barrier everywhere (A/B); default: two steps per barrier for bf16
-  static int tpb = -1;
-  if (tpb < 0) { const char* e = getenv("IVG_C3_TPB"); tpb = e ? atoi(e) : 2; }
 #define IVG_C3_TW(T, BNv, U, G, PR) (TW == 16 ? launch_c3<T, BNv, U, 16, G, PR>(d, a.Nimg, stream) : launch_c3<T, BNv, U, 32, G, PR>(d, a.Nimg, stream))
 #define IVG_C3_BN(T, U, G, PR) (bn == 128 ? IVG_C3_TW(T, 128, U, G, PR) : IVG_C3_TW(T, 64, U, G, PR))
   if (gna) return dtype == BF16 ? IVG_C3_BN(bf16_t, false, true, false) : IVG_C3_BN(float, false, true, false);
   // (measured per shape, profiles/r02_conv3x3_tpb.txt: +2 ... +3.5 % on the plain convolutions, -0.8 % on the upsampling ones,
   // whose 32-pixel-row instance also spills registers in the two-step form: those keep one step per barrier)
-  if (tpb == 2 && dtype == BF16 && !a.ups) return IVG_C3_BN(bf16_t, false, false, true);
+  if (dtype == BF16 && !a.ups) return IVG_C3_BN(bf16_t, false, false, true);   // two steps per barrier
   if (a.ups) return dtype == BF16 ? IVG_C3_BN(bf16_t, true, false, false) : IVG_C3_BN(float, true, false, false);
   return dtype == BF16 ? IVG_C3_BN(bf16_t, false, false, false) : IVG_C3_BN(float, false, false, false);
 #undef IVG_C3_BN

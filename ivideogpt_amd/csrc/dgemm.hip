@@ -21,6 +21,7 @@
 #include <cstdlib>
 
 #include "igemm.h"
+#include "switches.h"
 
 namespace ivg {
 
@@ -324,12 +325,9 @@ static int launch_dg(const DgDev& d, int waves, hipStream_t stream) {
   const int comb = waves * nfrag * 64 * 16 + waves * MF * 16 * 4;
   const int smem = std::max(stage, comb);
   if (smem > 160 * 1024 || waves > WMAX) return -1;
-  static unsigned long long attr_set = 0;
+  static DynLdsOnce once;
   auto kfn = dgemm_kernel<T, MF, FN, LG, WMAX>;
-  if (first_time_on_device(attr_set)) {
-    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-  }
+  if (hipError_t e = ensure_dyn_lds(once, (const void*)kfn, 160 * 1024); e != hipSuccess) return (int)e;
   dim3 grid((unsigned)cdiv(d.N, 16 * FN), (unsigned)cdiv(d.M, 16 * MF), 1);
   hipLaunchKernelGGL(kfn, grid, dim3(waves * 64), smem, stream, d);
   return (int)hipGetLastError();
@@ -357,7 +355,6 @@ static bool dg_split(long chunks, DgSplit& s) {
   return false;
 }
 
-static int g_dg_force[4] = {0, 0, 0, 0};   // IVG_DG_FORCE=MF,FN,WAVES,LG (tools/dgemm_sweep.py)
 
 // Measured picks (tools/dgemm_sweep.py on MI355X, profiles/r02_dgemm_sweep_*.txt) for the GEMMs of the released transformers,
 // keyed by (K bytes, N) -- never by the batch, so the K partition of a GEMM is fixed.  mf caps the row tiles per workgroup.
@@ -400,10 +397,7 @@ int dgemm_w_rows_per_block(const SkinnyArgs& a, DType dtype) {
 
 // -1: shape not covered (caller falls back to skinny.hip); otherwise a hipError_t
 int launch_dgemm(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
-  {
-    const char* v = getenv("IVG_DG");   // IVG_DG=0: first-generation kernel only (A/B runs)
-    if ((v && v[0] == '0') || a.splits > 1) return -1;
-  }
+  if (!sw().dg || a.splits > 1) return -1;   // IVG_DG=0: first-generation kernel only (A/B runs)
   const int es = dtype == BF16 ? 2 : 4;
   if (a.M <= 0 || a.N <= 0 || a.M > 128) return -1;
   if (((long)a.K * es) % 128 != 0 || ((long)a.ldx * es) % 16 != 0 || ((long)a.ldw * es) % 16 != 0) return -1;
@@ -434,43 +428,33 @@ int launch_dgemm(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
     nburst = (int)(chunks / ((long)waves * 8 * lgv));
     break;
   }
-  const char* ff = getenv("IVG_DG_FORCE");   // development: MF,FN,WAVES,LG of every launch (tools/dgemm_sweep.py)
-  const bool forced = ff && sscanf(ff, "%d,%d,%d,%d", &g_dg_force[0], &g_dg_force[1], &g_dg_force[2], &g_dg_force[3]) == 4;
-  if (forced) {
-    const long chunks = (long)a.K * es / 16;
-    MF = g_dg_force[0]; FN = g_dg_force[1]; waves = g_dg_force[2]; lgv = g_dg_force[3];
-    if (waves <= 0 || lgv <= 0 || chunks % ((long)waves * 8 * lgv) != 0) return (int)hipErrorInvalidValue;
-    nburst = (int)(chunks / ((long)waves * 8 * lgv));
-    if (glu && FN < 2) return (int)hipErrorInvalidValue;
-  }
   // The wave count (the K partition) is a function of (K bytes, N) only; the register class that holds it bounds the fragments a
   // workgroup may own (launch_dg_t: <= 4 waves any tile, <= 8 waves MF * FN <= 8, 16 waves MF * FN <= 2).  A tile the batch size
   // asked for that does not fit is CLAMPED here -- never answered with -1: falling back to skinny.hip for some batch sizes only
   // would give a trajectory a different K-summation order depending on its batch-mates (fp32 parity mode: M = 64 vs a 16-row shard).
-  if (!forced) {
+  {
     const int allowed = waves <= 4 ? 16 : (waves <= 8 ? 8 : 2);
     while (MF * FN > allowed && MF > 1) MF >>= 1;
     while (MF * FN > allowed && FN > (glu ? 2 : 1)) FN >>= 1;
   }
   // staging budget: waves * LG * (MF + FN) * 2 KiB of LDS.  Over budget: first more (shorter) bursts per wave -- the K partition over
   // the waves, and so every sum order, stays what it is -- then fewer row tiles per workgroup
-  while (lgv > 1 && waves * lgv * (MF + FN) * 2048 > 160 * 1024) {
+  const int budget = sw().decode_lds_kb * 1024;   // (IVG_DECODE_LDS_KB: room left for another batch's conv3x3 workgroup on the CU)
+  while (lgv > 1 && waves * lgv * (MF + FN) * 2048 > budget) {
     const int total = lgv * nburst;           // lines per wave
     --lgv;
     while (total % lgv != 0) --lgv;
     nburst = total / lgv;
   }
-  while (MF > 1 && waves * lgv * (MF + FN) * 2048 > 160 * 1024) MF >>= 1;
+  while (MF > 1 && waves * lgv * (MF + FN) * 2048 > budget) MF >>= 1;
   DgDev d{a.X, a.W, a.Y, a.M, a.N, a.K, a.ldx, a.ldw, a.ldy, a.flags, a.eps, a.bump, nburst, a.pos ? a.prof : nullptr, a.pos, a.prof_ld, a.dbg,
           nullptr, 0u, 0, 0};
-  static const bool pf_off = [] { const char* v = getenv("IVG_DG3_WARM"); return v && v[0] == '0'; }();
-  if (a.next_W && a.next_tile_bytes >= 1024 && a.next_tiles > 0 && !pf_off) {
+  if (a.next_W && a.next_tile_bytes >= 1024 && a.next_tiles > 0 && sw().dg3_warm) {
     const long grid = (long)cdiv(a.N, 16 * FN) * cdiv(a.M, 16 * MF);
     const long waves_per_xcd = std::max(1L, grid / 8) * waves;
     const long units_per_xcd = (long)cdiv(a.next_tiles, 8) * (a.next_tile_bytes >> 10);
     long per = (units_per_xcd + waves_per_xcd - 1) / waves_per_xcd;
-    static const int cap = [] { const char* v = getenv("IVG_DG3_WARM_CAP"); return v ? atoi(v) : 8; }();
-    if (per > cap) per = cap;
+    if (per > 8) per = 8;
     d.pf_base = (const char*)a.next_W; d.pf_tile_bytes = (unsigned)a.next_tile_bytes; d.pf_tiles = a.next_tiles; d.pf_per_wave = (int)per;
   }
   int rc;
@@ -478,7 +462,6 @@ int launch_dgemm(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
                                                                                      : launch_dg_t<bf16_t, 1>(d, MF, FN, waves, stream);
   else rc = lgv == 3 ? launch_dg_t<float, 3>(d, MF, FN, waves, stream) : lgv == 2 ? launch_dg_t<float, 2>(d, MF, FN, waves, stream)
                                                                                  : launch_dg_t<float, 1>(d, MF, FN, waves, stream);
-  if (rc == -1 && forced) return (int)hipErrorInvalidValue;
   return rc;
 }
 

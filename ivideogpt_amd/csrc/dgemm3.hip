@@ -28,6 +28,7 @@
 #include <cstdlib>
 
 #include "igemm.h"
+#include "switches.h"
 
 namespace ivg {
 
@@ -63,13 +64,13 @@ template <> struct Vec4T3<bf16_t> { typedef bf16x4 type; };
 template <> struct Vec4T3<float> { typedef f32x4 type; };
 
 // MF: 16-row tiles of X per workgroup, FN: 16-row tiles of W, WAVES: waves splitting K
-// WSKIP: trailing 8-row halves of the W tiles that are never requested -- a workgroup owns p.wr <= 16 FN rows of W (q/k/v: 20 of
-// 32, o-proj / down: 12 of 16), so that the N tiles x M tiles of a GEMM come out at ~256 workgroups: every CU takes part and
-// ingests fewer weight rows next to its activation rows (98 -> 80 KB per CU for q/k/v, 196 -> 172 for down).  Rows beyond wr are
-// neither requested (lanes masked off; a half tile with no valid row is not issued at all: WSKIP) nor stored.
-template <typename T, int MF, int FN, int WAVES, int WSKIP>
+// A workgroup owns p.wr <= 16 FN rows of W (o-proj / down of the small transformer: 12 of 16), so that the N tiles x M tiles of
+// a GEMM come out at ~256 workgroups: every CU takes part and ingests fewer weight rows next to its activation rows (196 -> 172
+// KB per CU for down).  Rows beyond wr are neither requested (lanes masked off) nor stored; wr > 16 FN - 8, so every half tile
+// still has a valid row and the request count per line is a compile-time constant.
+template <typename T, int MF, int FN, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void dg3_kernel(const Dg3Dev p) {
-  constexpr int PER = 2 * (MF + FN) - WSKIP;     // LDS-DMA requests per line (two 8-row halves per 16-row tile)
+  constexpr int PER = 2 * (MF + FN);             // LDS-DMA requests per line (two 8-row halves per 16-row tile)
   constexpr int NFRAG = FN * MF;
   constexpr int LINE = (MF + FN) * 2048;         // staged bytes of one 128-byte line of K: [MF activation tiles | FN weight tiles] x 2 KiB
   constexpr int NFIN = (NFRAG + WAVES - 1) / WAVES;   // output fragments a wave finalises
@@ -118,13 +119,12 @@ __global__ __launch_bounds__(WAVES * 64) void dg3_kernel(const Dg3Dev p) {
     for (int b = 0; b < MF; ++b)
 #pragma unroll
       for (int h = 0; h < 2; ++h) dg3_dma16(Xw + (size_t)line * 128, xoff[b][h], base + (b * 2 + h) * 1024);
-    // (every issued half tile has at least one valid row -- 16 FN - 8 WSKIP - 8 < wr by construction -- so the request count per
-    // line is exactly PER in every wave: the counted waits below depend on it)
+    // (every half tile has at least one valid row -- 16 FN - 8 < wr by construction -- so the request count per line is exactly
+    // PER in every wave: the counted waits below depend on it)
 #pragma unroll
     for (int a = 0; a < FN; ++a)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        if (a * 2 + h >= 2 * FN - WSKIP) continue;
         if (wreq[a][h]) {
           if (p.w_nt) dg3_dma16_nt(Ww + (size_t)line * 128, woff[a][h], base + ((MF + a) * 2 + h) * 1024);
           else dg3_dma16(Ww + (size_t)line * 128, woff[a][h], base + ((MF + a) * 2 + h) * 1024);
@@ -348,16 +348,13 @@ __global__ __launch_bounds__(WAVES * 64) void dg3_kernel(const Dg3Dev p) {
   if (p.bump && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { p.bump[0] += 1; p.bump[1] += 1; }
 }
 
-template <typename T, int MF, int FN, int WAVES, int WSKIP>
+template <typename T, int MF, int FN, int WAVES>
 static int launch_dg3(const Dg3Dev& d, hipStream_t stream) {
   const int smem = (int)d.wave_bytes * WAVES;
   if (smem > 160 * 1024) return -1;
-  static unsigned long long attr_set = 0;
-  auto kfn = dg3_kernel<T, MF, FN, WAVES, WSKIP>;
-  if (first_time_on_device(attr_set)) {
-    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-  }
+  static DynLdsOnce once;
+  auto kfn = dg3_kernel<T, MF, FN, WAVES>;
+  if (hipError_t e = ensure_dyn_lds(once, (const void*)kfn, 160 * 1024); e != hipSuccess) return (int)e;
   dim3 grid((unsigned)cdiv(d.N, d.wr), (unsigned)cdiv(d.M, 16 * MF), 1);
   hipLaunchKernelGGL(kfn, grid, dim3(WAVES * 64), smem, stream, d);
   return (int)hipGetLastError();
@@ -365,9 +362,7 @@ static int launch_dg3(const Dg3Dev& d, hipStream_t stream) {
 
 template <typename T, int WAVES>
 static int launch_dg3_w(const Dg3Dev& d, int MF, int FN, hipStream_t st) {
-  const int wskip = (16 * FN - d.wr) / 8;   // whole 8-row halves beyond the owned rows (0, or 1 with two W tiles)
-#define IVG_DG3(mf, fn) if (MF == mf && FN == fn) { if (wskip == 0) return launch_dg3<T, mf, fn, WAVES, 0>(d, st); \
-                                                    if constexpr (fn == 2) { if (wskip == 1) return launch_dg3<T, mf, fn, WAVES, 1>(d, st); } return -1; }
+#define IVG_DG3(mf, fn) if (MF == mf && FN == fn) return launch_dg3<T, mf, fn, WAVES>(d, st);
   IVG_DG3(1, 1) IVG_DG3(2, 1) IVG_DG3(4, 1)
   IVG_DG3(1, 2) IVG_DG3(2, 2) IVG_DG3(4, 2)
 #undef IVG_DG3
@@ -384,11 +379,11 @@ static int dg3_waves(long lines) {
 // (K bytes, N) -- never by the batch.  mf caps the row tiles per workgroup.
 struct Dg3Pick { int kbytes, N, mf, fn, wr; };   // wr: rows of W per workgroup (0: the full 16 fn)
 static const Dg3Pick kDg3Picks[] = {
-    {1536, 2304, 2, 2, 20},   // small: q/k/v      116 N tiles x 2 row halves = 232 workgroups, 49 + 31 KB each (32 rows: 144 x 98 KB)
+    {1536, 2304, 2, 2, 0},    // small: q/k/v      72 N tiles x 2 row halves = 144 workgroups x 98 KB
     {1536, 768, 1, 1, 12},    // small: o-proj      64 x 4 = 256 workgroups, 25 + 18 KB (16 rows: 192 x 49 KB)
     {1536, 6144, 4, 2, 0},    // small: gate/up    the [16 gate | 16 up] packing keeps the 32-row tile
     {6144, 768, 1, 1, 12},    // small: down        64 x 4 = 256 workgroups, 98 + 74 KB (16 rows: 192 x 196 KB)
-    {2048, 3072, 2, 2, 24},   // medium: q/k/v     128 x 2 = 256 workgroups
+    {2048, 3072, 2, 2, 0},    // medium: q/k/v
     {2048, 1024, 1, 1, 0},    // medium: o-proj    (on the skip list)
     {2048, 8192, 2, 2, 0},    // medium: gate/up   (on the skip list)
     {8192, 1024, 1, 1, 0},    // medium: down      64 x 4 = 256 workgroups already
@@ -418,9 +413,7 @@ static bool dg3_plan(const SkinnyArgs& a, DType dtype, Dg3Plan& pl) {
   if (glu && a.N % 32 != 0) return false;
   if (a.N < 4) return false;
   if ((a.flags & IG_RESIDUAL) && !(a.flags & IG_OUT_F32) && ((a.ldy & 3) != 0 || ((uintptr_t)a.Y & (4 * es - 1)) || (a.N & 3))) return false;
-  static const bool no_skip = [] { const char* v = getenv("IVG_DG3_ALL"); return v && v[0] == '1'; }();   // IVG_DG3_ALL=1: ignore kDg3Skip (A/B)
-  if (!no_skip)
-    for (const Dg3Skip& k : kDg3Skip) if (k.kbytes == a.K * es && k.N == a.N) return false;
+  for (const Dg3Skip& k : kDg3Skip) if (k.kbytes == a.K * es && k.N == a.N) return false;
   const long lines = (long)a.K * es / 128;
   int waves = dg3_waves(lines);
   if (!waves) return false;
@@ -432,33 +425,26 @@ static bool dg3_plan(const SkinnyArgs& a, DType dtype, Dg3Plan& pl) {
     while (MF > 1 && wgs(MF, FN) < 128) MF >>= 1;                 // narrow GEMMs: split the rows to fill the chip
   }
   int WR = 0;
-  static const bool full_tiles = [] { const char* v = getenv("IVG_DG3_WR"); return v && v[0] == '0'; }();   // IVG_DG3_WR=0: 16 FN rows per workgroup (A/B)
   for (const Dg3Pick& k : kDg3Picks) {
     if (k.kbytes != a.K * es || k.N != a.N) continue;
     MF = std::min(k.mf, mt >= 4 ? 4 : (mt >= 2 ? 2 : 1));
     FN = k.fn;
-    if (!glu && !full_tiles && k.wr % 4 == 0 && k.wr > 16 * FN - 8 && k.wr <= 16 * FN) WR = k.wr;
+    if (!glu && k.wr % 4 == 0 && k.wr > 16 * FN - 8 && k.wr <= 16 * FN) WR = k.wr;
     break;
-  }
-  static int force[4];   // development: IVG_DG3_FORCE=MF,FN,RING,WAVES (0 = automatic) for every launch (tools/ubench/dgemm_phase); read once
-  static const bool forced = [] { const char* ff = getenv("IVG_DG3_FORCE"); return ff && sscanf(ff, "%d,%d,%d,%d", &force[0], &force[1], &force[2], &force[3]) == 4; }();
-  if (forced) {
-    if ((force[3] == 16 || force[3] == 12 || force[3] == 8 || force[3] == 4) && lines % force[3] == 0) waves = force[3];
-    if (force[0] > 0) MF = std::min(force[0], mt >= 4 ? 4 : (mt >= 2 ? 2 : 1));
-    if (force[1] > 0) FN = force[1];
-    if (glu && FN < 2) FN = 2;
   }
   // one workgroup per CU (the staging fills most of the LDS): a GEMM whose W tiles outnumber the CUs would run in rounds, each
   // paying the full request latency -- lm_head (513 tiles) stays on the second-generation kernel, whose small workgroups are all
   // resident at once.  (A function of N and the pick only, like the rest of the coverage.)
-  if (WR == 0 || forced) WR = 16 * FN;
+  if (WR == 0) WR = 16 * FN;
   if (cdiv(a.N, WR) > 256) return false;
   const int klw = (int)(lines / waves);
-  // everything in flight at once needs waves * (MF + FN) * 2 KiB per line of K; over budget: fewer row tiles per workgroup
-  while (MF > 1 && waves * (MF + FN) * 2048 > 160 * 1024) MF >>= 1;
-  if (waves * (MF + FN) * 2048 > 160 * 1024) return false;
-  int ring = klw >= 2 && waves * 2 * (MF + FN) * 2048 <= 160 * 1024 ? 2 : 1;
-  if (forced && force[2] > 0 && force[2] <= ring) ring = force[2];
+  // everything in flight at once needs waves * (MF + FN) * 2 KiB per line of K; over budget: fewer row tiles per workgroup (never
+  // another K partition: MF only picks which rows share a workgroup).  The budget is the whole LDS of a CU unless the caller wants
+  // these workgroups to fit BESIDE a capped conv3x3 workgroup of another batch in flight (IVG_DECODE_LDS_KB, switches.h).
+  const int budget = sw().decode_lds_kb * 1024;
+  while (MF > 1 && waves * (MF + FN) * 2048 > budget) MF >>= 1;
+  if (waves * (MF + FN) * 2048 > budget) return false;
+  const int ring = klw >= 2 && waves * 2 * (MF + FN) * 2048 <= budget ? 2 : 1;
   pl = Dg3Plan{MF, FN, waves, klw, ring, (unsigned)(ring * (MF + FN) * 2048), WR};
   return true;
 }
@@ -471,10 +457,7 @@ int dgemm3_w_rows_per_block(const SkinnyArgs& a, DType dtype) {
 
 // -1: shape not covered; otherwise a hipError_t
 int launch_dgemm3(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
-  {
-    const char* v = getenv("IVG_DG3");   // IVG_DG3=0: second-generation kernel (A/B runs, tests of the older generations)
-    if (v && v[0] == '0') return -1;
-  }
+  if (!sw().dg3) return -1;   // IVG_DG3=0: second-generation kernel (A/B runs, tests of the older generations)
   Dg3Plan pl;
   if (!dg3_plan(a, dtype, pl)) return -1;
   const int es = dtype == BF16 ? 2 : 4;
@@ -483,18 +466,15 @@ int launch_dgemm3(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
   d.ldxb = (unsigned)a.ldx * es; d.ldwb = (unsigned)a.ldw * es; d.ldy = a.ldy;
   d.wr = pl.wr; d.klw = pl.klw; d.ring = pl.ring; d.wave_bytes = pl.wave_bytes; d.flags = a.flags;
   d.inv_k = 1.0f / (float)a.K; d.eps = a.eps; d.bump = a.bump;
-  static const int w_nt = [] { const char* v = getenv("IVG_DG3_NT"); return (v && v[0] == '0') ? 0 : 1; }();   // IVG_DG3_NT=0: default-policy weight requests (A/B)
-  d.w_nt = w_nt;
+  d.w_nt = 1;
   d.prof = a.pos ? a.prof : nullptr; d.pos = a.pos; d.prof_ld = a.prof_ld;
   d.dbg = a.dbg;
-  static const bool pf_off = [] { const char* v = getenv("IVG_DG3_WARM"); return v && v[0] == '0'; }();   // IVG_DG3_WARM=0: no L2 warm-up (A/B runs)
-  if (a.next_W && a.next_tile_bytes >= 1024 && a.next_tiles > 0 && !pf_off) {
+  if (a.next_W && a.next_tile_bytes >= 1024 && a.next_tiles > 0 && sw().dg3_warm) {   // IVG_DG3_WARM=0: no warm-up of the next launch's weights
     const long grid = (long)cdiv(a.N, pl.wr) * cdiv(a.M, 16 * pl.mf);
     const long waves_per_xcd = std::max(1L, grid / 8) * pl.waves;
     const long units_per_xcd = (long)cdiv(a.next_tiles, 8) * (a.next_tile_bytes >> 10);
     long per = (units_per_xcd + waves_per_xcd - 1) / waves_per_xcd;
-    static const int cap = [] { const char* v = getenv("IVG_DG3_WARM_CAP"); return v ? atoi(v) : 8; }();   // 1 KiB requests per wave at most
-    if (per > cap) per = cap;
+    if (per > 8) per = 8;   // 1 KiB requests per wave at most
     d.pf_base = (const char*)a.next_W; d.pf_tile_bytes = (unsigned)a.next_tile_bytes; d.pf_tiles = a.next_tiles; d.pf_per_wave = (int)per;
   }
   int rc;

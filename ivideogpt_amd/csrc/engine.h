@@ -58,6 +58,7 @@ struct ivg_cache {
   float* ctx_pixels = nullptr;             // [B][ctx][3][H][W]
   std::vector<void*> feat;                  // un-repeated per-trajectory context decoder features (NHWC)
   bool filled = false;
+  bool clamped = false;                     // the kept context pixels were written with the output clamp on (ivg_set_output_clamp at fill time)
 };
 
 struct ivg_engine {
@@ -86,12 +87,8 @@ struct ivg_engine {
   char* gen_buf = nullptr;   // persistent decode-step buffers (fixed addresses -> graph replay)
   size_t gen_bytes = 0;
   std::unordered_map<std::string, hipGraphExec_t> graphs;
-  bool use_graph = false;     // IVG_GRAPH=1 (see ivg_create)
-  int chains = 1;            // concurrent dependency chains (measured: no gain on MI355X, graph branches serialise; IVG_CHAINS=n to try)
-                             // of a decode step of a decode step (batch rows split across side streams)
-  hipStream_t side[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t fork_ev = nullptr;
-  hipEvent_t join_ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool use_graph = false;     // IVG_GRAPH=1 at ivg_create (switches.h)
+  float temperature = 1.0f;   // sampling temperature of the rollout (ivg_set_temperature; HF TemperatureLogitsWarper semantics)
   ivg::ProfClass prof[IVG_K_COUNT];
   unsigned long long* attn_prof = nullptr;  // [layers][IVG_ATTN_PROF_SLOTS][2][Lmax] wall-clock stamps of the decode attention
   bool attn_prof_on = false;                // ivg_profile_enable(IVG_K_DECODE_ATTN): part of the step-graph key

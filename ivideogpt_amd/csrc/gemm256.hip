@@ -17,6 +17,7 @@
 #include <cstdlib>
 
 #include "igemm.h"
+#include "switches.h"
 
 namespace ivg {
 
@@ -107,9 +108,6 @@ __device__ __forceinline__ void g256_epilogue(const G256Dev& p, f32x4 (&acc)[4][
   }
 }
 
-// PAIR: two K steps per workgroup barrier (the 16-wave barrier is the expensive event of this loop): the ring is used as two
-// double stages, the pair after this one is requested at the top of this pair and waited for at its end.
-template <bool PAIR>
 __global__ __launch_bounds__(1024) void gemm256_kernel(const G256Dev p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -159,20 +157,6 @@ __global__ __launch_bounds__(1024) void gemm256_kernel(const G256Dev p) {
         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[a]), __builtin_bit_cast(bf16x8, xa[b]),
                                                             acc[a][b], 0, 0, 0);
   };
-  if constexpr (PAIR) {
-    issue(0);
-    if (steps > 1) issue(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    for (int s = 0; s < steps; s += 2) {
-      if (s + 2 < steps) issue(s + 2);   // stages (s + 2) % 4, (s + 3) % 4 were read in the previous pair, before the last barrier
-      if (s + 3 < steps) issue(s + 3);
-      mma_step(s);
-      if (s + 1 < steps) mma_step(s + 1);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
-  } else {
   for (int s = 0; s < G256_STAGES - 1 && s < steps; ++s) issue(s);
   // step 0 must have landed: at most the (min(steps, STAGES - 1) - 1) younger steps (2 DMA instructions each) stay in flight
   if (steps >= 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -189,7 +173,6 @@ __global__ __launch_bounds__(1024) void gemm256_kernel(const G256Dev p) {
     else if (young == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-  }
   }
 
   g256_epilogue(p, acc, smem, m0, n0, wm, wn, lr, lg, tid);
@@ -277,14 +260,9 @@ __global__ __launch_bounds__(1024) void gemm256l_kernel(const G256Dev p) {
   g256_epilogue(p, acc, smem, m0, n0, wm, wn, lr, lg, tid);
 }
 
-static bool gemm256_enabled() {
-  const char* e = getenv("IVG_GEMM256");   // IVG_GEMM256=0: always the generic implicit GEMM (A/B tests)
-  return !(e && e[0] == '0');
-}
-
 // Returns -1 when the shape is not covered (caller uses launch_igemm).
 int launch_gemm256(const IgemmArgs& a, DType dtype, hipStream_t stream) {
-  if (dtype != BF16 || !gemm256_enabled()) return -1;
+  if (dtype != BF16 || !sw().gemm256) return -1;
   if (a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0 || a.ups) return -1;
   if (a.nb0 * a.nb1 * a.nb2 != 1 || a.alpha != 1.0f) return -1;
   if (a.flags & ~(IG_BIAS_N | IG_RESIDUAL | IG_SILU | IG_GLU)) return -1;
@@ -302,36 +280,23 @@ int launch_gemm256(const IgemmArgs& a, DType dtype, hipStream_t stream) {
   d.tiles_n = a.N / 256;
   d.flags = a.flags;
   d.tiles_m = cdiv(M, 256);
-  {  // N-tile groups whose weight slabs (gn x 256 rows x K bf16) stay within ~2.5 MB of the 4 MB L2 of an XCD; IVG_G256_GROUP=0: one group
-    const bool grouped = [] { const char* v = getenv("IVG_G256_GROUP"); return !(v && v[0] == '0'); }();
+  {  // N-tile groups whose weight slabs (gn x 256 rows x K bf16) stay within ~2.5 MB of the 4 MB L2 of an XCD
     const long slab = 256L * d.K * 2;
-    long gn = grouped ? (5L << 19) / slab : d.tiles_n;
-    d.gn = (int)std::max(1L, std::min<long>(gn, d.tiles_n));
+    d.gn = (int)std::max(1L, std::min<long>((5L << 19) / slab, d.tiles_n));
   }
   const int smem = 256 * G256_PITCH > G256_STAGES * G256_STAGE ? 256 * G256_PITCH : G256_STAGES * G256_STAGE;
-  // IVG_G256_PAIR=1: two K steps per barrier -- measured, no change (rollout 147.3-147.9 ms either way, profiles/r02_gemm256_pair.txt)
-  const bool pair = [] { const char* v = getenv("IVG_G256_PAIR"); return v && v[0] == '1'; }();   // (read per launch: the test flips it)
-  static unsigned long long attr_set = 0;
-  if (first_time_on_device(attr_set)) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-  }
   const long tiles = (long)cdiv(M, 256) * d.tiles_n;
   // whole-line requests (K steps of 64 elements) wherever K allows; IVG_G256_LINE=0: the 64-byte-row kernel (A/B, tests)
-  const bool line = [] { const char* v = getenv("IVG_G256_LINE"); return !(v && v[0] == '0'); }();
-  if (line && d.K % 64 == 0 && (long)d.M * d.ldx * 2 < (1L << 31) && (long)d.N * d.ldw * 2 < (1L << 31)) {
-    static unsigned long long attr_l = 0;
-    if (first_time_on_device(attr_l)) {
-      hipError_t e = hipFuncSetAttribute((const void*)gemm256l_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return (int)e;
-    }
+  if (sw().g256_line && d.K % 64 == 0 && (long)d.M * d.ldx * 2 < (1L << 31) && (long)d.N * d.ldw * 2 < (1L << 31)) {
+    static DynLdsOnce once_l;
+    if (hipError_t e = ensure_dyn_lds(once_l, (const void*)gemm256l_kernel, 160 * 1024); e != hipSuccess) return (int)e;
     const int smem_l = 256 * G256_PITCH > 2 * G256L_STAGE ? 256 * G256_PITCH : 2 * G256L_STAGE;
     hipLaunchKernelGGL(gemm256l_kernel, dim3((unsigned)tiles), dim3(1024), smem_l, stream, d);
     return (int)hipGetLastError();
   }
-  if (pair) hipLaunchKernelGGL(gemm256_kernel<true>, dim3((unsigned)tiles), dim3(1024), smem, stream, d);
-  else hipLaunchKernelGGL(gemm256_kernel<false>, dim3((unsigned)tiles), dim3(1024), smem, stream, d);
+  static DynLdsOnce once;
+  if (hipError_t e = ensure_dyn_lds(once, (const void*)gemm256_kernel, 160 * 1024); e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(gemm256_kernel, dim3((unsigned)tiles), dim3(1024), smem, stream, d);
   return (int)hipGetLastError();
 }
 

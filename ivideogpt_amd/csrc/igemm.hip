@@ -43,7 +43,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_wave
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool GLDS>
+template <typename T, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDev p) {
   constexpr int VEC = Traits<T>::VEC;
   constexpr int BK = 8 * VEC;  // one 128-byte row
@@ -81,43 +81,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDev p) {
     }
   }
   const int h_lim = p.ups ? 2 * p.Hin : p.Hin, w_lim = p.ups ? 2 * p.Win : p.Win;
-
-  Chunk16 ra[A_IT], rb[B_IT];
-  auto load_tile = [&](int kt) {
-    const int k0 = kt * BK;
-    const int tap = p.single_tap ? 0 : k0 / p.Cin;
-    const int c0 = k0 - tap * p.Cin;
-    const int kh = tap / p.KW, kw = tap - kh * p.KW;
-    const bool k_ok = (k0 + chunk * VEC) < p.K;  // K tail (1x1 / plain GEMM only): zero-filled chunks
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-      int ih = a_h[i] + kh, iw = a_w[i] + kw;
-      const bool ok = (ih >= 0) & (ih < h_lim) & (iw >= 0) & (iw < w_lim) & k_ok;
-      if (p.ups) { ih >>= 1; iw >>= 1; }
-      Chunk16 v = Chunk16{0u, 0u, 0u, 0u};
-      if (ok) v = *(const Chunk16*)(X + ((long)(a_base[i] + ih * p.Win + iw) * p.ldx + c0 + chunk * VEC));
-      ra[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-      const int r = row0 + 32 * i;
-      const int n = tile_n * BN + r;
-      Chunk16 v = Chunk16{0u, 0u, 0u, 0u};
-      if (r < BN && n < p.N && k_ok) v = *(const Chunk16*)(Wt + ((long)n * p.ldw + k0 + chunk * VEC));
-      rb[i] = v;
-    }
-  };
-  auto store_tile = [&](int buf) {
-    unsigned char* sA = smem + buf * STAGE;
-    unsigned char* sB = sA + A_BYTES;
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) *(Chunk16*)(sA + lds_off(row0 + 32 * i, chunk)) = ra[i];
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-      const int r = row0 + 32 * i;
-      if (r < BN) *(Chunk16*)(sB + lds_off(r, chunk)) = rb[i];
-    }
-  };
 
   const int wave = tid >> 6, lane = tid & 63;
   // LDS-DMA staging: lane (r = lane>>3, slot = lane&7) of instruction i lands at row 8*wave + 32*i + r, slot `slot`
@@ -161,19 +124,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDev p) {
     for (int b = 0; b < FM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (p.K + BK - 1) / BK;
-  if constexpr (GLDS) {
-    issue_tile(0, 0);
-  } else {
-    load_tile(0);
-    store_tile(0);
-  }
+  issue_tile(0, 0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) {
-      if constexpr (GLDS) issue_tile(kt + 1, buf ^ 1);
-      else load_tile(kt + 1);
-    }
+    if (kt + 1 < nk) issue_tile(kt + 1, buf ^ 1);
     const unsigned char* sA = smem + buf * STAGE;
     const unsigned char* sB = sA + A_BYTES;
 #pragma unroll
@@ -198,10 +153,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDev p) {
           }
         }
     }
-    if constexpr (!GLDS) {
-      if (kt + 1 < nk) store_tile(buf ^ 1);
-    }
-    __syncthreads();  // GLDS: the compiler drains the DMA (vmcnt(0)) in front of the barrier
+    __syncthreads();  // (the compiler drains the DMA queue, vmcnt(0), in front of the barrier)
   }
 
   // ---- epilogue: lane holds, per fragment, 4 consecutive n (= lg*4 + r) of pixel m (= lr)
@@ -283,30 +235,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDev p) {
   }
 }
 
-static bool use_glds() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("IVG_IGEMM_GLDS"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v == 1;
-}
-
-template <typename T, int BM, int BN, int WM, int WN, bool GLDS>
-static int launch_cfg2(const IgemmDev& d, int nbatch, hipStream_t stream) {
+template <typename T, int BM, int BN, int WM, int WN>
+static int launch_cfg(const IgemmDev& d, int nbatch, hipStream_t stream) {
   constexpr int smem = 2 * (BM + BN) * 128;
-  static unsigned long long attr_set = 0;
-  auto kfn = igemm_kernel<T, BM, BN, WM, WN, GLDS>;
-  if (first_time_on_device(attr_set)) {
-    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return (int)e;
-  }
+  static DynLdsOnce once;
+  auto kfn = igemm_kernel<T, BM, BN, WM, WN>;
+  if (hipError_t e = ensure_dyn_lds(once, (const void*)kfn, smem); e != hipSuccess) return (int)e;
   const long tiles = (long)cdiv(d.M, BM) * cdiv(d.N, BN);
   dim3 grid((unsigned)tiles, (unsigned)nbatch, 1);
   hipLaunchKernelGGL(kfn, grid, dim3(256), smem, stream, d);
   return (int)hipGetLastError();
-}
-
-template <typename T, int BM, int BN, int WM, int WN>
-static int launch_cfg(const IgemmDev& d, int nbatch, hipStream_t stream) {
-  return use_glds() ? launch_cfg2<T, BM, BN, WM, WN, true>(d, nbatch, stream) : launch_cfg2<T, BM, BN, WM, WN, false>(d, nbatch, stream);
 }
 
 template <typename T>

@@ -160,18 +160,12 @@ int launch_ingest(const unsigned char* src, int T, int H, int W, int crop, void*
   // (the kernel also has 8 bytes of static LDS: the dynamic part may take 160 KiB minus that)
   constexpr int kMaxDyn = 160 * 1024 - 64;
   if (smem > (size_t)kMaxDyn) return (int)hipErrorInvalidValue;
-  static unsigned long long attr_f = 0, attr_b = 0;
+  static DynLdsOnce once_f, once_b;
   if (dst_dt == BF16) {
-    if (first_time_on_device(attr_b)) {
-      const hipError_t e = hipFuncSetAttribute((const void*)ingest_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDyn);
-      if (e != hipSuccess) return (int)e;
-    }
+    if (hipError_t e = ensure_dyn_lds(once_b, (const void*)ingest_kernel<bf16_t>, kMaxDyn); e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(ingest_kernel<bf16_t>, dim3((unsigned)(T * d.blocks_per_frame)), dim3(256), smem, st, d);
   } else {
-    if (first_time_on_device(attr_f)) {
-      const hipError_t e = hipFuncSetAttribute((const void*)ingest_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDyn);
-      if (e != hipSuccess) return (int)e;
-    }
+    if (hipError_t e = ensure_dyn_lds(once_f, (const void*)ingest_kernel<float>, kMaxDyn); e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(ingest_kernel<float>, dim3((unsigned)(T * d.blocks_per_frame)), dim3(256), smem, st, d);
   }
   return (int)hipGetLastError();

@@ -7,6 +7,7 @@
 #include <cstdlib>
 
 #include "ops.h"
+#include "switches.h"
 
 namespace ivg {
 
@@ -446,8 +447,7 @@ __global__ __launch_bounds__(256) void xattn_kernel(const bf16_t* __restrict__ q
 
 // one predicate for the planner and the launcher: which (dtype, shape) the one-pass kernel covers
 bool xattn_covers(int P, int kv, int C, int nh, DType dt) {
-  static const bool off = [] { const char* v = getenv("IVG_FLASH_XATT"); return v && v[0] == '0'; }();
-  if (off || dt != BF16 || nh <= 0 || C % nh != 0 || P % 64 != 0 || kv % 64 != 0 || (C & 7)) return false;
+  if (!sw().flash_xatt || dt != BF16 || nh <= 0 || C % nh != 0 || P % 64 != 0 || kv % 64 != 0 || (C & 7)) return false;
   const int hd = C / nh;
   return hd == 32 || hd == 64 || hd == 128 || hd == 192 || hd == 512 || hd == 768;
 }
@@ -543,21 +543,16 @@ __device__ __forceinline__ float group_sum(float d, int lpk) {
   return d;
 }
 
-// development (IVG_ATTN_DEBUG): wall-clock (100 MHz) phase stamps of workgroups 0 and last at cache position 640
-__device__ unsigned long long g_attn_dbg[2][8];
-
 // NT: non-temporal loads of the cache rows (streamed once per step: keep them from evicting the weights)
 // HD: head dimension as a compile-time value (64 for the released transformers; 0 = generic, read from the argument) -- with it
 // the lane-group reductions, the group counts and the row strides are constants instead of chains of scalar branches per chunk
-// PRE2: two value blocks in flight across the softmax statistics (measured slower, see launch_decode_attn) -- a template
-// parameter, not a runtime switch: as a runtime branch the second path raised the kernel from 106 to 156 registers, one
-// workgroup per CU less for the 1,024 (trajectory, head) pairs of the medium transformer (config 5 rollout 753 -> 800 ms).
-template <typename T, bool NT, int HD, bool PRE2>
+// (Two value blocks in flight across the softmax statistics were built and measured slower in round 3 -- 64.3 vs 61.2 ms of
+// attention per step, profiles/r03_attn_pre2_ab.txt: one block per workgroup already keeps 25 MB in flight chip-wide -- removed.)
+template <typename T, bool NT, int HD>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
                                                           T* __restrict__ out, const float* __restrict__ cosT,
                                                           const float* __restrict__ sinT, int heads, int hd_arg, int Lmax,
                                                           const StepState* __restrict__ state, unsigned long long* prof) {
-  constexpr bool pre2 = PRE2;
   constexpr int VEC = Traits<T>::VEC;
   const int hd = HD > 0 ? HD : hd_arg;
   constexpr int UNR = 8;   // 16-byte loads in flight per lane: 3 workgroups x 256 lanes x 8 x 16 B = 96 KiB per CU
@@ -577,9 +572,6 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int sub = tid % lpk, grp = tid / lpk;
   const int pos = state->pos;        // position of the token being fed = number of cached keys
-  const bool dbg = prof && pos == 640 && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1);
-  unsigned long long* dslot = g_attn_dbg[blockIdx.x == 0 ? 0 : 1];
-  if (dbg) { dslot[0] = t_start; dslot[1] = wall_clock64(); }
   const int n_keys = pos + 1;
   const int H = heads * hd, half = hd / 2;
   const float scale = rsqrtf((float)hd);
@@ -621,7 +613,6 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
     vb[(long)pos * hd + tid] = va; vb[(long)pos * hd + tid + half] = vb2;
   }
   __syncthreads();
-  if (dbg) dslot[2] = wall_clock64();
   float qf[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) qf[j] = sq[sub * VEC + j];
@@ -660,10 +651,6 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
       for (int u = 0; u < UNR; ++u) cur[u] = nxt[u];
     }
   }
-  if (dbg) dslot[3] = wall_clock64();
-  // pre2 (off by default, measured slower: see launch_decode_attn): the SECOND block of value rows requested before the
-  // statistics phase as well (`nxt` is free: the last key rows have been consumed)
-  if (pre2 && step < pos) load_rows(nxt, vb, step);
   if (grp == 0) {
     float d = 0.f;
 #pragma unroll
@@ -685,7 +672,6 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   if (lane == 0) sred[4 + wv] = sum;
   __syncthreads();
   sum = (sred[4] + sred[5]) + (sred[6] + sred[7]);
-  if (dbg) dslot[4] = wall_clock64();
   // pass C: weighted V sum; group `grp` takes keys grp, grp+gpb, ... (fixed order), the new token's v from LDS
   float of[VEC];
 #pragma unroll
@@ -697,15 +683,6 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
       if (t < pos) axpy_chunk<T>(of, sc[t], rows[u]);
     }
   };
-  if (pre2) {   // two blocks in flight throughout: a buffer is requested again right after it has been consumed (same key order, same sums)
-    for (int t0 = 0; t0 < pos; t0 += 2 * step) {
-      weighted(cur, t0);
-      if (t0 + 2 * step < pos) load_rows(cur, vb, t0 + 2 * step);
-      if (t0 + step >= pos) break;
-      weighted(nxt, t0 + step);
-      if (t0 + 3 * step < pos) load_rows(nxt, vb, t0 + 3 * step);
-    }
-  } else {
     for (int t0 = 0; t0 < pos; t0 += 2 * step) {  // cur holds value rows [t0, t0 + step) (requested during pass A / the last iteration)
       if (t0 + step < pos) load_rows(nxt, vb, t0 + step);
       weighted(cur, t0);
@@ -713,8 +690,6 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
       if (t0 + 2 * step < pos) load_rows(cur, vb, t0 + 2 * step);
       weighted(nxt, t0 + step);
     }
-  }
-  if (dbg) dslot[5] = wall_clock64();
   if (grp == 0) {
     const float pw = sc[pos];
 #pragma unroll
@@ -728,21 +703,10 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
     for (int g = 0; g < gpb; ++g) a += red[g * hd + tid];
     out[(long)b * H + h * hd + tid] = from_f32<T>(a / sum);
   }
-  if (dbg) dslot[6] = wall_clock64();
   if (prof && tid == 0) {
     unsigned long long* slot = prof + (size_t)((blockIdx.x * 7 + blockIdx.y) % IVG_ATTN_PROF_SLOTS) * 2 * Lmax;
     atomicMax(slot + pos, ~t_start);
     atomicMax(slot + Lmax + pos, (unsigned long long)wall_clock64());
-  }
-}
-
-void attn_debug_dump() {
-  unsigned long long h[2][8];
-  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_attn_dbg), sizeof(h)) != hipSuccess) return;
-  for (int b = 0; b < 2; ++b) {
-    fprintf(stderr, "[attn dbg] wg %s (x10 ns since wg0 start): start %lld | pos read +%lld | rope+sync +%lld | K pass +%lld | stats +%lld | V pass +%lld | reduce+store +%lld\n", b ? "last" : "0",
-            (long long)(h[b][0] - h[0][0]), (long long)(h[b][1] - h[b][0]), (long long)(h[b][2] - h[b][1]), (long long)(h[b][3] - h[b][2]),
-            (long long)(h[b][4] - h[b][3]), (long long)(h[b][5] - h[b][4]), (long long)(h[b][6] - h[b][5]));
   }
 }
 
@@ -753,19 +717,10 @@ int launch_decode_attn(const void* qkv, void* kc, void* vc, void* out, const flo
   const int gpb = 256 / (hd / vec);
   const size_t smem = (size_t)(3 * hd + Lmax + gpb * hd) * sizeof(float);
   dim3 g(B * heads);
-  // non-temporal cache-row loads: 5.57 -> 6.28 TB/s on a pure stream, 203 -> 191 ms per rollout (IVG_ATTN_NT=0: plain loads, A/B)
-  static const bool nt = [] { const char* v = getenv("IVG_ATTN_NT"); return !(v && v[0] == '0'); }();
-#define IVG_DA(T, NTv, HDv)                                                                                                       \
-  do {                                                                                                                            \
-    if (pre2) hipLaunchKernelGGL((decode_attn_kernel<T, NTv, HDv, true>), g, dim3(256), smem, st, (const T*)qkv, (T*)kc, (T*)vc, (T*)out, cosT, sinT, heads, hd, Lmax, state, prof); \
-    else hipLaunchKernelGGL((decode_attn_kernel<T, NTv, HDv, false>), g, dim3(256), smem, st, (const T*)qkv, (T*)kc, (T*)vc, (T*)out, cosT, sinT, heads, hd, Lmax, state, prof); \
-  } while (0)
-  // IVG_ATTN_PRE2=1: two value blocks in flight across the softmax statistics.  Measured (profiles/r03_attn_pre2_ab.txt): 64.3 vs
-  // 61.2 ms per step of attention, rollout 150.4 vs 147.5 ms -- SLOWER: one block per workgroup already keeps 25 MB in flight
-  // chip-wide, the second only deepens the HBM queues every workgroup then waits behind.  Off by default; the path is kept for A/B.
-  static const int pre2 = [] { const char* v = getenv("IVG_ATTN_PRE2"); return (v && v[0] == '1') ? 1 : 0; }();
-  if (dt == BF16 && nt) { if (hd == 64) IVG_DA(bf16_t, true, 64); else IVG_DA(bf16_t, true, 0); }
-  else if (dt == BF16) { if (hd == 64) IVG_DA(bf16_t, false, 64); else IVG_DA(bf16_t, false, 0); }
+  // non-temporal cache-row loads (bf16): 5.57 -> 6.28 TB/s on a pure stream, 203 -> 191 ms per rollout
+#define IVG_DA(T, NTv, HDv) \
+  hipLaunchKernelGGL((decode_attn_kernel<T, NTv, HDv>), g, dim3(256), smem, st, (const T*)qkv, (T*)kc, (T*)vc, (T*)out, cosT, sinT, heads, hd, Lmax, state, prof)
+  if (dt == BF16) { if (hd == 64) IVG_DA(bf16_t, true, 64); else IVG_DA(bf16_t, true, 0); }
   else { if (hd == 64) IVG_DA(float, false, 64); else IVG_DA(float, false, 0); }
 #undef IVG_DA
   return (int)hipGetLastError();
@@ -817,9 +772,6 @@ __global__ __launch_bounds__(256) void sample_embed_kernel(SampleArgs a) {
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int j = a.state->j;
   const int V = a.V;
-  int dbg_n = 0;
-  auto stamp = [&]() { if (a.dbg && b == 0 && tid == 0) a.dbg[dbg_n++] = (long long)__builtin_readcyclecounter(); };
-  stamp();
   const bool forced = a.forced_period > 0 && (j % a.forced_period) == 0;
   long tok = 0;
   if (forced) {
@@ -844,7 +796,12 @@ __global__ __launch_bounds__(256) void sample_embed_kernel(SampleArgs a) {
     }
     if (tid == 0) s_tok = -1;
     __syncthreads();
-    stamp();
+    // HF TemperatureLogitsWarper runs BEFORE the top-k filter: scores = scores / temperature in fp32 (IEEE division, as torch's);
+    // every later read of the row (candidates, exponentials) sees the scaled values.  1.0 (every caller of the reference): untouched.
+    if (a.temperature != 1.0f) {
+      for (int i = tid; i < V; i += 256) lg[i] = lg[i] / a.temperature;
+      __syncthreads();
+    }
     const int seg = (V + 255) / 256;
     const int i0 = tid * seg;
     const int nvalid = max(0, min(seg, V - i0));   // this thread owns ids [i0, i0 + nvalid)
@@ -870,7 +827,6 @@ __global__ __launch_bounds__(256) void sample_embed_kernel(SampleArgs a) {
     mx = s_f[0]; mi = s_i[0];
 #pragma unroll
     for (int w = 1; w < 4; ++w) if (s_f[w] > mx || (s_f[w] == mx && s_i[w] < mi)) { mx = s_f[w]; mi = s_i[w]; }
-    stamp();
     if (a.uniforms == nullptr) {
       tok = mi;
     } else {
@@ -895,10 +851,8 @@ __global__ __launch_bounds__(256) void sample_embed_kernel(SampleArgs a) {
           const unsigned o = (unsigned)__builtin_amdgcn_readlane((int)mine, jl);
           rank += (o > mine || (o == mine && jl < lane)) ? 1 : 0;
         }
-        stamp();
         if (rank == (kk + 3) / 4 - 1) s4[wv] = (int)mine;   // ranks are a permutation of 0..63: one writer per wave
         __syncthreads();
-        stamp();
         unsigned pivot = (unsigned)s4[0];
 #pragma unroll
         for (int w = 1; w < 4; ++w) pivot = (unsigned)s4[w] < pivot ? (unsigned)s4[w] : pivot;
@@ -916,7 +870,6 @@ __global__ __launch_bounds__(256) void sample_embed_kernel(SampleArgs a) {
         if (tid == 0) s_sel[1] = hi + cc;           // number of candidates (>= k)
         __syncthreads();
         const int n_c = s_sel[1];
-        stamp();
         if (n_c <= SAMPLE_CAP) {
           int off = n_c - hi - cc;                   // candidates in lower threads = lower ids
 #pragma unroll
@@ -931,7 +884,6 @@ __global__ __launch_bounds__(256) void sample_embed_kernel(SampleArgs a) {
           }
           if (tid < 4) s_ck[n_c + tid] = 0u;           // pad to a multiple of 4 (hist has room beyond CAP)
           __syncthreads();
-          stamp();
           unsigned best = 0xffffffffu;               // smallest candidate with fewer than k strictly larger ones = k-th largest
           const uint4* c4 = (const uint4*)s_ck;
           const int n4 = (n_c + 3) >> 2;
@@ -945,7 +897,6 @@ __global__ __launch_bounds__(256) void sample_embed_kernel(SampleArgs a) {
             }
             if (g < kk && ci < best) best = ci;
           }
-          stamp();
 #pragma unroll
           for (int o = 32; o > 0; o >>= 1) { const unsigned ob = __shfl_xor(best, o, 64); best = ob < best ? ob : best; }
           if (lane == 0) s4[wv] = (int)best;
@@ -987,7 +938,6 @@ __global__ __launch_bounds__(256) void sample_embed_kernel(SampleArgs a) {
       }
       thr = prefix;
       }
-      stamp();
       // everything >= thr is kept (ties at the threshold included, as HF's masked_fill)
       // ---- inverse CDF in ascending id order, fp64 (oracle: double cumsum of exp(logit - max) over the kept ids)
       if (n_list < 0) {   // radix path: list the kept tokens now
@@ -1007,11 +957,9 @@ __global__ __launch_bounds__(256) void sample_embed_kernel(SampleArgs a) {
           n_list = n_kept;
         }
       }
-      stamp();
       if (n_list >= 0) {
         // the listed tokens (about top_k of them) are spread over the threads, so the fp64 exponentials run once each, in
         // parallel; listed tokens below the threshold (pre-filter path) weigh zero, exactly as in the oracle's masked sum
-        stamp();
         const int per = (n_list + 255) / 256;  // <= 4
         const int e0 = tid * per, e1 = min(n_list, e0 + per);
         double ex[SAMPLE_CAP / 256];
@@ -1024,7 +972,6 @@ __global__ __launch_bounds__(256) void sample_embed_kernel(SampleArgs a) {
             part += ex[r];
           }
         }
-        stamp();
         double incl = part;  // inclusive scan over threads (thread order == id order)
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -1052,7 +999,6 @@ __global__ __launch_bounds__(256) void sample_embed_kernel(SampleArgs a) {
         __syncthreads();
         tok = s_tok;
         if (tok < 0) tok = mi;  // unreachable for u in [0, 1): defensive
-        stamp();
       } else {
         // general path (massive ties at the threshold): every thread walks its own id segment
         double part = 0.0;
@@ -1098,7 +1044,6 @@ __global__ __launch_bounds__(256) void sample_embed_kernel(SampleArgs a) {
   // a row of NaN / -inf logits leaves the arg-max index at its initial value: never let it reach the id buffer or the
   // embedding gather (out-of-bounds read inside a replayed graph); such a row decides token 0
   if (tok < 0 || tok >= V) tok = 0;
-  if (a.dbg && b == 0 && tid == 0) a.dbg[31] = dbg_n;
   if (tid == 0) a.ids_out[(long)b * a.ids_stride + a.L0 + (j - 1)] = (int64_t)tok;
   // ---- next input embedding
   const T* src = (const T*)a.E + tok * a.H;
@@ -1114,9 +1059,8 @@ __global__ __launch_bounds__(256) void sample_embed_kernel(SampleArgs a) {
 
 template <typename T, int KPT>
 static void launch_sample_t(const SampleArgs& a, int B, size_t smem, hipStream_t st) {
-  static unsigned long long attr_set = 0;
-  if (first_time_on_device(attr_set))
-    (void)hipFuncSetAttribute((const void*)sample_embed_kernel<T, KPT>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  static DynLdsOnce once;
+  (void)ensure_dyn_lds(once, (const void*)sample_embed_kernel<T, KPT>, 96 * 1024);
   hipLaunchKernelGGL((sample_embed_kernel<T, KPT>), dim3(B), dim3(256), smem, st, a);
 }
 

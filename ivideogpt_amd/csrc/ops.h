@@ -75,7 +75,6 @@ bool xattn_covers(int P, int kv, int C, int nh, DType dt);   // pure predicate (
 // prof (nullable): [IVG_ATTN_PROF_SLOTS][Lmax starts | Lmax ends] wall-clock stamps (100 MHz) of the launch at each cache
 // position; workgroups spread over the slots so the atomics do not serialise on one address
 #define IVG_ATTN_PROF_SLOTS 32
-void attn_debug_dump();   // development: prints the phase stamps of the last profiled decode attention at position 640
 int launch_decode_attn(const void* qkv, void* kc, void* vc, void* out, const float* cosT, const float* sinT, int B, int heads, int hd,
                        int Lmax, const StepState* state, unsigned long long* prof, DType dt, hipStream_t st);
 // token decision + embedding of the decided token (+ action embedding on forced sdf slots) + state advance
@@ -89,7 +88,7 @@ struct SampleArgs {
   const void* act; int act_T; int ctx;         // act[B][act_T][H] (T) or null: added on forced slots, index slot0 + j/period + ctx - 1
   int slot0;                                   // sdf slots already inside the prompt beyond the first: (L0 - 257*ctx) / 17
   StepState* state;
-  long long* dbg;                              // development: cycle stamps of workgroup 0 (null in production)
+  float temperature;                           // logits / temperature before the top-k filter (HF TemperatureLogitsWarper); 1.0: none
 };
 int launch_sample_embed(const SampleArgs& a, int B, DType dt, hipStream_t st);
 int launch_step_advance(StepState* state, hipStream_t st);

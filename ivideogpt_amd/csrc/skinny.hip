@@ -196,12 +196,9 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_kernel(const SkinnyDev p) {
 template <typename T, int MF, int FN, int WAVES>
 static int launch_sk(const SkinnyDev& d, hipStream_t stream) {
   constexpr int smem = WAVES * FN * MF * 64 * 16 + WAVES * MF * 16 * 4;
-  static unsigned long long attr_set = 0;
+  static DynLdsOnce once;
   auto kfn = skinny_kernel<T, MF, FN, WAVES>;
-  if (first_time_on_device(attr_set)) {
-    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return (int)e;
-  }
+  if (hipError_t e = ensure_dyn_lds(once, (const void*)kfn, smem); e != hipSuccess) return (int)e;
   SkinnyDev dd = d;
   dd.tail_split = (MF > 1 && d.M <= 16 * MF && d.splits == 1 && d.N % (16 * FN) != 0 && d.N > 16 * FN && !(d.flags & IG_GLU)) ? 1 : 0;
   const unsigned gx = dd.tail_split ? (unsigned)(d.N / (16 * FN) + cdiv(d.M, 16)) : (unsigned)cdiv(d.N, 16 * FN);
@@ -242,16 +239,9 @@ static void pick_tile(int M, int N, int K, bool glu, int& MF, int& FN) {
     }
 }
 
-static int g_force_waves = 0;   // tuning override (IVG_SK_FORCE=MF,FN,WAVES; tools/skinny_tune.py), 0 = cost model
-
 template <typename T, int MF, int FN>
 static int launch_sk_w(const SkinnyDev& d, hipStream_t stream) {
-  int w = pick_waves(d.K, d.splits, Traits<T>::dtype);
-  if (g_force_waves) {
-    const int kstep = Traits<T>::dtype == BF16 ? 32 : 16;
-    if ((d.K / d.splits) % (g_force_waves * kstep) != 0) return (int)hipErrorInvalidValue;
-    w = g_force_waves;
-  }
+  const int w = pick_waves(d.K, d.splits, Traits<T>::dtype);
   if constexpr (MF + FN <= 5 && MF * FN <= 4) {  // 1024-thread workgroups only where the 128-VGPR budget holds the burst
     if (w == 16) return launch_sk<T, MF, FN, 16>(d, stream);
   }
@@ -288,11 +278,6 @@ int launch_skinny(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
   }
   int MF, FN;
   pick_tile(a.M, a.N, a.K, glu, MF, FN);
-  g_force_waves = 0;
-  if (const char* f = getenv("IVG_SK_FORCE")) {   // development: measure a tile shape the cost model would not pick
-    int mf = 0, fn = 0, wv = 0;
-    if (sscanf(f, "%d,%d,%d", &mf, &fn, &wv) == 3) { MF = mf; FN = fn; g_force_waves = wv; }
-  }
   if (MF == 8 && FN == 4) FN = 2;
   return dtype == BF16 ? launch_sk_t<bf16_t>(d, MF, FN, stream) : launch_sk_t<float>(d, MF, FN, stream);
 }

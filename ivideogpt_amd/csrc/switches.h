@@ -1,0 +1,36 @@
+// Every run-time switch of libivg, in ONE place.  The table is read from the environment when the library is loaded, again at
+// every ivg_create and on ivg_reload_switches() (tests flip a variable, then call it); the kernels' launchers only ever read the
+// published table -- no getenv() and no lazily initialised static on a launch path, so engines driven from several host threads
+// (bench.py --lanes, replica()) share nothing that is written after start-up.
+//
+//   variable                 default  meaning
+//   ---- which kernel runs a shape (A/B runs and the tests of the alternative paths)
+//   IVG_CONV3X3              1        0: every 3x3 convolution on the generic implicit GEMM (igemm.hip)
+//   IVG_GEMM256              1        0: large dense GEMMs on the generic implicit GEMM
+//   IVG_G256_LINE            1        0: the 64-byte-row gemm256 kernel everywhere (1: whole-line kernel where K % 64 == 0)
+//   IVG_DG3                  1        0: decode GEMMs on the second-generation kernel (dgemm.hip)
+//   IVG_DG                   1        0: decode GEMMs on the first-generation kernel (skinny.hip) -- with IVG_DG3=0
+//   IVG_FLASH_PREFILL        1        0: prompt attention as score GEMM + softmax + P.V GEMM (what the fp32 engine mode runs)
+//   IVG_FLASH_XATT           1        0: tokenizer attention as score GEMM + softmax + P.V GEMM
+//   IVG_GN_FUSE              1        0: every GroupNorm computes its own statistics (1: reduced by the producing conv3x3's epilogue)
+//   IVG_GN_APPLY_FUSE        1        0: GroupNorm + SiLU as a separate apply pass (1: inside the consuming conv3x3's halo staging)
+//   IVG_X3                   1        0: the fp32 decode path of the tokenizer on f32-input MFMAs (1: split-bf16 "x3" convolutions)
+//   ---- launch policy
+//   IVG_GRAPH                0        1: decode steps replayed from hipGraphs (8 steps per launch) instead of eager launches
+//   IVG_DG3_WARM             1        0: decode GEMMs do not pull the next launch's weights toward the chip
+//   IVG_CONV_CAP             0        1: conv3x3 grids at ONE workgroup per CU (LDS padded past half a CU's 160 KiB): leaves half of
+//                                        every CU's LDS, wave slots and registers to the kernels of another batch in flight
+//   IVG_DECODE_LDS_KB        160      LDS budget of a decode-GEMM workgroup in KiB (<= 78: it fits beside a capped conv3x3 workgroup)
+#pragma once
+
+namespace ivg {
+
+struct Switches {
+  int conv3x3 = 1, gemm256 = 1, g256_line = 1, dg3 = 1, dg = 1, flash_prefill = 1, flash_xatt = 1, gn_fuse = 1, gn_apply_fuse = 1, x3 = 1;
+  int graph = 0, dg3_warm = 1, conv_cap = 0, decode_lds_kb = 160;
+};
+
+const Switches& sw();       // the published table (never null; atomically replaced by reload_switches)
+void reload_switches();     // re-read the environment and publish a new table
+
+}  // namespace ivg

@@ -15,6 +15,7 @@
 //   * nearest-x2 upsampling, the stride-2 right/bottom zero pad and 4x4 patchify are index arithmetic
 //     inside the implicit-GEMM gather, never materialised.
 #include "engine_impl.h"
+#include "switches.h"
 
 namespace ivg {
 
@@ -23,11 +24,7 @@ namespace ivg {
 static size_t esz(DType d) { return d == BF16 ? 2 : 4; }
 
 // -------------------------------------------------------------------------------------------- primitive wrappers
-static bool gn_fuse_enabled() {   // IVG_GN_FUSE=0: every GroupNorm computes its own statistics (A/B runs)
-  static int v = -1;
-  if (v < 0) { const char* s = getenv("IVG_GN_FUSE"); v = (s && s[0] == '0') ? 0 : 1; }
-  return v == 1;
-}
+static bool gn_fuse_enabled() { return sw().gn_fuse != 0; }   // IVG_GN_FUSE=0: every GroupNorm computes its own statistics (A/B runs)
 
 size_t Run::gn_stats_bytes(int N, int H, int W, int C) const {
   return (size_t)N * conv3x3_gn_chunks_bound(H, W, C) * e->cfg.norm_num_groups * sizeof(double) * 2;
@@ -114,10 +111,7 @@ int Run::gnorm(DType dt, const void* X, void* Y, int N, int P, int C, const Norm
 // already the busier one, this cost more than the apply pass it removed (decode 65.5 vs 63.0 ms,
 // profiles/r02_eager_vs_graph_and_gn_fusion.txt); with the rebuilt loop (2 vector instructions per step) it wins: 214.0 vs 216.2 ms
 // per step (encode -1.1, decode -1.0; profiles/r02_gn_apply_fusion_ab.txt).  IVG_GN_APPLY_FUSE=0: separate apply pass (A/B).
-static bool gn_apply_fuse_enabled() {   // (read per call: tests/test_gpu_models.py flips it)
-  const char* s = getenv("IVG_GN_APPLY_FUSE");
-  return !(s && s[0] == '0');
-}
+static bool gn_apply_fuse_enabled() { return sw().gn_apply_fuse != 0; }
 
 int Run::norm_conv(DType dt, const void* x, int N, int H, int W, const NormW& n, float eps, const GnStats* x_stats, const ConvW& c, void* Y,
                    const void* Rres, void* scratch, GnStats* out_stats) {
@@ -128,10 +122,9 @@ int Run::norm_conv(DType dt, const void* x, int N, int H, int W, const NormW& n,
   void* coef = e->ws.alloc((size_t)N * C * sizeof(float) * 2);
   int rc = 0;
   if (!planning) {
-    // every N tile (128 output channels) of the fused kernel normalises the whole input halo again: with 2-4 N tiles the in-place
-    // transform is done 2-4 times.  IVG_GN_APPLY_FUSE_MAXN=n: fuse only up to n N tiles, separate apply pass beyond (A/B; default: always)
-    static const int fuse_maxn = [] { const char* v = getenv("IVG_GN_APPLY_FUSE_MAXN"); return v ? atoi(v) : 1 << 30; }();
-    const bool fuse = gn_apply_fuse_enabled() && c.k == 3 && (c.cout + 127) / 128 <= fuse_maxn;
+    // (every N tile of the fused kernel normalises the whole input halo again; fusing only where a convolution has one or two N
+    // tiles measured within the run-to-run spread in round 3, so it is fused wherever the 3x3 kernel covers the shape)
+    const bool fuse = gn_apply_fuse_enabled() && c.k == 3;
     const void* st_part = x_stats && x_stats->chunks > 0 ? x_stats->part : nullptr;
     int chunks = st_part ? x_stats->chunks : 0;
     if (!st_part) {   // x has no statistics from its producer: one pass over it
@@ -558,6 +551,11 @@ int Run::detokenize(const int64_t* ids, int B, int F, float* out_pixels, ivg_cac
   decoder_feature_plan(c, feats);
   const bool use_cache = cache && cache_mode == 2;
   if (use_cache && (!cache->filled || cache->B != B)) return e->fail(IVG_ERR_INVALID, "detokenize: cache is empty or was made for another batch size");
+  // the kept context frames are pixels as they were written at fill time: reusing them under the other clamp mode would hand back
+  // clamped context frames beside raw predicted ones (or the reverse) -- refuse instead of mixing
+  if (use_cache && cache->clamped != e->clamp_out)
+    return e->fail(IVG_ERR_INVALID, std::string("detokenize: cache was filled with clamp ") + (cache->clamped ? "on" : "off") +
+                                        ", this call runs with clamp " + (e->clamp_out ? "on" : "off") + " (fill it again in this mode)");
   if (cache && cache_mode == 1 && cache->B != B)   // the fill writes B trajectories of features / pixels into buffers sized for cache->B
     return e->fail(IVG_ERR_INVALID, "detokenize: cache was created for " + std::to_string(cache->B) + " trajectories, this call has " + std::to_string(B));
   {
@@ -591,6 +589,7 @@ int Run::detokenize(const int64_t* ids, int B, int F, float* out_pixels, ivg_cac
       CK((int)hipMemcpy2DAsync(cache->ctx_pixels, (size_t)ctx * 3 * res * res * 4, out_pixels, (size_t)T * 3 * res * res * 4,
                                (size_t)ctx * 3 * res * res * 4, B, hipMemcpyDeviceToDevice, st));
       cache->filled = true;
+      cache->clamped = e->clamp_out;
     }
   } else if (!planning) {
     CK((int)hipMemcpy2DAsync(out_pixels, (size_t)T * 3 * res * res * 4, cache->ctx_pixels, (size_t)ctx * 3 * res * res * 4,

@@ -15,6 +15,7 @@
 //   * the prompt pass uses the 256 x 256-tile GEMM (gemm256.hip), a vectorised RoPE + cache append and, in bf16, a one-pass
 //     causal attention kernel; step-wise callers (MBRL) keep the KV cache across calls (ivg_generate_continue).
 #include "engine_impl.h"
+#include "switches.h"
 
 namespace ivg {
 
@@ -24,14 +25,12 @@ static size_t esz(DType d) { return d == BF16 ? 2 : 4; }
 static size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct GenBuf {  // persistent decode-step buffers (fixed addresses so the captured step graph can be replayed)
-  StepState* state;  // [MAX_CHAINS], one per concurrent chain, 256 B apart
+  StepState* state;
   char* x; char* qkv; char* attn; char* act; float* logits;
   int64_t* ids; float* uni; char* act_emb; int Bc, ids_ld;
   float* last_act;   // [Bc][max_frames][action_dim]: the action table of the call that built the kept KV cache
   int* flag;         // mismatch counter of the prefix verification
 };
-constexpr int MAX_CHAINS = 8;
-static StepState* chain_state(const GenBuf& g, int c) { return (StepState*)((char*)g.state + 256 * c); }
 
 static int gen_chunk(const ivg_engine* e) { return std::min(e->cfg.max_batch, 128); }
 
@@ -43,7 +42,7 @@ static void gen_layout(const ivg_engine* e, GenBuf& g, char* base, size_t* total
   g.ids_ld = e->Lmax;
   size_t off = 0;
   auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off = rup(off + bytes, 256); return p; };
-  g.state = (StepState*)take(256 * MAX_CHAINS);
+  g.state = (StepState*)take(256);
   g.x = take((size_t)Bc * H * esz(dt));
   g.qkv = take((size_t)Bc * 3 * H * esz(dt));
   g.attn = take((size_t)Bc * H * esz(dt));
@@ -71,8 +70,7 @@ static char* kc_ptr(const ivg_engine* e, int layer, int which) {
 
 // -------------------------------------------------------------------------------------------- prefill
 static bool flash_prefill_covers(DType dt, int hd) {
-  const char* v = getenv("IVG_FLASH_PREFILL");   // IVG_FLASH_PREFILL=0: score GEMM + softmax + P.V GEMM (A/B tests)
-  return !(v && v[0] == '0') && dt == BF16 && hd == 64;
+  return sw().flash_prefill && dt == BF16 && hd == 64;   // IVG_FLASH_PREFILL=0: score GEMM + softmax + P.V GEMM (A/B tests)
 }
 
 int Run::prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const void* act_emb, int act_T, int ctx, bool all_slots,
@@ -191,14 +189,15 @@ int Run::prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const voi
 // -------------------------------------------------------------------------------------------- one decode step
 // decide token j (sample / forced), embed it, run it through the layers against the KV cache, produce the
 // logits for token j+1, advance the device-side state.
-// One chain = rows [b0, b0 + B) of the generate batch: its own dependency chain, state counters and buffer slices.
-static int step_chain(ivg_engine* e, hipStream_t st, const GenBuf& g, int chain, int b0, int B, const SampleArgs& sa0, bool forward,
-                      bool skip_sample = false) {
+// (Splitting the rows into several concurrent chains on side streams was measured twice -- rounds 2 and 3, also on CU-masked
+// streams -- without gain: every launch is bound by what one CU ingests, half-batch GEMMs cost what full-batch ones do.  Removed.)
+static int step_body(ivg_engine* e, hipStream_t st, const GenBuf& g, int B, const SampleArgs& sa0, bool forward, bool skip_sample = false) {
+  constexpr int b0 = 0;
   const ivg_config& c = e->cfg;
   const DType dt = e->llm_dt;
   const int H = c.hidden_size, I = c.intermediate_size, V = c.vocab_size;
   const size_t es = esz(dt);
-  StepState* state = chain_state(g, chain);
+  StepState* state = g.state;
   char* x = g.x + (size_t)b0 * H * es;
   char* qkv = g.qkv + (size_t)b0 * 3 * H * es;
   char* attn = g.attn + (size_t)b0 * H * es;
@@ -274,27 +273,6 @@ static int step_chain(ivg_engine* e, hipStream_t st, const GenBuf& g, int chain,
   return 0;
 }
 
-// A decode step of the whole batch: the rows are split into `nc` chains that run CONCURRENTLY on side streams (fork /
-// join by events; under stream capture this becomes one graph with nc parallel branches).  Every kernel of a step is
-// latency- or per-CU-ingest-bound and uses a fraction of the chip, so independent chains overlap almost for free and
-// the HBM-bound attention of one chain hides the launch latencies of the others.
-static int step_body(ivg_engine* e, hipStream_t st, const GenBuf& g, int B, int nc, int cs, const SampleArgs& sa, bool forward,
-                     bool skip_sample = false) {
-  if (nc <= 1) return step_chain(e, st, g, 0, 0, B, sa, forward, skip_sample);
-  CK((int)hipEventRecord(e->fork_ev, st));
-  for (int c = 1; c < nc; ++c) CK((int)hipStreamWaitEvent(e->side[c - 1], e->fork_ev, 0));
-  for (int c = 0; c < nc; ++c) {
-    const int b0 = c * cs, bc = std::min(cs, B - b0);
-    if (bc <= 0) continue;
-    IVG_TRY(step_chain(e, c == 0 ? st : e->side[c - 1], g, c, b0, bc, sa, forward, skip_sample));
-  }
-  for (int c = 1; c < nc; ++c) {
-    CK((int)hipEventRecord(e->join_ev[c - 1], e->side[c - 1]));
-    CK((int)hipStreamWaitEvent(st, e->join_ev[c - 1], 0));
-  }
-  return 0;
-}
-
 int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, int n_new, const float* actions, int act_T, int ctx,
                   const float* uniforms, int top_k, int64_t* ids_out, float* reward_out, bool reuse_kv, const void* embeds,
                   int64_t* new_ids_out, void* hidden_out, bool force_sdf) {
@@ -344,15 +322,10 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
         CK((int)hipMemcpy2DAsync(g.x, (size_t)H * es, (const char*)embeds + (size_t)(L0 - 1) * H * es, (size_t)L0 * H * es, (size_t)H * es, Bc,
                                  hipMemcpyDeviceToDevice, st));
     }
-    // chains: rows split into up to e->chains groups of a multiple of 16 rows
-    int nc = std::max(1, std::min(e->chains, MAX_CHAINS));
-    int cs = ((Bc + nc - 1) / nc + 15) / 16 * 16;
-    nc = (Bc + cs - 1) / cs;
-    if (st == nullptr) { nc = 1; cs = Bc; }  // side streams cannot fork from the legacy default stream under capture
     // reuse_kv: the cache already holds positions [0, L0 - 1); the step counter starts at j = 0, whose "decision" is the
     // forced sdf the prompt ends with (0 % 17 == 0): the sampler re-embeds it with the new action and the forward pass of
     // that step appends position L0 - 1 and yields the logits of new token 1 -- exactly what the prefill would have left
-    for (int c = 0; c < nc; ++c) CK(launch_state_set(chain_state(g, c), reuse_kv ? L0 - 1 : L0, reuse_kv ? 0 : 1, st));
+    CK(launch_state_set(g.state, reuse_kv ? L0 - 1 : L0, reuse_kv ? 0 : 1, st));
     SampleArgs sa{};
     sa.logits = g.logits; sa.V = V;
     sa.uniforms = uniforms ? g.uni : nullptr; sa.n_uni = g.ids_ld;
@@ -363,8 +336,9 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
     sa.act = actions ? g.act_emb : nullptr; sa.act_T = act_T; sa.ctx = ctx;
     sa.slot0 = actions ? (L0 - 257 * ctx) / 17 : 0;  // a prompt that already holds t generated frames (MBRL step-wise rollout)
     sa.state = g.state;
+    sa.temperature = e->temperature;
     // step 1 eagerly (also performs every kernel's one-time attribute setup), then replay a captured step graph
-    const std::string key = std::to_string(Bc) + ":" + std::to_string(nc) + ":" + (uniforms ? "s" : "g") + ":" + std::to_string(top_k) + ":" +
+    const std::string key = std::to_string(Bc) + ":" + std::to_string(e->temperature) + ":" + (uniforms ? "s" : "g") + ":" + std::to_string(top_k) + ":" +
                             std::to_string(sa.forced_period) + ":" + std::to_string(ctx) + ":" + std::to_string(act_T) + ":" +
                             std::to_string(L0) + (e->attn_prof_on ? ":p" : "") + (e->gemm_prof_on ? ":q" : "");   // (the same step graph serves both entry modes)
     // reward head: reads the residual stream left by the LAST forward pass, i.e. before the final decide-only step
@@ -380,9 +354,9 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
       return 0;
     };
     int j = 1;
-    if (reuse_kv) IVG_TRY(step_body(e, st, g, Bc, nc, cs, sa, true, embeds != nullptr));   // j = 0: feed the prompt's last token
+    if (reuse_kv) IVG_TRY(step_body(e, st, g, Bc, sa, true, embeds != nullptr));   // j = 0: feed the prompt's last token
     if (n_new == 1) IVG_TRY(reward());
-    if (n_new >= 1) { IVG_TRY(step_body(e, st, g, Bc, nc, cs, sa, j < n_new)); ++j; }
+    if (n_new >= 1) { IVG_TRY(step_body(e, st, g, Bc, sa, j < n_new)); ++j; }
     // the step sequence is position-independent (all step-dependent scalars live in StepState): it is captured once as a graph of
     // ONE step and once as a graph of `multi` consecutive steps -- the long rollouts replay the multi-step graph (a graph launch
     // costs the host ~10-16 us and leaves a bubble on the device; 8 steps per launch amortise it), the tail the single-step one
@@ -396,7 +370,7 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
       hipGraphExec_t ex = nullptr;
       if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
         int rc = 0;
-        for (int i = 0; i < n_steps && rc == 0; ++i) rc = step_body(e, st, g, Bc, nc, cs, sa, true);
+        for (int i = 0; i < n_steps && rc == 0; ++i) rc = step_body(e, st, g, Bc, sa, true);
         const hipError_t ce = hipStreamEndCapture(st, &graph);
         if (rc == 0 && ce == hipSuccess && graph && hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0) == hipSuccess) {
           if (e->graphs.size() >= 64) {   // bound the cache (a server fed ever new prompt lengths): drop all, recapture on demand
@@ -415,18 +389,18 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
       }
       return 0;
     };
-    static const int multi = [] { const char* v = getenv("IVG_GRAPH_STEPS"); const int n = v ? atoi(v) : 8; return n < 1 ? 1 : (n > 32 ? 32 : n); }();
+    constexpr int multi = 8;
     hipGraphExec_t exec = nullptr, exec_multi = nullptr;
     if (j < n_new) IVG_TRY(get_graph(1, &exec));
     if (exec && multi > 1 && n_new - j >= 2 * multi) IVG_TRY(get_graph(multi, &exec_multi));
     while (j < n_new) {
       if (exec_multi && n_new - j >= multi) { CK((int)hipGraphLaunch(exec_multi, st)); j += multi; }
       else if (exec) { CK((int)hipGraphLaunch(exec, st)); ++j; }
-      else { IVG_TRY(step_body(e, st, g, Bc, nc, cs, sa, true)); ++j; }
+      else { IVG_TRY(step_body(e, st, g, Bc, sa, true)); ++j; }
     }
     if (j == n_new && n_new > 1) {
       IVG_TRY(reward());
-      IVG_TRY(step_body(e, st, g, Bc, nc, cs, sa, false));  // decide the last token (no forward)
+      IVG_TRY(step_body(e, st, g, Bc, sa, false));  // decide the last token (no forward)
     }
     if (embeds) {
       CK((int)hipMemcpy2DAsync(new_ids_out + (long)b0 * n_new, (size_t)n_new * 8, g.ids + L0, (size_t)g.ids_ld * 8, (size_t)n_new * 8, Bc,

@@ -62,6 +62,7 @@ class Engine:
         self._stream = torch.cuda.Stream(device=self.device)  # dedicated non-default stream (graph capture needs one)
         self._caches = set()   # live detokenize caches (device memory owned here: released with the engine)
         self._clamp_out = False
+        self._temperature = 1.0
         self._run = None       # the stream of the last call (the dedicated one, or the caller's own)
 
     def close(self):
@@ -109,6 +110,14 @@ class Engine:
         _lib.check(rc, self.h, what)
 
     # ---- entry points
+    def set_temperature(self, t):
+        """``temperature`` of the reference's generate calls (engine state: rarely anything but 1.0)."""
+        t = float(t)
+        if t != self._temperature:
+            self.check(self.lib.ivg_set_temperature(self.h, t), "set_temperature")
+            self._temperature = t
+        return self
+
     def set_context_length(self, k):
         self.check(self.lib.ivg_set_context_length(self.h, int(k)), "set_context_length")
 

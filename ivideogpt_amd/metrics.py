@@ -9,7 +9,7 @@ from . import _lib
 from .packing import dtype_code
 
 
-_WS = {}   # device -> scratch tensor of ivg_frame_metrics (partial sums of the metric tiles)
+_WS = {}   # (device, stream) -> scratch tensor of ivg_frame_metrics (partial sums of the metric tiles)
 
 
 @torch.no_grad()
@@ -27,10 +27,16 @@ def frame_metric_rows(video_gt, video_pred, gt_t0=0, pred_t0=0, frames=None):
     T = frames if frames is not None else min(Tg - gt_t0, Tp - pred_t0)
     rows = torch.empty(B, 3, dtype=torch.float32, device=gt.device)
     nbytes = lib.ivg_frame_metrics_ws_bytes(n, T, H, W)
-    ws = _WS.get(gt.device)              # kept per device: no allocation on the hot path (a serving loop calls this every step)
+    # The scratch is kept PER (device, stream): no allocation on the hot path (a serving loop calls this every step), and two batches
+    # in flight on two streams / host threads (bench.py --lanes) never share partial sums -- the tile kernel writes them and the reduce
+    # kernel of the same call reads them back, ordered by the stream.  A buffer that has to grow is replaced by one allocated under
+    # the same current stream, so the caching allocator hands the old block only to later work of that stream.
+    stream = torch.cuda.current_stream(gt.device)
+    key = (gt.device, stream.cuda_stream)
+    ws = _WS.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
-        ws = _WS[gt.device] = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=gt.device)
-    st = C.c_void_p(torch.cuda.current_stream(gt.device).cuda_stream)
+        ws = _WS[key] = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=gt.device)
+    st = C.c_void_p(stream.cuda_stream)
     _lib.check(lib.ivg_frame_metrics(C.c_void_p(gt.data_ptr()), dtype_code(gt.dtype), B, Tg, gt_t0, C.c_void_p(pred.data_ptr()), n, Tp, pred_t0,
                                      T, H, W, C.c_void_p(rows.data_ptr()), C.c_void_p(ws.data_ptr()), nbytes, st), None, "frame_metrics")
     return rows

@@ -84,10 +84,17 @@ class LlamaForCausalLM:
         self.torch_dtype = torch_dtype(dtype_code(dtype))
         self.device = torch.device("cpu")
         self._engine = None
-        self._packed, self._packed_key = None, None   # the packed weights in HBM, kept across engine rebuilds and shared by replicas
+        # the packed weights in HBM, kept across engine rebuilds and shared by replicas.  Validity is an explicit version counter
+        # bumped by every load_state_dict (never id(dict): a reloaded or in-place mutated dict keeps its id, a collected one's is reused)
+        self._packed, self._packed_key, self._sd_version = None, None, 0
 
     def _pack_key(self):
-        return (id(self._sd), self._prefix, str(self.device), self.dtype)
+        return (self._sd_version, self._prefix, str(self.device), self.dtype)
+
+    def _invalidate_pack(self):
+        """Called whenever the weights, their key prefix or the device change: the old pack is released with the engine that used it."""
+        self._sd_version += 1
+        self._packed, self._packed_key = None, None
 
     def _packed_weights(self):
         if self._packed is None or self._packed_key != self._pack_key():
@@ -103,6 +110,7 @@ class LlamaForCausalLM:
         r = LlamaForCausalLM(self._cfg, self._sd, dtype=self.dtype, prefix=self._prefix, action_dim=self._action_dim,
                              reward_prediction=self._reward)
         r.device = self.device
+        r._sd_version = self._sd_version
         r._packed, r._packed_key = self._packed_weights(), self._pack_key()
         return r
 
@@ -128,6 +136,7 @@ class LlamaForCausalLM:
             W.validate_state_dict(sd, W.llama_param_shapes(self._cfg), "transformer")
         self._sd, self._prefix = sd, ""
         self._drop_engine()
+        self._invalidate_pack()
 
     def save_pretrained(self, path, subfolder="transformer"):
         W.save_transformer_checkpoint(path, self._cfg, self._sd, subfolder)
@@ -140,6 +149,7 @@ class LlamaForCausalLM:
             if dev != self.device:
                 self.device = dev
                 self._drop_engine()
+                self._packed, self._packed_key = None, None   # the pack lives on the old device
         return self
 
     def cuda(self, index=None):
@@ -188,14 +198,15 @@ class LlamaForCausalLM:
         ``hidden_states[-1][-1]`` = last layer (post final norm) of the LAST forward pass, (B, 1, hidden).
         When the engine's KV cache was built from exactly ``inputs_embeds[:, :-1]`` (the step-wise rollout: previous prompt +
         the embeddings of the tokens it generated), only the last row is fed -- verified on the device, never assumed."""
-        assert temperature == 1.0, "the reference always samples at temperature 1.0"
+        if not (isinstance(temperature, (int, float)) and temperature > 0):   # HF's TemperatureLogitsWarper raises the same way
+            raise ValueError(f"`temperature` (={temperature}) has to be a strictly positive float")
         if inputs_embeds is not None:
             emb = inputs_embeds.to(device=self.device, dtype=self.torch_dtype).contiguous()
             B, L0, _ = emb.shape
             out = torch.empty(B, max_new_tokens, dtype=torch.int64, device=self.device)
             hidden = torch.empty(B, 1, emb.shape[-1], dtype=self.torch_dtype, device=self.device) if output_hidden_states else None
             u = uniforms if uniforms is not None else self._uniforms(B, max_new_tokens, do_sample, generator)
-            self.last_generate_reused_cache = self._ensure(B).generate_embeds(
+            self.last_generate_reused_cache = self._ensure(B).set_temperature(temperature).generate_embeds(
                 emb, max_new_tokens, out, hidden=hidden, uniforms=u, top_k=top_k or self._cfg["vocab_size"], allow_reuse=use_cache)
             if not return_dict_in_generate:
                 return out
@@ -204,7 +215,7 @@ class LlamaForCausalLM:
         B, L0 = ids.shape
         out = torch.empty(B, L0 + max_new_tokens, dtype=torch.int64, device=self.device)
         u = uniforms if uniforms is not None else self._uniforms(B, max_new_tokens, do_sample, generator)
-        self._ensure(B).generate(ids, max_new_tokens, out, uniforms=u, top_k=top_k or self._cfg["vocab_size"])
+        self._ensure(B).set_temperature(temperature).generate(ids, max_new_tokens, out, uniforms=u, top_k=top_k or self._cfg["vocab_size"])
         return out
 
     @torch.no_grad()
@@ -261,7 +272,9 @@ class HeadModelWithAction:
         self.token_for_sdf = llm.config.vocab_size - 1
         self.reward_prediction = reward_prediction
         self.action_recon = action_recon
-        llm._action_dim, llm._reward, llm._prefix = action_dim, reward_prediction, "llm."
+        if (llm._action_dim, llm._reward, llm._prefix) != (action_dim, reward_prediction, "llm."):
+            llm._action_dim, llm._reward, llm._prefix = action_dim, reward_prediction, "llm."
+            llm._invalidate_pack()   # other key prefix / extra heads: whatever was packed for the bare llm is stale
         llm._drop_engine()   # an engine built for the bare llm has no action / reward head
         self.device = llm.device
         self.action_linear = _ActionLinear(llm)
@@ -274,12 +287,9 @@ class HeadModelWithAction:
 
     def replica(self):
         """As LlamaForCausalLM.replica: a second wrapper (own engine) over the same weights in HBM."""
-        llm = self.llm.replica()
-        packed, key = llm._packed, llm._packed_key
-        r = HeadModelWithAction(llm, self.action_dim, self.prelude_tokens_num, self.tokens_num_per_dyna, self.context, self.segment_length,
-                                model_type=self.model_type, reward_prediction=self.reward_prediction, action_recon=self.action_recon)
-        llm._packed, llm._packed_key = packed, key
-        return r
+        llm = self.llm.replica()   # (carries action_dim / reward / prefix and the shared pack: the wrapper below changes none of them)
+        return HeadModelWithAction(llm, self.action_dim, self.prelude_tokens_num, self.tokens_num_per_dyna, self.context, self.segment_length,
+                                   model_type=self.model_type, reward_prediction=self.reward_prediction, action_recon=self.action_recon)
 
     def load_state_dict(self, sd, strict=True):
         if strict:
@@ -287,6 +297,7 @@ class HeadModelWithAction:
                                   W.llama_param_shapes(self.llm._cfg, self.action_dim, self.reward_prediction), "HeadModelWithAction")
         self.llm._sd, self.llm._prefix = sd, "llm."
         self.llm._drop_engine()
+        self.llm._invalidate_pack()
 
     def state_dict(self):
         return self.llm._sd
@@ -307,7 +318,8 @@ class HeadModelWithAction:
         ``reuse_cache=True`` (step-wise rollouts, mbrl/video_predictor.py:286-317): the prompt is the previous call's full
         output plus the forced ``sdf``; the engine keeps the KV cache of that call and feeds only the last prompt token
         instead of prefilling the grown prompt again (raises AssertionError when the cache holds something else)."""
-        assert temperature == 1.0
+        if not (isinstance(temperature, (int, float)) and temperature > 0):
+            raise ValueError(f"`temperature` (={temperature}) has to be a strictly positive float")
         llm = self.llm
         ids = inputs_token.to(device=llm.device, dtype=torch.int64).contiguous()
         B, L0 = ids.shape
@@ -315,7 +327,7 @@ class HeadModelWithAction:
         out = torch.empty(B, L0 + max_new_tokens, dtype=torch.int64, device=llm.device)
         u = uniforms if uniforms is not None else llm._uniforms(B, max_new_tokens, do_sample, generator)
         reward = torch.empty(B, dtype=torch.float32, device=llm.device) if return_reward else None
-        llm._ensure(B, act.shape[1]).generate(ids, max_new_tokens, out, actions=act, ctx=self.context, uniforms=u,
+        llm._ensure(B, act.shape[1]).set_temperature(temperature).generate(ids, max_new_tokens, out, actions=act, ctx=self.context, uniforms=u,
                                               top_k=top_k or llm._cfg["vocab_size"], reward=reward, reuse_kv=reuse_cache)
         return (out, reward) if return_reward else out
 
@@ -325,14 +337,15 @@ class HeadModelWithAction:
         """action_model.py:123-152 (no caller in the reference): per future frame 16 sampled tokens, then the forced ``sdf`` -- the
         schedule of ``generate`` without any action embedding; the last forced ``sdf`` is dropped.  -> int64 (B, L0 + max_new_tokens).
         One prefill + cached steps instead of the reference's per-frame re-prefill (token-identical: same argument as ``generate``)."""
-        assert temperature == 1.0
+        if not (isinstance(temperature, (int, float)) and temperature > 0):
+            raise ValueError(f"`temperature` (={temperature}) has to be a strictly positive float")
         llm = self.llm
         ids = inputs_token.to(device=llm.device, dtype=torch.int64).contiguous()
         B, L0 = ids.shape
         assert (max_new_tokens + 1) % (self.segment_length - self.context) == 0, "max_new_tokens must be (tokens_per_dyna + 1) * frames - 1"
         out = torch.empty(B, L0 + max_new_tokens, dtype=torch.int64, device=llm.device)
         u = uniforms if uniforms is not None else llm._uniforms(B, max_new_tokens, do_sample, generator)
-        llm._ensure(B).generate_forced_sdf(ids, max_new_tokens, out, ctx=self.context, uniforms=u, top_k=top_k or llm._cfg["vocab_size"])
+        llm._ensure(B).set_temperature(temperature).generate_forced_sdf(ids, max_new_tokens, out, ctx=self.context, uniforms=u, top_k=top_k or llm._cfg["vocab_size"])
         return out
 
     @torch.no_grad()

@@ -53,11 +53,13 @@ class CompressiveVQModel:
         self.encode_dtype, self.decode_dtype = encode_dtype, decode_dtype
         self.device = torch.device("cpu")
         self._engine = None
-        self._packed, self._packed_key = None, None   # the packed weights in HBM, kept across engine rebuilds and shared by replicas
+        # the packed weights in HBM, kept across engine rebuilds and shared by replicas; valid for one (weights version, device,
+        # dtypes) -- the version is bumped by load_state_dict (never id(dict): it survives in-place edits and is reused after gc)
+        self._packed, self._packed_key, self._sd_version = None, None, 0
         self.training = False
 
     def _pack_key(self):
-        return (id(self._sd), str(self.device), self.encode_dtype, self.decode_dtype, self._pretrained_context)
+        return (self._sd_version, str(self.device), self.encode_dtype, self.decode_dtype, self._pretrained_context)
 
     def _packed_weights(self, cfg):
         from .packing import dtype_code
@@ -75,6 +77,7 @@ class CompressiveVQModel:
         cfg["context_length"] = self._pretrained_context
         r = CompressiveVQModel(cfg, self._sd, encode_dtype=self.encode_dtype, decode_dtype=self.decode_dtype)
         r.device = self.device
+        r._sd_version = self._sd_version
         r._packed, r._packed_key = self._packed_weights(cfg), self._pack_key()
         if self.context_length != self._pretrained_context:
             r.set_context_length(self.context_length)
@@ -102,6 +105,8 @@ class CompressiveVQModel:
             W.validate_state_dict(sd, W.tokenizer_param_shapes(self.config), "tokenizer")
         self._sd = sd
         self._drop_engine()
+        self._sd_version += 1
+        self._packed, self._packed_key = None, None
 
     def save_pretrained(self, path, subfolder=None):
         cfg = dict(self.config)
@@ -116,6 +121,7 @@ class CompressiveVQModel:
             if dev != self.device:
                 self.device = dev
                 self._drop_engine()
+                self._packed, self._packed_key = None, None   # the pack lives on the old device
         return self
 
     def cuda(self, index=None):

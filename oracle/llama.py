@@ -90,13 +90,16 @@ class LlamaRef:
         return self.forward_embeds(self.embed(ids) if embeds is None else embeds)[0]
 
 
-def sample_from_logits(logits, top_k, u):
-    """logits [B,V] fp32; u [B] in [0,1) or None (greedy).  Restates TopKLogitsWarper + softmax +
+def sample_from_logits(logits, top_k, u, temperature=1.0):
+    """logits [B,V] fp32; u [B] in [0,1) or None (greedy).  Restates TemperatureLogitsWarper (``scores / temperature`` in fp32,
+    applied first: HF builds the warper list temperature -> top-k) + TopKLogitsWarper + softmax +
     one draw: keep every token whose logit >= the k-th largest (ties at the threshold are all
     kept), p = softmax over the kept set, pick the first kept token, in ascending id order, whose
     cumulative probability exceeds u * sum(p)."""
     if u is None:
         return torch.argmax(logits, -1)
+    if temperature != 1.0:
+        logits = logits / torch.tensor(temperature, dtype=torch.float32)
     kth = torch.topk(logits, min(top_k, logits.shape[-1]), dim=-1).values[..., -1:]
     keep = logits >= kth
     m = logits.max(-1, keepdim=True).values
@@ -109,7 +112,7 @@ def sample_from_logits(logits, top_k, u):
 
 @torch.no_grad()
 def generate_cached(model, input_ids, n_new, top_k=100, uniforms=None, action_embeds=None, ctx=None,
-                    tokens_per_dyn=16, sdf_token=None, return_last_hidden=False):
+                    tokens_per_dyn=16, sdf_token=None, return_last_hidden=False, temperature=1.0):
     """One prefill + cached single-token steps (the engine's algorithm; SURVEY.md 3.3 shows it is
     token-identical to the reference's per-frame re-prefill).
 
@@ -139,7 +142,7 @@ def generate_cached(model, input_ids, n_new, top_k=100, uniforms=None, action_em
         if forced:
             tok = torch.full((B,), sdf_token, dtype=input_ids.dtype)
         else:
-            tok = sample_from_logits(last, top_k, None if uniforms is None else uniforms[:, j - 1]).to(input_ids.dtype)
+            tok = sample_from_logits(last, top_k, None if uniforms is None else uniforms[:, j - 1], temperature).to(input_ids.dtype)
         out.append(tok[:, None])
         if j == n_new:
             break

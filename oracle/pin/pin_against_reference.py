@@ -425,6 +425,36 @@ def pin_fractal_clip():
     save("fractal_clip_seed0.npz", clip=clip_ref, seed=0, dataset_name="fractal20220817_data", segment_length=16, resolution=64)
 
 
+def pin_sampler():
+    """oracle.llama.sample_from_logits against HF's own logits processors (the reference passes temperature / top_k straight to HF
+    generate: inference/predict.py:57-69, action_model.py:101-110): TemperatureLogitsWarper -> TopKLogitsWarper -> softmax.  HF
+    then calls torch.multinomial (stream not reproducible); the draw is pinned as the inverse CDF of HF's probabilities in
+    ascending id order.  Writes tests/golden/sampler_temperature.npz (seeded logits are re-derived by the test)."""
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopKLogitsWarper
+    B, V, k = 48, 16386, 100
+    g = torch.Generator().manual_seed(777)
+    logits = torch.randn(B, V, generator=g) * 3
+    u = torch.rand(B, generator=g)
+    out = {}
+    for T in (0.7, 1.0, 1.3):
+        scores = logits.clone()
+        if T != 1.0:
+            scores = TemperatureLogitsWarper(T)(None, scores)
+        scores = TopKLogitsWarper(top_k=k, filter_value=-float("inf"))(None, scores)
+        probs = torch.softmax(scores, -1)
+        assert int((probs > 0).sum(-1).min()) >= k
+        cdf = torch.cumsum(probs.double(), -1)
+        tok_hf = (cdf > (u.double() * cdf[:, -1]).view(-1, 1)).double().argmax(-1)
+        tok = OL.sample_from_logits(logits, k, u, temperature=T)
+        kept = OL.sample_from_logits(logits, k, None)   # greedy is temperature-free
+        assert torch.equal(kept, logits.argmax(-1))
+        assert torch.equal(tok, tok_hf), f"sampler at temperature {T}: oracle != HF processors"
+        out[f"tok_T{T}"] = tok
+    assert not torch.equal(out["tok_T0.7"], out["tok_T1.3"])
+    save("sampler_temperature.npz", seed=np.int64(777), B=np.int64(B), V=np.int64(V), top_k=np.int64(k), u=u, **out)
+    print("[sampler] oracle == HF TemperatureLogitsWarper + TopKLogitsWarper + softmax inverse CDF at T = 0.7 / 1.0 / 1.3")
+
+
 def pin_param_counts():
     n64 = W.count_params(W.tokenizer_param_shapes(W.CTX_VAE64))
     n256 = W.count_params(W.tokenizer_param_shapes(W.CTX_VAE256))
@@ -456,6 +486,7 @@ def main():
     pin_eval_forward(HeadModelWithAction, "tiny_ctx2", tiny, seed=41, B=3, ctx=2, F=3, action_dim=4)
     pin_bf16(CompressiveVQModel, "mini64_ctx2", mini64, 11, tiny, 21, 0.4)
     pin_fractal_clip()
+    pin_sampler()
     print("all pins passed")
 
 

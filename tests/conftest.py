@@ -16,3 +16,22 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture
+def switches(monkeypatch):
+    """``switches(IVG_X="0", IVG_Y=None)``: set / delete IVG_* variables and publish them to the loaded library (the switch table
+    of csrc/switches.h is read at load, at ivg_create and on ivg_reload_switches -- an op-level test that flips a switch between two
+    launches has to say so).  The environment and the library's table are restored after the test."""
+    from ivideogpt_amd import _lib
+
+    def apply(**kv):
+        for k, v in kv.items():
+            if v is None:
+                monkeypatch.delenv(k, raising=False)
+            else:
+                monkeypatch.setenv(k, str(v))
+        _lib.reload_switches()
+    yield apply
+    monkeypatch.undo()
+    _lib.reload_switches()

@@ -356,10 +356,50 @@ def test_sampler_matches_oracle(case):
     want = sample_from_logits(logits, k, u)
     lg, ud = logits.to(DEV), u.to(DEV)
     out = torch.full((B,), -7, dtype=torch.int64, device=DEV)
-    assert l.ivg_op_sample(P(lg), B, V, k, P(ud), P(out), stream()) == 0
+    assert l.ivg_op_sample(P(lg), B, V, k, 1.0, P(ud), P(out), stream()) == 0
     assert torch.equal(out.cpu(), want), (out.cpu() != want).nonzero().flatten().tolist()
-    assert l.ivg_op_sample(P(lg), B, V, k, None, P(out), stream()) == 0
+    assert l.ivg_op_sample(P(lg), B, V, k, 1.0, None, P(out), stream()) == 0
     assert torch.equal(out.cpu(), sample_from_logits(logits, k, None))
+
+
+@pytest.mark.parametrize("temperature", [0.7, 1.3, 0.05, 9.0])
+@pytest.mark.parametrize("V", [8194, 16386])
+def test_sampler_temperature_matches_oracle(temperature, V):
+    """``generate(..., temperature=T)`` of the reference (action_model.py:61,89; HF TemperatureLogitsWarper: scores / T in fp32
+    BEFORE the top-k filter): token-identical to oracle/llama.py sample_from_logits(temperature=T), greedy unchanged."""
+    from oracle.llama import sample_from_logits
+    L, l = lib()
+    g = torch.Generator().manual_seed(int(temperature * 100) + V)
+    B, k = 64, 100
+    logits = torch.randn(B, V, generator=g) * 3
+    logits[3, 11] = float("-inf")
+    u = torch.rand(B, generator=g)
+    u[0], u[2] = 0.0, 0.99999994
+    want = sample_from_logits(logits, k, u, temperature=temperature)
+    assert not torch.equal(want, sample_from_logits(logits, k, u)), "the case must tell the temperatures apart"
+    lg, ud = logits.to(DEV), u.to(DEV)
+    out = torch.full((B,), -7, dtype=torch.int64, device=DEV)
+    assert l.ivg_op_sample(P(lg), B, V, k, temperature, P(ud), P(out), stream()) == 0
+    assert torch.equal(out.cpu(), want), (out.cpu() != want).nonzero().flatten().tolist()
+    assert l.ivg_op_sample(P(lg), B, V, k, temperature, None, P(out), stream()) == 0
+    assert torch.equal(out.cpu(), sample_from_logits(logits, k, None))
+    assert l.ivg_op_sample(P(lg), B, V, k, 0.0, P(ud), P(out), stream()) == -1, "temperature must be strictly positive (HF raises)"
+
+
+def test_sampler_temperature_vs_hf_processor_golden():
+    """The sampler kernel against tokens drawn through HF's own TemperatureLogitsWarper -> TopKLogitsWarper -> softmax
+    (tests/golden/sampler_temperature.npz; the reference hands temperature / top_k to HF generate)."""
+    from helpers import load_golden
+    L, l = lib()
+    g = load_golden("sampler_temperature.npz")
+    B, V, k = int(g["B"]), int(g["V"]), int(g["top_k"])
+    gen = torch.Generator().manual_seed(int(g["seed"]))
+    lg = (torch.randn(B, V, generator=gen) * 3).to(DEV)
+    ud = torch.from_numpy(g["u"]).to(DEV)
+    out = torch.full((B,), -7, dtype=torch.int64, device=DEV)
+    for T in (0.7, 1.0, 1.3):
+        assert l.ivg_op_sample(P(lg), B, V, k, T, P(ud), P(out), stream()) == 0
+        assert torch.equal(out.cpu(), torch.from_numpy(g[f"tok_T{T}"])), T
 
 
 @pytest.mark.parametrize("M", [64, 50, 16])
@@ -389,18 +429,13 @@ DECODE_SHAPES = [  # (K, N, flags): every decode-step GEMM of the small (768 / 3
 @pytest.mark.parametrize("gen", ["gen3", "gen2", "gen1"])
 @pytest.mark.parametrize("dt", ["bf16", "fp32"])
 @pytest.mark.parametrize("K,N,mode", DECODE_SHAPES)
-def test_decode_gemm_model_shapes(K, N, mode, dt, gen, monkeypatch):
+def test_decode_gemm_model_shapes(K, N, mode, dt, gen, switches):
     """The decode-step GEMMs at the shapes the rollouts run (BASELINE configs 2 and 5), with their fused epilogues -- RMSNorm row
     scale, in-place residual, SiLU(gate) * up, fp32 logits -- against fp64, for the third-generation kernel (dgemm3.hip: K over up
     to 16 waves, one barrier; the default), the second (IVG_DG3=0, dgemm.hip: activations as whole lines through LDS) and the
     first (IVG_DG=0, skinny.hip)."""
     L, l = lib()
-    monkeypatch.delenv("IVG_DG", raising=False)
-    monkeypatch.delenv("IVG_DG3", raising=False)
-    if gen in ("gen2", "gen1"):
-        monkeypatch.setenv("IVG_DG3", "0")
-    if gen == "gen1":
-        monkeypatch.setenv("IVG_DG", "0")
+    switches(IVG_DG3="0" if gen in ("gen2", "gen1") else None, IVG_DG="0" if gen == "gen1" else None, IVG_DECODE_LDS_KB=None)
     g = torch.Generator().manual_seed(K + N)
     for M in (64, 37, 128):
         x = q(torch.randn(M, K, generator=g) * 1.7, dt)
@@ -440,17 +475,14 @@ def test_decode_gemm_model_shapes(K, N, mode, dt, gen, monkeypatch):
 
 @pytest.mark.parametrize("line", ["1", "0"])
 @pytest.mark.parametrize("mode", ["plain", "bias_residual_inplace", "glu", "silu", "k_short", "k_odd_steps", "nimg"])
-def test_gemm256_large_dense(mode, line, monkeypatch):
-    """(k_odd_steps also runs the two-steps-per-barrier variant, IVG_G256_PAIR=1, whose last pair is half empty)
-    256 x 256-tile GEMM of the prompt pass (bf16, rows not a multiple of 256): every epilogue against fp64, and bit-for-bit
+def test_gemm256_large_dense(mode, line, switches):
+    """256 x 256-tile GEMM of the prompt pass (bf16, rows not a multiple of 256): every epilogue against fp64, and bit-for-bit
     agreement is NOT required with the 128 x 128 kernel -- but both must sit inside the same bf16 tolerance.
     line = 1: whole-line requests (K steps of 64 elements, the default where K % 64 == 0; k_odd_steps has K = 160 and stays on
     the 64-byte-row kernel); line = 0 (IVG_G256_LINE=0): the 64-byte-row kernel everywhere."""
-    monkeypatch.setenv("IVG_G256_LINE", line)
+    switches(IVG_G256_LINE=line)
     g = torch.Generator().manual_seed(len(mode))
-    if mode == "k_odd_steps":
-        monkeypatch.setenv("IVG_G256_PAIR", "1")
-    M, N, K = 4900, 512, {"k_short": 64, "k_odd_steps": 96 + 64}.get(mode, 384)   # 2 / 5 / 12 K steps (two per barrier)
+    M, N, K = 4900, 512, {"k_short": 64, "k_odd_steps": 96 + 64}.get(mode, 384)   # 2 / 5 / 12 K steps
     dt = "bf16"
     X = q(torch.randn(M, K, generator=g), dt)
     W_ = q(torch.randn(N, K, generator=g) / K ** 0.5, dt)

@@ -178,3 +178,18 @@ def test_frame_metric_oracle_known_answers():
     assert torch.allclose(rows[:, 2], torch.tensor((2 * a * b1 + c1) / (a * a + b1 * b1 + c1), dtype=torch.float32), atol=2e-4)
     same = frame_metric_rows(gt, gt.clone())
     assert same[:, 0].abs().max().item() == 0 and torch.allclose(same[:, 1], torch.tensor(80.0), atol=1e-3) and torch.allclose(same[:, 2], torch.tensor(1.0))
+
+
+def test_sampler_with_temperature_vs_hf_processor_golden():
+    """oracle.llama.sample_from_logits against tokens drawn through HF's OWN TemperatureLogitsWarper -> TopKLogitsWarper -> softmax
+    (tests/golden/sampler_temperature.npz, written by oracle/pin/pin_against_reference.py: pin_sampler) at T = 0.7 / 1.0 / 1.3."""
+    from helpers import load_golden
+    from oracle.llama import sample_from_logits
+    g = load_golden("sampler_temperature.npz")
+    B, V, k = int(g["B"]), int(g["V"]), int(g["top_k"])
+    gen = torch.Generator().manual_seed(int(g["seed"]))
+    logits = torch.randn(B, V, generator=gen) * 3
+    u = torch.from_numpy(g["u"])
+    assert torch.equal(torch.rand(B, generator=gen), u)
+    for T in (0.7, 1.0, 1.3):
+        assert torch.equal(sample_from_logits(logits, k, u, temperature=T), torch.from_numpy(g[f"tok_T{T}"])), T

@@ -14,8 +14,8 @@ u = torch.rand(64, generator=g).cuda()
 out = torch.zeros(64, dtype=torch.int64, device="cuda")
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 for k in (100, 100, 100, 100, 1000, 1000):
-    assert l.ivg_op_sample(C.c_void_p(lg.data_ptr()), 64, V, k, C.c_void_p(u.data_ptr()), C.c_void_p(out.data_ptr()), st) == 0
+    assert l.ivg_op_sample(C.c_void_p(lg.data_ptr()), 64, V, k, 1.0, C.c_void_p(u.data_ptr()), C.c_void_p(out.data_ptr()), st) == 0
 for _ in range(3):
-    assert l.ivg_op_sample(C.c_void_p(lg.data_ptr()), 64, V, 100, None, C.c_void_p(out.data_ptr()), st) == 0
+    assert l.ivg_op_sample(C.c_void_p(lg.data_ptr()), 64, V, 100, 1.0, None, C.c_void_p(out.data_ptr()), st) == 0
 torch.cuda.synchronize()
 print("ok", out[:4].tolist())
