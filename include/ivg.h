@@ -30,7 +30,10 @@ typedef struct ivg_engine ivg_engine;
 typedef struct ivg_cache ivg_cache;
 typedef void* ivg_stream; /* hipStream_t */
 
-enum ivg_dtype { IVG_F32 = 0, IVG_BF16 = 1 };
+/* IVG_F32X3 (ivg_config.decode_dtype / llm_dtype only): the tensors are float32 in HBM (pass IVG_F32 pointers), the matrix products of
+ * the path run in split-bf16 arithmetic -- every operand as bf16 hi + bf16 lo (2^-17), all four partial products on the bf16 MFMA
+ * path, fp32 accumulation: the mode that meets the 1e-3 parity bar on pixels / logits without the f32-input MFMA rate (1/16 of bf16). */
+enum ivg_dtype { IVG_F32 = 0, IVG_BF16 = 1, IVG_F32X3 = 2 };
 
 enum ivg_status {
   IVG_OK = 0,
@@ -76,9 +79,9 @@ typedef struct {
   int32_t action_dim;      /* 0: action-free LlamaForCausalLM; >0: HeadModelWithAction */
   int32_t reward_head;     /* 1: reward_linear present */
   /* ---- arithmetic types */
-  int32_t encode_dtype;    /* tokenize path (default IVG_F32: VQ indices must match the fp32 reference) */
-  int32_t decode_dtype;    /* detokenize path */
-  int32_t llm_dtype;       /* transformer */
+  int32_t encode_dtype;    /* tokenize path (default IVG_F32: VQ indices must match the fp32 reference; IVG_F32X3 is refused) */
+  int32_t decode_dtype;    /* detokenize path: IVG_F32, IVG_BF16 or IVG_F32X3 */
+  int32_t llm_dtype;       /* transformer: IVG_F32, IVG_BF16 or IVG_F32X3 */
   /* ---- capacity the workspace / KV cache are sized for */
   int32_t max_batch;       /* trajectories per call */
   int32_t max_frames;      /* frames per clip (T) */
@@ -253,6 +256,12 @@ int ivg_op_conv_gn(const ivg_igemm_args* a, int dtype, void* gn_part, int groups
 /* y = conv3x3(silu(GroupNorm(x))) (+ bias, residual) with the GroupNorm applied inside the convolution's input staging: the
  * normalised tensor is never written.  ws: scratch of at least Nimg * (ceil(Hin*Win/1024) * groups * 16 + Cin * 8) bytes. */
 int ivg_op_gn_conv(const ivg_igemm_args* a, int dtype, int groups, const float* gamma, const float* beta, float eps, void* ws, ivg_stream stream);
+/* 3x3 convolution on fp32 tensors in split-bf16 arithmetic (the "x3" decode mode): w_x3 = the [N][9 * Cin] weight matrix with every 4
+ * consecutive K elements stored as [bf16 hi(4) | bf16 lo(4)] (ivideogpt_amd/packing.py: pack_x3), activations split the same way
+ * inside the kernel, fp32 accumulate.  gamma != NULL: y = conv3x3(silu(GroupNorm(x))) with the normalisation inside the staging
+ * (ws as ivg_op_gn_conv).  IVG_ERR_INVALID when the 3x3 kernel does not cover the shape. */
+int ivg_op_conv_x3(const ivg_igemm_args* a, const void* w_x3, int groups, const float* gamma, const float* beta, float eps, void* ws,
+                   ivg_stream stream);
 /* Tokenizer cross-attention in one pass (bf16 only; IVG_ERR_INVALID when the shape is not covered): q [M][P][C], Kp [M/F][kv][C],
  * VpT [M/F][C][kv] -> out [M][P][C], heads of C / nh channels, softmax(q k^T / sqrt(C / nh)) v per head
  * (ivideogpt/vq_model/conditional_vae.py:38-55). */

@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libivg.so")
 
-IVG_F32, IVG_BF16 = 0, 1
+IVG_F32, IVG_BF16, IVG_F32X3 = 0, 1, 2
 IVG_K_IGEMM_BF16, IVG_K_IGEMM_F32, IVG_K_CONV3X3_BF16, IVG_K_CONV3X3_F32, IVG_K_DECODE_ATTN, IVG_K_DECODE_GEMM = 0, 1, 2, 3, 4, 5
 # igemm epilogue flags (csrc/igemm.h)
 IG_BIAS_N, IG_BIAS_M, IG_RESIDUAL, IG_SILU, IG_GLU, IG_OUT_F32 = 1, 2, 4, 8, 16, 32
@@ -92,6 +92,7 @@ EXPORTS = {
     "ivg_op_conv_gn": (C.c_int, [C.POINTER(IvgIgemmArgs), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int,
                                  C.c_void_p]),
     "ivg_op_gn_conv": (C.c_int, [C.POINTER(IvgIgemmArgs), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    "ivg_op_conv_x3": (C.c_int, [C.POINTER(IvgIgemmArgs), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "ivg_op_xattn": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 7 + [C.c_void_p]),
     "ivg_op_skinny": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 9 + [C.c_void_p]),
     "ivg_op_groupnorm": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_float, C.c_int, C.c_int, C.c_void_p]),

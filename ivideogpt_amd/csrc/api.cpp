@@ -41,6 +41,8 @@ struct Lookup {
     ConvW c; c.cin = cin; c.cout = cout; c.k = k;
     c.w = data(n + ".weight", (int)dt, (int64_t)cout * k * k * cin);
     c.b = f32(n + ".bias", cout);
+    // optional: the same matrix pre-split into bf16 (hi, lo) pairs for the split-bf16 3x3 kernel (packing.py: pack_x3)
+    if (dt == F32 && k == 3 && e->wmap.count(n + ".weight.x3")) c.w3 = data(n + ".weight.x3", IVG_BF16, (int64_t)2 * cout * k * k * cin);
     return c;
   }
   NormW norm(const std::string& n, int C) { NormW r; r.g = f32(n + ".weight", C); r.b = f32(n + ".bias", C); return r; }
@@ -293,7 +295,10 @@ int ivg_create(const ivg_config* cfg, const ivg_tensor* weights, int n_weights, 
   // issues a launch in ~4 us against ~10 us of device time per kernel, so it stays ahead).  IVG_GRAPH=1 captures the step into
   // a hipGraph (8 steps per launch) for callers that need the host thread back early.
   e->use_graph = sw().graph != 0;
-  e->enc_dt = (DType)cfg->encode_dtype; e->dec_dt = (DType)cfg->decode_dtype; e->llm_dt = (DType)cfg->llm_dtype;
+  if (cfg->encode_dtype == IVG_F32X3) { e->err = "ivg_create: encode_dtype cannot be IVG_F32X3 (bit-exact VQ indices need the exact fp32 chain)"; return bail(IVG_ERR_INVALID); }
+  // IVG_F32X3: fp32 tensors, split-bf16 matrix arithmetic (conv3x3.hip / igemm.hip X3 instances)
+  e->dec_x3 = cfg->decode_dtype == IVG_F32X3; e->llm_x3 = cfg->llm_dtype == IVG_F32X3;
+  e->enc_dt = (DType)cfg->encode_dtype; e->dec_dt = e->dec_x3 ? F32 : (DType)cfg->decode_dtype; e->llm_dt = e->llm_x3 ? F32 : (DType)cfg->llm_dtype;
   e->ctx = cfg->context_length > 0 ? cfg->context_length : 1;
   for (int i = 0; i < n_weights; ++i) e->wmap[weights[i].name] = weights[i];
   if (cfg->max_batch <= 0 || cfg->max_frames <= 0) { e->err = "ivg_create: max_batch / max_frames must be positive"; return bail(IVG_ERR_INVALID); }
@@ -749,6 +754,29 @@ int ivg_op_gn_conv(const ivg_igemm_args* a, int dtype, int groups, const float* 
   if (launch_gn_coef(part, nch, gamma, beta, a->Nimg, P, a->Cin, groups, eps, coef, (hipStream_t)stream)) return IVG_ERR_HIP;
   g.gn_in_coef = coef;
   const int rc = launch_conv3x3(g, (DType)dtype, (hipStream_t)stream);
+  return rc == 0 ? IVG_OK : (rc > 0 ? IVG_ERR_HIP : IVG_ERR_INVALID);
+}
+
+int ivg_op_conv_x3(const ivg_igemm_args* a, const void* w_x3, int groups, const float* gamma, const float* beta, float eps, void* ws, ivg_stream stream) {
+  // unit-test hook of the split-bf16 3x3 convolution (fp32 tensors, weights pre-split by packing.py pack_x3); gamma != NULL: with
+  // GroupNorm + SiLU of the input applied (and the result split) inside the staging, ws as in ivg_op_gn_conv
+  IgemmArgs g;
+  g.X = a->X; g.W = a->W; g.Y = a->Y; g.R = a->R; g.bias = a->bias;
+  g.Nimg = a->Nimg; g.Hin = a->Hin; g.Win = a->Win; g.Cin = a->Cin; g.ldx = a->ldx; g.Hout = a->Hout; g.Wout = a->Wout;
+  g.KH = a->KH; g.KW = a->KW; g.stride = a->stride; g.pad = a->pad; g.ups = a->ups; g.N = a->N; g.ldw = a->ldw;
+  g.c_img = a->c_img; g.c_pix = a->c_pix; g.c_ch = a->c_ch; g.c_grp = a->c_grp; g.c_grp_stride = a->c_grp_stride;
+  g.flags = a->flags; g.alpha = a->alpha;
+  g.W_x3 = w_x3;
+  if (!w_x3) return IVG_ERR_INVALID;
+  if (gamma) {
+    const int P = a->Hin * a->Win, nch = gn_num_chunks(P);
+    char* part = (char*)ws;
+    char* coef = part + (size_t)a->Nimg * nch * groups * 16;
+    if (launch_groupnorm_partial(a->X, part, a->Nimg, P, a->Cin, groups, F32, (hipStream_t)stream)) return IVG_ERR_HIP;
+    if (launch_gn_coef(part, nch, gamma, beta, a->Nimg, P, a->Cin, groups, eps, coef, (hipStream_t)stream)) return IVG_ERR_HIP;
+    g.gn_in_coef = coef;
+  }
+  const int rc = launch_conv3x3(g, F32, (hipStream_t)stream);
   return rc == 0 ? IVG_OK : (rc > 0 ? IVG_ERR_HIP : IVG_ERR_INVALID);
 }
 

@@ -108,8 +108,15 @@ template <int N> __device__ __forceinline__ void wait_dma_keep() {   // all DMA 
 // TPB2: two (tap, chunk) steps per workgroup barrier -- the weight ring holds two slots of two tiles and is refilled one PAIR of
 // steps ahead, the fragment registers are reused by the second step; 80 KiB of LDS, still two workgroups per CU.
 // (Reading the halo fragments of step s + 1 under the MFMAs of step s was measured: +-0.5 %, removed.)
-template <typename T, int BN, bool UPS, int TW, bool GNA, bool TPB2>
+// X3 (T = float only): "split-bf16" arithmetic for the 1e-3-compliant decode path.  Activations and weights stay fp32 in HBM;
+// a staged halo slot (4 fp32 channels) is rewritten in place as [hi(4) | lo(4)] bf16 with hi = bf16(x), lo = bf16(x - hi) -- the same
+// 16 bytes -- and the weights arrive pre-split in the same slot layout (packing.py: pack_x3).  One K = 32 bf16 MFMA then multiplies
+// a slot's [a_hi | a_lo] by [w_hi | w_hi], a second one by [w_lo | w_lo]: all four partial products, fp32 accumulate, for 2 x 16
+// MFMA clocks per 16 channels where the f32-input MFMA path needs 4 x 32 -- 2^-17 relative per operand instead of 2^-24 (far inside
+// the 1e-3 bar on pixels; NOT used by tokenize, whose bit-exact ids need the exact fp32 chain).  Same LDS geometry as the fp32 instances.
+template <typename T, int BN, bool UPS, int TW, bool GNA, bool TPB2, bool X3 = false>
 __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
+  static_assert(!X3 || sizeof(T) == 4, "split-bf16 arithmetic reads fp32 tensors");
   constexpr int VEC = Traits<T>::VEC;
   constexpr int CK = 4 * VEC;              // channels per chunk: one 64-byte LDS row per halo pixel (one MFMA K-step)
   constexpr int WN = BN / 2;               // 8 waves = 4 (pixels) x 2 (channels)
@@ -212,6 +219,14 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
   };
   // normalise one piece of a staged halo chunk in place (same lane -> (pixel, slot) map as the DMA)
   auto transform_piece = [&](int chunk, int it, unsigned char* hb) {
+    if constexpr (X3 && !GNA) {   // split only: out-of-image slots hold zeros, whose split is zeros -- no bounds test needed
+      Chunk16* ptr = (Chunk16*)(hb + (size_t)(it * 512 + tid) * 16);
+      const f32x4 x = __builtin_bit_cast(f32x4, *ptr);
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const bf16_t hi = (bf16_t)x[j]; o[j] = hi; o[4 + j] = (bf16_t)(x[j] - (float)hi); }
+      *ptr = __builtin_bit_cast(Chunk16, o);
+    }
     if constexpr (GNA) {
       const int q = it * 512 + tid;
       const int row = q >> 2, slot = q & 3;
@@ -234,7 +249,14 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
           f32x4 o;
 #pragma unroll
           for (int j = 0; j < 4; ++j) o[j] = silu_t<T>(fmaf(x[j], cf[j][0], cf[j][1]));
-          *ptr = __builtin_bit_cast(Chunk16, o);
+          if constexpr (X3) {
+            bf16x8 s8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const bf16_t hi = (bf16_t)o[j]; s8[j] = hi; s8[4 + j] = (bf16_t)(o[j] - (float)hi); }
+            *ptr = __builtin_bit_cast(Chunk16, s8);
+          } else {
+            *ptr = __builtin_bit_cast(Chunk16, o);
+          }
         }
       }
     }
@@ -286,7 +308,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
   (void)load_coef(0);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  if constexpr (GNA) {   // the first chunk is normalised before its first tap; later chunks under the taps of their predecessor
+  if constexpr (GNA || X3) {   // the first chunk is normalised / split before its first tap; later chunks under the taps of their predecessor
     for (int it = 0; it < HI; ++it) transform_piece(0, it, hbuf0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -312,8 +334,8 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
         if (tap < HI) { if (more) { issue_halo_piece(tap, chunk + 1, hb_next); issued += h_any[tap < HI ? tap : 0]; } }
       };
       (void)h_more;
-      if (GNA || early) issue_dma();   // (the fused-GroupNorm instances issue at the top in every wave: one code path less, no spills)
-      if constexpr (GNA) {
+      if (GNA || X3 || early) issue_dma();   // (the instances that transform the staged halo issue at the top in every wave: one code path less, no spills)
+      if constexpr (GNA || X3) {
         if (more) {
           if (tap == 0) issued += load_coef(chunk + 1);
           // piece `it` of the next chunk was requested at tap `it` and has landed by the end of tap `it + 1`: normalise it at
@@ -321,13 +343,29 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
           if (tap >= 4 && tap - 4 < HI) transform_piece(chunk + 1, tap - 4, hb_next);
         }
       }
-      if (!GNA && !early) issue_dma();
+      if (!GNA && !X3 && !early) issue_dma();
       __builtin_amdgcn_sched_barrier(0);   // (as in the two-step loop: bounds the register pressure of the unrolled taps)
       Chunk16 wv[FN];
 #pragma unroll
       for (int b = 0; b < FM; ++b) xa[b] = read_a(PAR, tap, b);
 #pragma unroll
       for (int a = 0; a < FN; ++a) wv[a] = *(const Chunk16*)(wbuf0 + w_base + ((tap % 3) * W_BYTES + a * 1024));
+      if constexpr (X3) {
+        // W fragment outermost: one duplicated half ([w_hi | w_hi], then [w_lo | w_lo]) is live at a time -- built for all FN fragments
+        // up front (the order the compiler prefers) it costs 32 registers the 128-channel instances do not have (13-31 spilled, and
+        // a spill reload drains the DMA queue); an accumulator is revisited after FM MFMAs, beyond the dependent-issue latency
+#pragma unroll
+        for (int a = 0; a < FN; ++a) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            Chunk16 wd = Chunk16{wv[a][2 * h], wv[a][2 * h + 1], wv[a][2 * h], wv[a][2 * h + 1]};
+            asm volatile("" : "+v"(wd));   // (keeps the duplicate from being hoisted out of its four MFMAs)
+#pragma unroll
+            for (int b = 0; b < FM; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wd), __builtin_bit_cast(bf16x8, xa[b]), acc[a][b], 0, 0, 0);
+          }
+        }
+      } else {
 #pragma unroll
       for (int b = 0; b < FM; ++b) {
 #pragma unroll
@@ -341,6 +379,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
             for (int u = 0; u < 4; ++u) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u], xf[u], acc[a][b], 0, 0, 0);
           }
         }
+      }
       }
       // everything issued BEFORE this step has landed once at most `issued` transfers are still in flight
       if (issued == 0) wait_dma_keep<0>();
@@ -356,7 +395,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
       if (chunk + 1 < nchunks) run_chunk(chunk + 1, std::integral_constant<int, 1>{});
     }
   } else {
-    static_assert(!(GNA && TPB2), "the fused input GroupNorm runs on the one-step-per-barrier loop");
+    static_assert(!((GNA || X3) && TPB2), "the instances that transform the staged halo run on the one-step-per-barrier loop");
     // Two chunks = 18 steps = nine PAIRS of steps, unrolled: step s of the group is (chunk cg + s / 9, tap s % 9) and reads halo
     // buffer (s / 9) & 1.  Weight ring: two slots of two tiles; the pair after this one is requested at the top of this pair
     // into the other slot (free since the barrier that ended the previous pair) and has landed at this pair's end -- the
@@ -535,7 +574,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
   }
 }
 
-template <typename T, int BN, bool UPS, int TW, bool GNA, bool TPB2>
+template <typename T, int BN, bool UPS, int TW, bool GNA, bool TPB2, bool X3 = false>
 static int launch_c3(const Conv3Dev& d, int nimg, hipStream_t stream) {
   constexpr int TH = 256 / TW;
   constexpr int HROWS = (UPS ? TH / 2 + 2 : TH + 2) * (UPS ? TW / 2 + 2 : TW + 2);
@@ -556,7 +595,7 @@ static int launch_c3(const Conv3Dev& d, int nimg, hipStream_t stream) {
   // beside HBM- / latency-bound ones instead of a grid that holds every CU until it drains.
   if (sw().conv_cap) smem = std::max(smem, 82 * 1024);
   static DynLdsOnce once;
-  auto kfn = conv3x3_kernel<T, BN, UPS, TW, GNA, TPB2>;
+  auto kfn = conv3x3_kernel<T, BN, UPS, TW, GNA, TPB2, X3>;
   if (hipError_t e = ensure_dyn_lds(once, (const void*)kfn, 160 * 1024); e != hipSuccess) return (int)e;
   const long blocks = (long)nimg * d.tiles_per_img * d.tiles_n;
   hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(512), smem, stream, dd);
@@ -603,6 +642,16 @@ int launch_conv3x3(const IgemmArgs& a, DType dtype, hipStream_t stream) {
   }
 #define IVG_C3_TW(T, BNv, U, G, PR) (TW == 16 ? launch_c3<T, BNv, U, 16, G, PR>(d, a.Nimg, stream) : launch_c3<T, BNv, U, 32, G, PR>(d, a.Nimg, stream))
 #define IVG_C3_BN(T, U, G, PR) (bn == 128 ? IVG_C3_TW(T, 128, U, G, PR) : IVG_C3_TW(T, 64, U, G, PR))
+  if (a.W_x3) {   // split-bf16 arithmetic on fp32 tensors (the launcher swaps in the pre-split weights: same bytes per row)
+    if (dtype != F32) return (int)hipErrorInvalidValue;
+    d.W = a.W_x3;
+#define IVG_C3X_TW(BNv, U, G) (TW == 16 ? launch_c3<float, BNv, U, 16, G, false, true>(d, a.Nimg, stream) : launch_c3<float, BNv, U, 32, G, false, true>(d, a.Nimg, stream))
+#define IVG_C3X_BN(U, G) (bn == 128 ? IVG_C3X_TW(128, U, G) : IVG_C3X_TW(64, U, G))
+    if (gna) return IVG_C3X_BN(false, true);
+    return a.ups ? IVG_C3X_BN(true, false) : IVG_C3X_BN(false, false);
+#undef IVG_C3X_BN
+#undef IVG_C3X_TW
+  }
   if (gna) return dtype == BF16 ? IVG_C3_BN(bf16_t, false, true, false) : IVG_C3_BN(float, false, true, false);
   // (measured per shape, profiles/r02_conv3x3_tpb.txt: +2 ... +3.5 % on the plain convolutions, -0.8 % on the upsampling ones,
   // whose 32-pixel-row instance also spills registers in the two-step form: those keep one step per barrier)

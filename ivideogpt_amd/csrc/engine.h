@@ -26,7 +26,8 @@ struct Arena {
   void reset(size_t m) { off = m; }
 };
 
-struct ConvW { const void* w = nullptr; const float* b = nullptr; int cin = 0, cout = 0, k = 1; };
+struct ConvW { const void* w = nullptr; const float* b = nullptr; int cin = 0, cout = 0, k = 1;
+               const void* w3 = nullptr; /* fp32 3x3 convs of the "x3" decode mode: weights pre-split into bf16 (hi, lo) pairs */ };
 struct NormW { const float* g = nullptr; const float* b = nullptr; };
 struct ResnetW { NormW n1, n2; ConvW c1, c2, sc; bool has_sc = false; int cin = 0, cout = 0; };
 struct AttnW { NormW gn; ConvW q, k, v, o; };
@@ -69,7 +70,8 @@ struct ivg_engine {
   ivg::Arena ws;
   int ctx = 1;  // current context length (set_context_length)
   bool clamp_out = false;   // detokenize writes clamp(frames, 0, 1) (conv_out epilogue) instead of the raw decoder output (ivg_set_output_clamp)
-  ivg::DType enc_dt, dec_dt, llm_dt;
+  ivg::DType enc_dt, dec_dt, llm_dt;   // element types in HBM
+  bool dec_x3 = false, llm_x3 = false;  // IVG_F32X3: fp32 tensors, split-bf16 matrix arithmetic on that path
   // tokenizer
   ivg::TrunkW enc, cenc, dec, cdec;
   ivg::ConvW quant_conv, post_quant_conv, quant_linear, post_quant_linear;

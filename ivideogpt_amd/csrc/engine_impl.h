@@ -18,6 +18,7 @@ struct Run {
   ivg_engine* e;
   hipStream_t st;
   bool planning;  // true: only walk the allocation plan (no launches) to size the workspace
+  bool x3 = false;   // the entry point running now computes its fp32 matrix products in split-bf16 arithmetic (IVG_F32X3 path)
 
   // ---- primitives (tokenizer.cpp)
   int conv(DType dt, const void* X, int N, int H, int W, const ConvW& c, void* Y, int stride, int ups, const void* Rres, int flags,

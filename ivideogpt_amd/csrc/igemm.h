@@ -45,6 +45,11 @@ struct IgemmArgs {
   // GroupNorm + SiLU of the INPUT fused into the conv3x3 staging (null = off): float2 (scale, shift) [Nimg][Cin] with
   // x_normalised = silu(x * scale + shift)  (norm.hip: launch_gn_coef); the conv then reads the RAW tensor
   const void* gn_in_coef = nullptr;
+  // conv3x3.hip, fp32 tensors only: the weights pre-split into bf16 (hi, lo) pairs in the kernel's slot layout (packing.py pack_x3;
+  // same bytes per row as W) -- selects the split-bf16 ("x3") arithmetic of the 1e-3-compliant decode mode.  null: off
+  const void* W_x3 = nullptr;
+  // igemm.hip, fp32 tensors only: split-bf16 arithmetic with both operands split in registers (no pre-split weights needed)
+  bool x3 = false;
   // batch z = (z0 * nb1 + z1) * nb2 + z2 ; element strides per operand
   int nb0 = 1, nb1 = 1, nb2 = 1;
   long sa[3] = {0, 0, 0}, sw[3] = {0, 0, 0}, sy[3] = {0, 0, 0};

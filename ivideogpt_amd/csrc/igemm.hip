@@ -43,8 +43,21 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds_wave
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+// 4 fp32 values -> [bf16 hi(4) | bf16 lo(4)] with hi = bf16(x), lo = bf16(x - hi): the operand format of the split-bf16 ("x3") mode
+__device__ __forceinline__ bf16x8 split_hi_lo(const f32x4 x) {
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const bf16_t hi = (bf16_t)x[j]; o[j] = hi; o[4 + j] = (bf16_t)(x[j] - (float)hi); }
+  return o;
+}
+
+// X3 (T = float only): split-bf16 arithmetic of the 1e-3-compliant decode / rollout mode.  Both operands stay fp32 in HBM and in
+// LDS; a fragment (4 fp32 of K per lane) is split into [hi | lo] bf16 in registers, and two K = 32 bf16 MFMAs -- the activation
+// slot against [w_hi | w_hi], then against [w_lo | w_lo] -- produce all four partial products with fp32 accumulation: 2 x 16 MFMA
+// clocks per 16 elements of K where the f32-input MFMA path needs 4 x 32.  Operand error 2^-17 instead of 2^-24.
+template <typename T, int BM, int BN, int WM, int WN, bool X3 = false>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDev p) {
+  static_assert(!X3 || sizeof(T) == 4, "split-bf16 arithmetic reads fp32 tensors");
   constexpr int VEC = Traits<T>::VEC;
   constexpr int BK = 8 * VEC;  // one 128-byte row
   constexpr int FM = WM / 16, FN = WN / 16;
@@ -139,6 +152,23 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDev p) {
       for (int b = 0; b < FM; ++b) xa[b] = *(const Chunk16*)(sA + lds_off(wm * WM + b * 16 + lr, c));
 #pragma unroll
       for (int a = 0; a < FN; ++a) wb[a] = *(const Chunk16*)(sB + lds_off(wn * WN + a * 16 + lr, c));
+      if constexpr (X3) {
+        bf16x8 xs[FM];
+#pragma unroll
+        for (int b = 0; b < FM; ++b) xs[b] = split_hi_lo(__builtin_bit_cast(f32x4, xa[b]));
+#pragma unroll
+        for (int a = 0; a < FN; ++a) {
+          const Chunk16 ws = __builtin_bit_cast(Chunk16, split_hi_lo(__builtin_bit_cast(f32x4, wb[a])));
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {   // one duplicated half live at a time (registers), an accumulator revisited after FM MFMAs
+            Chunk16 wd = Chunk16{ws[2 * h], ws[2 * h + 1], ws[2 * h], ws[2 * h + 1]};
+            asm volatile("" : "+v"(wd));
+#pragma unroll
+            for (int b = 0; b < FM; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wd), xs[b], acc[a][b], 0, 0, 0);
+          }
+        }
+      } else {
 #pragma unroll
       for (int a = 0; a < FN; ++a)
 #pragma unroll
@@ -152,6 +182,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDev p) {
             for (int s = 0; s < 4; ++s) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[s], xv[s], acc[a][b], 0, 0, 0);
           }
         }
+      }
     }
     __syncthreads();  // (the compiler drains the DMA queue, vmcnt(0), in front of the barrier)
   }
@@ -235,11 +266,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmDev p) {
   }
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, bool X3 = false>
 static int launch_cfg(const IgemmDev& d, int nbatch, hipStream_t stream) {
   constexpr int smem = 2 * (BM + BN) * 128;
   static DynLdsOnce once;
-  auto kfn = igemm_kernel<T, BM, BN, WM, WN>;
+  auto kfn = igemm_kernel<T, BM, BN, WM, WN, X3>;
   if (hipError_t e = ensure_dyn_lds(once, (const void*)kfn, smem); e != hipSuccess) return (int)e;
   const long tiles = (long)cdiv(d.M, BM) * cdiv(d.N, BN);
   dim3 grid((unsigned)tiles, (unsigned)nbatch, 1);
@@ -247,12 +278,12 @@ static int launch_cfg(const IgemmDev& d, int nbatch, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-template <typename T>
+template <typename T, bool X3 = false>
 static int launch_typed(const IgemmDev& d, int nbatch, hipStream_t stream) {
-  if (d.flags & IG_GLU) return launch_cfg<T, 128, 128, 64, 64>(d, nbatch, stream);
-  if (d.N > 64) return launch_cfg<T, 128, 128, 64, 64>(d, nbatch, stream);
-  if (d.N > 16) return launch_cfg<T, 128, 64, 32, 64>(d, nbatch, stream);
-  return launch_cfg<T, 128, 16, 32, 16>(d, nbatch, stream);
+  if (d.flags & IG_GLU) return launch_cfg<T, 128, 128, 64, 64, X3>(d, nbatch, stream);
+  if (d.N > 64) return launch_cfg<T, 128, 128, 64, 64, X3>(d, nbatch, stream);
+  if (d.N > 16) return launch_cfg<T, 128, 64, 32, 64, X3>(d, nbatch, stream);
+  return launch_cfg<T, 128, 16, 32, 16, X3>(d, nbatch, stream);
 }
 
 int launch_igemm(const IgemmArgs& a, DType dtype, hipStream_t stream) {
@@ -274,6 +305,7 @@ int launch_igemm(const IgemmArgs& a, DType dtype, hipStream_t stream) {
   if (a.Cin % (d.single_tap ? vec : bk) != 0 || a.ldx % vec != 0 || a.ldw % vec != 0) return (int)hipErrorInvalidValue;
   if (((uintptr_t)a.X & 15) || ((uintptr_t)a.W & 15)) return (int)hipErrorInvalidValue;
   if ((a.flags & IG_GLU) && (a.N % 32 != 0)) return (int)hipErrorInvalidValue;
+  if (a.x3 && dtype == F32) return launch_typed<float, true>(d, nbatch, stream);   // split-bf16 arithmetic on fp32 tensors
   return dtype == BF16 ? launch_typed<bf16_t>(d, nbatch, stream) : launch_typed<float>(d, nbatch, stream);
 }
 

@@ -50,6 +50,7 @@ int Run::conv(DType dt, const void* X, int N, int H, int W, const ConvW& c, void
   if (planning) return 0;
   if (out_stats && out_stats->part && gn_fuse_enabled()) { a.gn_part = out_stats->part; a.gn_groups = e->cfg.norm_num_groups; }
   a.gn_in_coef = in_coef;
+  if (dt == F32 && x3 && sw().x3) { a.x3 = true; a.W_x3 = c.w3; }   // split-bf16 arithmetic (IVG_F32X3 decode; IVG_X3=0: f32-input MFMAs)
   const double flops = 2.0 * N * Ho * Wo * (double)c.cout * k * k * c.cin;
   const double bytes = (double)esz(dt) * ((double)N * H * W * c.cin + (double)c.cout * k * k * c.cin) + (double)(out_f32 ? 4 : esz(dt)) * N * Ho * Wo * c.cout;
   if (k == 3 && stride == 1) {  // FLOP majority: LDS-halo kernel; shapes it does not cover fall through to the implicit GEMM
@@ -66,9 +67,11 @@ int Run::conv(DType dt, const void* X, int N, int H, int W, const ConvW& c, void
   return 0;
 }
 
-int Run::gemm(DType dt, const IgemmArgs& a, double flops, double bytes) {
+int Run::gemm(DType dt, const IgemmArgs& a0, double flops, double bytes) {
   Run& R = *this;
   if (planning) return 0;
+  IgemmArgs a = a0;
+  a.x3 = dt == F32 && x3 && sw().x3;
   prof_begin(dt, flops, bytes);
   int rc = launch_gemm256(a, dt, st);   // large dense GEMMs (prompt pass); -1 = not covered
   if (rc == -1) rc = launch_igemm(a, dt, st);
@@ -388,6 +391,7 @@ static void encoder_feature_plan(const ivg_config& c, std::vector<Feature>& f) {
 
 int Run::tokenize(const void* pixels, DType pix_dt, int B, int T, int64_t* ids, int64_t ids_stride, int64_t* labels, bool ctx_only) {
   Run& R = *this;
+  x3 = false;   // bit-exact ids: the exact fp32 chain, always
   const ivg_config& c = e->cfg;
   const DType dt = e->enc_dt;
   const int ctx = e->ctx, F = T - ctx, lat = c.latent_channels, dim = c.vq_embed_dim;
@@ -541,6 +545,7 @@ int Run::decoder_trunk(const TrunkW& w, const void* z, int B, int per, int T_tot
 
 int Run::detokenize(const int64_t* ids, int B, int F, float* out_pixels, ivg_cache* cache, int cache_mode) {
   Run& R = *this;
+  x3 = e->dec_x3;
   const ivg_config& c = e->cfg;
   const DType dt = e->dec_dt;
   const int ctx = e->ctx, T = ctx + F, lat = c.latent_channels, dim = c.vq_embed_dim, p = c.patch_size;

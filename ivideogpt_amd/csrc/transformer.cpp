@@ -78,6 +78,7 @@ int Run::prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const voi
                  float* token_nll) {
   const ivg_config& c = e->cfg;
   const DType dt = e->llm_dt;
+  x3 = e->llm_x3;
   const int H = c.hidden_size, I = c.intermediate_size, V = c.vocab_size, heads = e->heads, hd = e->hd, Lmax = e->Lmax;
   const long M = (long)B * L;
   const int Lp = (int)rup(L, 64);

@@ -16,7 +16,22 @@ def torch_dtype(code):
     return _TORCH_DT[code]
 
 
+X3 = "x3"   # arithmetic mode name: fp32 tensors in HBM, split-bf16 (hi + lo) MFMAs with fp32 accumulation (csrc/conv3x3.hip, X3)
+
+
+def is_x3(dt):
+    return isinstance(dt, str) and dt.lower() in ("x3", "fp32x3", "f32x3")
+
+
+def config_code(dt):
+    """ivg_config.{encode,decode,llm}_dtype: like dtype_code, but "x3" is IVG_F32X3 (fp32 tensors, split-bf16 matrix arithmetic)."""
+    return _lib.IVG_F32X3 if is_x3(dt) else dtype_code(dt)
+
+
 def dtype_code(dt):
+    """Element type of the tensors in HBM.  "x3" stores fp32 (only the matrix arithmetic differs)."""
+    if is_x3(dt):
+        return _lib.IVG_F32
     if dt in (torch.float32, "fp32", "float32", "f32", _lib.IVG_F32):
         return _lib.IVG_F32
     if dt in (torch.bfloat16, "bf16", "bfloat16", _lib.IVG_BF16):
@@ -28,8 +43,21 @@ def _conv(w, dt):
     return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dt).contiguous()
 
 
-def pack_tokenizer(sd, cfg, device, enc_code, dec_code):
-    """DF state dict of CompressiveVQModel -> {name: device tensor} for ivg_create."""
+def pack_x3(w):
+    """fp32 [N, K] (K % 4 == 0) -> bfloat16 [N, 2K]: every 4 consecutive K elements become one 16-byte slot [hi(4) | lo(4)] with
+    hi = bf16(w), lo = bf16(w - hi) -- the slot layout the X3 kernels multiply against an activation slot split the same way
+    (hi * hi + hi * lo + lo * hi + lo * lo by two K = 32 bf16 MFMAs).  Same bytes per row as the fp32 matrix."""
+    n, k = w.shape
+    assert k % 4 == 0
+    w = w.float()
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    return torch.stack([hi.view(n, k // 4, 4), lo.view(n, k // 4, 4)], 2).reshape(n, 2 * k).contiguous()
+
+
+def pack_tokenizer(sd, cfg, device, enc_code, dec_code, dec_x3=False):
+    """DF state dict of CompressiveVQModel -> {name: device tensor} for ivg_create.  dec_x3: the 3x3 convolutions of the two
+    decoders also get their weights pre-split for the split-bf16 kernels (``<name>.x3``, beside the fp32 matrix other shapes use)."""
     enc_dt, dec_dt = torch_dtype(enc_code), torch_dtype(dec_code)
     out = {}
     for k, v in sd.items():
@@ -42,6 +70,8 @@ def pack_tokenizer(sd, cfg, device, enc_code, dec_code):
             out[k] = v.contiguous()                       # raw [C0, 3, 3, 3] fp32: direct first-layer kernel
         elif v.dim() == 4:
             out[k] = _conv(v, dt)
+            if dec_x3 and top in ("decoder", "cond_decoder") and v.shape[2] == 3 and v.shape[1] % 16 == 0:
+                out[k + ".x3"] = pack_x3(out[k])
         elif v.dim() == 2:
             out[k] = v.to(dt).contiguous()                # Linear / MHA in_proj / out_proj; quant_linear is already (ph, pw, c)
         else:

@@ -161,3 +161,57 @@ class Turnstile:
         with self._cv:
             self._aborted = True
             self._cv.notify_all()
+
+
+class PhaseGate:
+    """Orders one KIND of phase across the batches in flight on a GPU: at most one lane's convolution phase (context encode, frame
+    decode: MFMA-bound grids of thousands of workgroups) is on the device at a time, while the other lanes' rollouts (14.7 k short
+    HBM- / latency-bound launches) run beside it.  Device-side ordering only: a lane entering a gated phase makes ITS stream wait
+    for the event that closed the previous gated phase (whatever lane ran it), queues its kernels and records the next event -- the
+    host threads never wait for the device, only for each other while one of them queues a phase (a few hundred launches).
+    ``with gate.phase(stream): ...`` around the calls of the phase; ``gate = None`` callers skip it."""
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._last = None
+
+    def phase(self, stream):
+        return _GatedPhase(self, stream)
+
+
+class _GatedPhase:
+    def __init__(self, gate, stream):
+        self.gate, self.stream = gate, stream
+
+    def __enter__(self):
+        self.gate._lock.acquire()
+        if self.gate._last is not None:
+            self.stream.wait_event(self.gate._last)
+        return self
+
+    def __exit__(self, *exc):
+        try:
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+            self.gate._last = ev
+        finally:
+            self.gate._lock.release()
+        return False
+
+
+def cu_masked_stream(device, cu_bits):
+    """A HIP stream whose kernels only run on the compute units whose bits are set in ``cu_bits`` (iterable of CU indices, 256 on an
+    MI355X): ``hipExtStreamCreateWithCUMask`` wrapped as a ``torch.cuda.ExternalStream``.  Used to give the MFMA-bound convolution
+    phases and the HBM- / latency-bound rollouts of several batches in flight DISJOINT parts of the chip (bench.py --cu-split)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    words = [0] * 8
+    for b in cu_bits:
+        words[b >> 5] |= 1 << (b & 31)
+    arr = (C.c_uint32 * 8)(*words)
+    h = C.c_void_p()
+    with torch.cuda.device(device):
+        rc = hip.hipExtStreamCreateWithCUMask(C.byref(h), 8, arr)
+    if rc != 0:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed: {rc}")
+    return torch.cuda.ExternalStream(h.value, device=device)

@@ -4,22 +4,47 @@ Same sequence as ``predict()`` in /root/reference/inference/predict.py:47-73 (to
 context tokens, ``generate`` 17*F - 1 new tokens, ``detokenize``, ``clamp(0, 1)``), minus the work the
 reference does and then throws away (it cond-encodes every future frame only to drop those tokens, :53-54).
 """
+import contextlib
+
 import torch
 
 
 @torch.no_grad()
 def predict_frames(tokenizer, model, pixel_values, context_length, future_length, actions=None, do_sample=True, top_k=100,
-                   generator=None, uniforms=None, return_tokens=False):
-    """pixel_values (B, >=ctx, 3, H, W) on the GPU (fp32 or bf16, [0,1]).  -> float32 (B, ctx+F, 3, H, W) in [0,1]."""
-    prompt = tokenizer.encode_context(pixel_values, context_length)
+                   generator=None, uniforms=None, return_tokens=False, temperature=1.0, conv_gate=None, metrics_of=None, rollout_stream=None):
+    """pixel_values (B, >=ctx, 3, H, W) on the GPU (fp32 or bf16, [0,1]).  -> float32 (B, ctx+F, 3, H, W) in [0,1].
+    ``conv_gate`` (parallel.PhaseGate, several batches in flight on one GPU): the two convolution phases -- context encode, frame
+    decode -- are ordered against the other lanes' convolution phases; the rollout between them is not.  ``metrics_of`` (ground-truth
+    clip): the per-trajectory metric rows of the predicted frames are computed inside the decode phase and returned beside the frames.
+    ``rollout_stream``: the rollout runs on this stream (ordered after the encode and before the decode of the current stream) -- e.g. a
+    CU-masked stream, so that rollouts and convolution phases of different lanes own disjoint compute units."""
+    stream = torch.cuda.current_stream(pixel_values.device)
+    gated = (lambda: conv_gate.phase(stream)) if conv_gate is not None else contextlib.nullcontext
+    with gated():
+        prompt = tokenizer.encode_context(pixel_values, context_length)
     n_new = 17 * future_length - 1
+    kw = {} if temperature == 1.0 else {"temperature": temperature}
     if actions is not None:
-        tokens = model.generate(prompt, do_sample=do_sample, top_k=top_k, max_new_tokens=n_new, action=actions, generator=generator,
-                                uniforms=uniforms)
+        kw["action"] = actions
+    if do_sample and uniforms is None:   # drawn on the caller's stream (the generator's state is not tied to a stream)
+        uniforms = torch.rand(prompt.shape[0], n_new, device=prompt.device, dtype=torch.float32, generator=generator)
+    if rollout_stream is not None:
+        rollout_stream.wait_stream(stream)
+        with torch.cuda.stream(rollout_stream):
+            tokens = model.generate(prompt, do_sample=do_sample, top_k=top_k, max_new_tokens=n_new, uniforms=uniforms, **kw)
+        stream.wait_stream(rollout_stream)
+        for t in (prompt, uniforms, tokens):
+            if t is not None:
+                t.record_stream(rollout_stream)
     else:
-        tokens = model.generate(prompt, do_sample=do_sample, top_k=top_k, max_new_tokens=n_new, generator=generator, uniforms=uniforms)
-    frames = tokenizer.detokenize(tokens, context_length, clamp=True)   # clamp(0, 1) in the epilogue of the decoders' last convolution
-    return (frames, tokens) if return_tokens else frames
+        tokens = model.generate(prompt, do_sample=do_sample, top_k=top_k, max_new_tokens=n_new, uniforms=uniforms, **kw)
+    with gated():
+        frames = tokenizer.detokenize(tokens, context_length, clamp=True)   # clamp(0, 1) in the epilogue of the decoders' last convolution
+        rows = frame_metrics(frames, metrics_of, first_frame=context_length) if metrics_of is not None else None
+    out = (frames, tokens) if return_tokens else (frames,)
+    if metrics_of is not None:
+        out = out + (rows,)
+    return out if len(out) > 1 else out[0]
 
 
 @torch.no_grad()

@@ -62,9 +62,10 @@ class CompressiveVQModel:
         return (self._sd_version, str(self.device), self.encode_dtype, self.decode_dtype, self._pretrained_context)
 
     def _packed_weights(self, cfg):
-        from .packing import dtype_code
+        from .packing import dtype_code, is_x3
         if self._packed is None or self._packed_key != self._pack_key():
-            self._packed = pack_tokenizer(self._sd, cfg, self.device, dtype_code(self.encode_dtype), dtype_code(self.decode_dtype))
+            self._packed = pack_tokenizer(self._sd, cfg, self.device, dtype_code(self.encode_dtype), dtype_code(self.decode_dtype),
+                                          dec_x3=is_x3(self.decode_dtype))
             self._packed_key = self._pack_key()
         return self._packed
 

@@ -514,7 +514,7 @@ def test_gemm256_large_dense(mode, line, switches):
     e_big = rel_err(Y.float(), ref)
     assert e_big < TOL[dt], f"{mode}: rel err {e_big:.3e}"
     if mode == "plain":                      # the generic kernel on the same operands: same tolerance class
-        monkeypatch.setenv("IVG_GEMM256", "0")
+        switches(IVG_GEMM256="0")
         Y2 = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
         igemm(dt, Xd, Wd, Y2, **kw)
         assert rel_err(Y2.float(), ref) < TOL[dt] and (Y2.float() - Y.float()).abs().max().item() <= 2 * TOL[dt] * ref.abs().max().item()
@@ -673,6 +673,59 @@ def test_conv3x3_with_fused_input_groupnorm(dt, H, Cin, Cout, res):
     torch.cuda.synchronize()
     assert torch.isfinite(Y.float()).all()
     assert rel_err(Y.float().permute(0, 3, 1, 2), ref) < (5e-5 if dt == "fp32" else TOL[dt])
+
+
+@pytest.mark.parametrize("gn", [0, 1])
+@pytest.mark.parametrize("H,Cin,Cout,ups,res", [(64, 128, 128, 0, 1), (32, 256, 512, 0, 0), (16, 512, 512, 1, 0), (32, 128, 64, 1, 1),
+                                                 (16, 64, 192, 0, 1), (16, 48, 128, 0, 0), (32, 16, 64, 0, 1), (64, 32, 128, 1, 1)])
+def test_conv3x3_x3_split_bf16(H, Cin, Cout, ups, res, gn):
+    """The split-bf16 ("x3") 3x3 convolution of the 1e-3-compliant decode mode: fp32 tensors in HBM, activations split into bf16
+    (hi, lo) pairs inside the halo staging, weights pre-split by packing.pack_x3, two K = 32 bf16 MFMAs per 16 channels, fp32
+    accumulate -- against fp64 torch conv2d on the SAME fp32 inputs.  Error bar 2e-5 relative (each operand carries 2^-17; the
+    f32-input MFMA path is held to 1e-5 by test_conv3x3_halo_kernel) -- 50x inside the 1e-3 bar on pixels.  Both tile shapes, odd
+    chunk counts, one-chunk Cin, ragged N, upsampling, residual, and (gn) GroupNorm + SiLU applied inside the staging before the split."""
+    from ivideogpt_amd.packing import pack_x3
+    if gn and ups:
+        pytest.skip("the upsampling convolutions take un-normalised inputs")
+    L, l = lib()
+    g = torch.Generator().manual_seed(H + Cin + Cout + 17 * gn)
+    Nb, groups = 3, 16 if Cin % 32 else 32
+    x = torch.randn(Nb, Cin, H, H, generator=g) * 1.5 + 0.3
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(Cin, generator=g), 0.2 * torch.randn(Cin, generator=g)
+    Ho = 2 * H if ups else H
+    xin = x.double()
+    if gn:
+        xin = F.silu(F.group_norm(xin, groups, gamma.double(), beta.double(), eps=1e-6))
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xin, w.double(), b.double(), padding=1)
+    r = torch.randn(Nb, Cout, Ho, Ho, generator=g) if res else None
+    if res:
+        ref = ref + r.double()
+    X = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    Wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(DEV)
+    W3 = pack_x3(Wp)
+    assert W3.dtype == torch.bfloat16 and W3.shape == (Cout, 18 * Cin)
+    Y = torch.full((Nb, Ho, Ho, Cout), float("nan"), device=DEV)
+    if res:
+        Y.copy_(r.permute(0, 2, 3, 1))
+    bd, gd, btd = b.to(DEV), gamma.to(DEV), beta.to(DEV)
+    a = L.IvgIgemmArgs()
+    a.X, a.W, a.Y, a.R, a.bias = X.data_ptr(), Wp.data_ptr(), Y.data_ptr(), (Y.data_ptr() if res else None), bd.data_ptr()
+    for k, v in dict(Nimg=Nb, Hin=H, Win=H, Cin=Cin, ldx=Cin, Hout=Ho, Wout=Ho, KH=3, KW=3, stride=1, pad=1, ups=ups, N=Cout, ldw=9 * Cin,
+                     c_img=Ho * Ho * Cout, c_pix=Cout, c_ch=1, c_grp=1, c_grp_stride=0, flags=1 | (4 if res else 0), alpha=1.0, nb0=1, nb1=1,
+                     nb2=1).items():
+        setattr(a, k, v)
+    ws = torch.empty(Nb * (((H * H + 1023) // 1024) * groups * 16 + Cin * 8) + 256, dtype=torch.uint8, device=DEV)
+    rc = l.ivg_op_conv_x3(C.byref(a), P(W3), groups, P(gd) if gn else None, P(btd) if gn else None, 1e-6, P(ws), stream())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    assert torch.isfinite(Y).all()
+    e = rel_err(Y.permute(0, 3, 1, 2), ref)
+    assert e < 2e-5, f"rel err {e:.3e}"
+    assert e > 1e-8 or Cin <= 16, "suspiciously exact: is this the f32-input MFMA path?"
 
 
 @pytest.mark.parametrize("C_,nh,P_,ctx,B,Fr", [(512, 4, 256, 2, 2, 3), (768, 4, 256, 2, 1, 2), (512, 4, 1024, 1, 1, 2), (256, 4, 64, 2, 2, 1),

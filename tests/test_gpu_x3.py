@@ -1,0 +1,115 @@
+"""The 1e-3-compliant arithmetic that is not fp32-rate ("x3": IVG_F32X3, include/ivg.h): fp32 tensors in HBM, every matrix product on
+the bf16 MFMA path with both operands split into bf16 hi + lo (conv3x3.hip / igemm.hip X3 instances), fp32 accumulation.  Held to the
+SAME bars as the fp32 engine mode -- decoded pixels and logits within 1e-3 of the reference's vectors and of the oracle at full width,
+greedy rollouts token-identical -- and shown to really be another arithmetic than the f32-input MFMA path (IVG_X3=0 switches it off)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import llama_fixture, oracle_llama, oracle_tokenizer, tokenizer_fixture
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+RECORD = {}
+
+
+def make_tok(cfg, sd, ctx, dec):
+    from ivideogpt_amd import CompressiveVQModel
+    m = CompressiveVQModel(cfg, sd, encode_dtype="fp32", decode_dtype=dec).to(DEV)
+    if ctx != cfg["context_length"]:
+        m.set_context_length(ctx)
+    return m
+
+
+def make_llm(cfg, sd, dtype):
+    from ivideogpt_amd import LlamaForCausalLM
+    return LlamaForCausalLM(cfg, sd, dtype=dtype).to(DEV)
+
+
+@pytest.mark.parametrize("name", ["tok_mini64_ctx2.npz", "tok_mini64_ctx1.npz", "tok_mini256_ctx2.npz"])
+def test_x3_detokenize_within_1e3_of_reference_vectors(name):
+    """Pixels the REFERENCE CompressiveVQModel.detokenize produced (tests/golden): x3 decode within 1e-3, tokenize untouched (the
+    encoder never runs in x3: ids stay bit-exact)."""
+    cfg, sd, ctx, px, g = tokenizer_fixture(name)
+    m = make_tok(cfg, sd, ctx, "x3")
+    ids, _ = m.tokenize(px.to(DEV), ctx)
+    assert np.array_equal(ids.cpu().numpy(), g["indices"]), "tokenize must not be affected by the decode arithmetic"
+    s = int(g["subsample"])
+    for key_i, key_o in (("indices", "recon"), ("indices_perturbed", "recon_perturbed")):
+        rec = m.detokenize(torch.from_numpy(g[key_i]).to(DEV), ctx).cpu().numpy()[..., ::s, ::s]
+        err = np.abs(rec - g[key_o]).max()
+        assert err < 1e-3, f"{name} {key_o}: x3 decoded pixels max abs err {err:.2e} vs reference"
+    m32 = make_tok(cfg, sd, ctx, "fp32")
+    a = m.detokenize(torch.from_numpy(g["indices"]).to(DEV), ctx)
+    b = m32.detokenize(torch.from_numpy(g["indices"]).to(DEV), ctx)
+    d = (a - b).abs().max().item()
+    assert 0 < d < 1e-3, f"x3 vs fp32 engine decode: max abs difference {d:.2e} (0 would mean the x3 kernels did not run)"
+
+
+@pytest.mark.parametrize("res", [64, 256])
+def test_x3_full_width_decode_vs_oracle(res):
+    """ctx_vae64 (114 M) / ctx_vae256 (310 M) decoders at full width: x3 pixels within 1e-3 of the CPU oracle's fp32 decode; the
+    deviation is recorded next to the fp32 engine mode's."""
+    from ivideogpt_amd import weights as W
+    cfg = W.tokenizer_config(**(W.CTX_VAE64 if res == 64 else W.CTX_VAE256))
+    sd = W.random_tokenizer_state_dict(cfg, 31 if res == 64 else 33, codebook_std=0.4)
+    T = 4 if res == 64 else 3
+    px = torch.randint(0, 256, (1, T, 3, res, res), generator=torch.Generator().manual_seed(2)).float() / 255
+    ora = oracle_tokenizer(cfg, sd, 2)
+    m = make_tok(cfg, sd, 2, "x3")
+    ids, _ = m.tokenize(px.to(DEV), 2)
+    ref = ora.detokenize(ids.cpu(), 2)
+    e3 = (m.detokenize(ids, 2).cpu() - ref).abs()
+    e32 = (make_tok(cfg, sd, 2, "fp32").detokenize(ids, 2).cpu() - ref).abs()
+    msg = f"{res}x{res} full-width decode vs fp32 oracle: x3 max {e3.max():.2e} mean {e3.mean():.2e}; fp32 engine max {e32.max():.2e} mean {e32.mean():.2e}"
+    print(msg)
+    RECORD[f"decode_{res}"] = msg
+    assert e3.max().item() < 1e-3, msg
+
+
+@pytest.mark.parametrize("name", ["llama_tiny_ctx2_free.npz", "llama_tiny_ctx1_free.npz"])
+def test_x3_llama_logits_and_greedy_rollout_vs_hf_vectors(name):
+    cfg, sd, g = llama_fixture(name)
+    m = make_llm(cfg, sd, "x3")
+    lg = m.logits(torch.from_numpy(g["teacher_ids"]).to(DEV)).cpu().numpy()
+    e = max(np.abs(lg[:, -2:] - g["teacher_logits_last"]).max(), np.abs(lg[:, ::37, ::101] - g["teacher_logits_sub"]).max())
+    assert e < 1e-3, f"x3 teacher-forced logits: max abs err {e:.2e} vs HF"
+    prompt = torch.from_numpy(g["prompt"]).to(DEV)
+    out = m.generate(prompt, do_sample=False, max_new_tokens=g["greedy"].shape[1] - prompt.shape[1]).cpu().numpy()
+    assert np.array_equal(out, g["greedy"]), f"{(out != g['greedy']).sum()} greedy tokens differ from HF generate"
+
+
+def test_x3_full_width_llama_logits_vs_oracle():
+    """12 layers / 768 wide (138 M): teacher-forced logits of the x3 prompt pass within 1e-3 of the fp32 oracle, beside the fp32 engine."""
+    from ivideogpt_amd import weights as W
+    cfg = dict(W.LLAMA_SMALL)
+    sd = W.random_llama_state_dict(cfg, 41)
+    ids = torch.randint(0, 16386, (2, 300), generator=torch.Generator().manual_seed(3))
+    ref = oracle_llama(cfg, sd).logits(ids)
+    e3 = (make_llm(cfg, sd, "x3").logits(ids.to(DEV)).cpu() - ref).abs()
+    e32 = (make_llm(cfg, sd, "fp32").logits(ids.to(DEV)).cpu() - ref).abs()
+    msg = (f"12-layer logits vs fp32 oracle (scale {ref.abs().max():.1f}): x3 max {e3.max():.2e} mean {e3.mean():.2e}; "
+           f"fp32 engine max {e32.max():.2e} mean {e32.mean():.2e}")
+    print(msg)
+    RECORD["logits_small"] = msg
+    assert e3.max().item() < 1e-3, msg
+    assert e3.max().item() > 0.0
+
+
+def test_x3_switch_off_is_the_fp32_path(switches):
+    """IVG_X3=0: an engine created in x3 mode runs the f32-input MFMA kernels -- bit-identical to the fp32 mode."""
+    cfg, sd, ctx, px, g = tokenizer_fixture("tok_mini64_ctx2.npz")
+    ids = torch.from_numpy(g["indices"]).to(DEV)
+    ref = make_tok(cfg, sd, ctx, "fp32").detokenize(ids, ctx)
+    switches(IVG_X3="0")
+    off = make_tok(cfg, sd, ctx, "x3").detokenize(ids, ctx)
+    assert torch.equal(off, ref)
+
+
+def test_zz_record_x3_margins():
+    import json
+    import os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "r04_x3_margins.json"), "w") as f:
+        json.dump(RECORD, f, indent=1)
