@@ -123,6 +123,12 @@ int ivg_encode_context(ivg_engine* e, const void* pixels, int pixel_dtype, int B
  * (cache=...): context frames are then not decoded again (their pixels are copied from the cache). */
 int ivg_detokenize(ivg_engine* e, const int64_t* ids, int B, int F, float* pixels_out, ivg_cache* cache, int cache_mode,
                    ivg_stream stream);
+/* The same with the element type of the result chosen by the caller: pixel_dtype IVG_F32, or IVG_BF16 when the engine decodes in
+ * bfloat16 (decode_dtype = IVG_BF16) -- what the reference's callers get under torch.autocast(bfloat16)
+ * (vp/ivideogpt_interface.py:180, mbrl/video_predictor.py:269): half the bytes of the clip, written by the last convolution's
+ * epilogue.  A cache remembers the element type it was filled with; reuse with another one is IVG_ERR_INVALID. */
+int ivg_detokenize_to(ivg_engine* e, const int64_t* ids, int B, int F, void* pixels_out, int pixel_dtype, ivg_cache* cache, int cache_mode,
+                      ivg_stream stream);
 /* on != 0: ivg_detokenize writes clamp(frames, 0, 1) -- the post-processing every caller of the reference applies to the decoded
  * clip (inference/predict.py:73, vp/ivideogpt_interface.py:199, train_gpt.py:438) -- from the epilogue of the decoders' last
  * convolution instead of a separate pass over the clip.  Default off: CompressiveVQModel.detokenize returns the raw output. */

@@ -239,7 +239,7 @@ static int plan_and_allocate(ivg_engine* e) {
       e->ctx = ctx;
       if (T > ctx) {
         int rc = r.tokenize(nullptr, F32, B, T, nullptr, 257 * ctx - 1 + 17 * (T - ctx), nullptr, false); if (rc) return rc;
-        rc = r.detokenize(nullptr, B, T - ctx, nullptr, nullptr, 0); if (rc) return rc;
+        rc = r.detokenize(nullptr, B, T - ctx, nullptr, F32, nullptr, 0); if (rc) return rc;
       }
     }
     e->ctx = saved;
@@ -388,11 +388,17 @@ int ivg_set_output_clamp(ivg_engine* e, int on) {
   return IVG_OK;
 }
 
-int ivg_detokenize(ivg_engine* e, const int64_t* ids, int B, int F, float* pixels_out, ivg_cache* cache, int cache_mode, ivg_stream stream) {
+int ivg_detokenize_to(ivg_engine* e, const int64_t* ids, int B, int F, void* pixels_out, int pixel_dtype, ivg_cache* cache, int cache_mode,
+                      ivg_stream stream) {
   if (!e) return IVG_ERR_INVALID;
   IVG_TRY(check_tok(e, B, e->ctx + F, "detokenize"));
   if (F < 0) return e->fail(IVG_ERR_INVALID, "detokenize: token count does not match 257*ctx - 1 + 17*F");
-  return plan_then_run(e, (hipStream_t)stream, [&](Run& r) { return r.detokenize(ids, B, F, pixels_out, cache, cache ? cache_mode : 0); });
+  if (pixel_dtype != IVG_F32 && pixel_dtype != IVG_BF16) return e->fail(IVG_ERR_INVALID, "detokenize: pixels are float32 or bfloat16");
+  return plan_then_run(e, (hipStream_t)stream, [&](Run& r) { return r.detokenize(ids, B, F, pixels_out, (DType)pixel_dtype, cache, cache ? cache_mode : 0); });
+}
+
+int ivg_detokenize(ivg_engine* e, const int64_t* ids, int B, int F, float* pixels_out, ivg_cache* cache, int cache_mode, ivg_stream stream) {
+  return ivg_detokenize_to(e, ids, B, F, pixels_out, IVG_F32, cache, cache_mode, stream);
 }
 
 int ivg_cache_create(ivg_engine* e, int B, ivg_cache** out) {

@@ -43,6 +43,8 @@ struct Dg3Dev {
   unsigned wave_bytes;      // LDS bytes per wave (ring * line bytes)
   int flags;
   int w_nt;                  // weights by non-temporal requests (streamed once per step) or default-policy ones
+  int x3;                    // fp32 tensors only: split-bf16 arithmetic (both fragments split into bf16 hi | lo in registers, two K = 32
+                             // bf16 MFMAs per fragment pair instead of four f32-input ones: IVG_F32X3 rollout mode)
   float inv_k, eps;
   int* bump;
   unsigned long long* prof; const int* pos; int prof_ld;
@@ -57,6 +59,12 @@ __device__ __forceinline__ void dg3_dma16(const void* sbase, unsigned voff, unsi
 __device__ __forceinline__ void dg3_dma16_nt(const void* sbase, unsigned voff, unsigned lds_wave_base) {   // nt: streamed-once weights
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(lds_wave_base), "v"(voff), "s"(sbase) : "memory");
 }
+__device__ __forceinline__ bf16x8 dg3_split_hi_lo(const f32x4 x) {   // 4 fp32 -> [bf16 hi(4) | bf16 lo(4)], lo = bf16(x - hi)
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const bf16_t hi = (bf16_t)x[j]; o[j] = hi; o[4 + j] = (bf16_t)(x[j] - (float)hi); }
+  return o;
+}
 __device__ __forceinline__ unsigned dg3_lds_addr(const void* p) { return (unsigned)(unsigned long)(__attribute__((address_space(3))) const void*)p; }
 
 template <typename T> struct Vec4T3;
@@ -68,8 +76,11 @@ template <> struct Vec4T3<float> { typedef f32x4 type; };
 // a GEMM come out at ~256 workgroups: every CU takes part and ingests fewer weight rows next to its activation rows (196 -> 172
 // KB per CU for down).  Rows beyond wr are neither requested (lanes masked off) nor stored; wr > 16 FN - 8, so every half tile
 // still has a valid row and the request count per line is a compile-time constant.
-template <typename T, int MF, int FN, int WAVES>
+// X3 (T = float only, p.x3): split-bf16 arithmetic -- a template parameter, not a run-time branch: with both paths in one kernel the
+// f32-input instances with four row tiles grew from 124-150 to 168-184 registers and spilled.
+template <typename T, int MF, int FN, int WAVES, bool X3 = false>
 __global__ __launch_bounds__(WAVES * 64) void dg3_kernel(const Dg3Dev p) {
+  static_assert(!X3 || sizeof(T) == 4, "split-bf16 arithmetic reads fp32 tensors");
   constexpr int PER = 2 * (MF + FN);             // LDS-DMA requests per line (two 8-row halves per 16-row tile)
   constexpr int NFRAG = FN * MF;
   constexpr int LINE = (MF + FN) * 2048;         // staged bytes of one 128-byte line of K: [MF activation tiles | FN weight tiles] x 2 KiB
@@ -206,6 +217,28 @@ __global__ __launch_bounds__(WAVES * 64) void dg3_kernel(const Dg3Dev p) {
           }
         }
     }
+    if constexpr (X3) {
+      {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          bf16x8 xs[MF];
+#pragma unroll
+          for (int b = 0; b < MF; ++b) xs[b] = dg3_split_hi_lo(__builtin_bit_cast(f32x4, xa[tt][b]));
+#pragma unroll
+          for (int a = 0; a < FN; ++a) {
+            const Chunk16 ws = __builtin_bit_cast(Chunk16, dg3_split_hi_lo(__builtin_bit_cast(f32x4, wa[tt][a])));
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              Chunk16 wd = Chunk16{ws[2 * h], ws[2 * h + 1], ws[2 * h], ws[2 * h + 1]};   // [w_hi | w_hi], then [w_lo | w_lo]
+              asm volatile("" : "+v"(wd));
+#pragma unroll
+              for (int b = 0; b < MF; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wd), xs[b], acc[a][b], 0, 0, 0);
+            }
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -221,6 +254,7 @@ __global__ __launch_bounds__(WAVES * 64) void dg3_kernel(const Dg3Dev p) {
             for (int u = 0; u < 4; ++u) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[u], xf[u], acc[a][b], 0, 0, 0);
           }
         }
+    }
   }
   stamp(4);   // (the last line's wait was vmcnt(0): the residual rows are here as well)
 
@@ -348,12 +382,15 @@ __global__ __launch_bounds__(WAVES * 64) void dg3_kernel(const Dg3Dev p) {
   if (p.bump && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { p.bump[0] += 1; p.bump[1] += 1; }
 }
 
-template <typename T, int MF, int FN, int WAVES>
+template <typename T, int MF, int FN, int WAVES, bool X3 = false>
 static int launch_dg3(const Dg3Dev& d, hipStream_t stream) {
+  if constexpr (sizeof(T) == 4 && !X3) {
+    if (d.x3) return launch_dg3<T, MF, FN, WAVES, true>(d, stream);
+  }
   const int smem = (int)d.wave_bytes * WAVES;
   if (smem > 160 * 1024) return -1;
   static DynLdsOnce once;
-  auto kfn = dg3_kernel<T, MF, FN, WAVES>;
+  auto kfn = dg3_kernel<T, MF, FN, WAVES, X3>;
   if (hipError_t e = ensure_dyn_lds(once, (const void*)kfn, 160 * 1024); e != hipSuccess) return (int)e;
   dim3 grid((unsigned)cdiv(d.N, d.wr), (unsigned)cdiv(d.M, 16 * MF), 1);
   hipLaunchKernelGGL(kfn, grid, dim3(WAVES * 64), smem, stream, d);
@@ -467,6 +504,7 @@ int launch_dgemm3(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
   d.wr = pl.wr; d.klw = pl.klw; d.ring = pl.ring; d.wave_bytes = pl.wave_bytes; d.flags = a.flags;
   d.inv_k = 1.0f / (float)a.K; d.eps = a.eps; d.bump = a.bump;
   d.w_nt = 1;
+  d.x3 = (a.x3 && dtype == F32) ? 1 : 0;
   d.prof = a.pos ? a.prof : nullptr; d.pos = a.pos; d.prof_ld = a.prof_ld;
   d.dbg = a.dbg;
   if (a.next_W && a.next_tile_bytes >= 1024 && a.next_tiles > 0 && sw().dg3_warm) {   // IVG_DG3_WARM=0: no warm-up of the next launch's weights

@@ -56,7 +56,8 @@ struct ProfClass { bool enabled = false; std::vector<ProfSlot> used; std::vector
 
 struct ivg_cache {
   int B = 0;
-  float* ctx_pixels = nullptr;             // [B][ctx][3][H][W]
+  float* ctx_pixels = nullptr;             // [B][ctx][3][H][W] (sized for float32; holds pix_dt elements)
+  int pix_dt = 0;                           // element type of the kept context pixels (the output type of the call that filled the cache)
   std::vector<void*> feat;                  // un-repeated per-trajectory context decoder features (NHWC)
   bool filled = false;
   bool clamped = false;                     // the kept context pixels were written with the output clamp on (ivg_set_output_clamp at fill time)

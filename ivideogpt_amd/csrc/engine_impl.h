@@ -41,9 +41,9 @@ struct Run {
   int encoder_trunk(const TrunkW& w, const void* pixels, DType pix_dt, int B, int per, int T_total, int t0,
                     std::vector<Feature>* keep, const std::vector<Feature>* cond, void* latent);
   int decoder_trunk(const TrunkW& w, const void* z, int B, int per, int T_total, int t0, std::vector<Feature>* keep,
-                    const std::vector<Feature>* cond, float* out_pixels);
+                    const std::vector<Feature>* cond, void* out_pixels, DType out_dt);
   int tokenize(const void* pixels, DType pix_dt, int B, int T, int64_t* ids, int64_t ids_stride, int64_t* labels, bool ctx_only);
-  int detokenize(const int64_t* ids, int B, int F, float* out_pixels, ivg_cache* cache, int cache_mode);
+  int detokenize(const int64_t* ids, int B, int F, void* out_pixels, DType out_dt, ivg_cache* cache, int cache_mode);
 
   // ---- transformer (transformer.cpp)
   int prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const void* act_emb, int act_T, int ctx, bool all_slots,

@@ -447,7 +447,7 @@ static void decoder_feature_plan(const ivg_config& c, std::vector<Feature>& f) {
 
 // z [N,16,16,latent] -> pixels written (fp32, planar) into out_pixels frames (b, t0 + n % per)
 int Run::decoder_trunk(const TrunkW& w, const void* z, int B, int per, int T_total, int t0, std::vector<Feature>* keep,
-                       const std::vector<Feature>* cond, float* out_pixels) {
+                       const std::vector<Feature>* cond, void* out_pixels, DType out_dt) {
   Run& R = *this;
   const DType dt = e->dec_dt;
   const ivg_config& c = e->cfg;
@@ -528,24 +528,28 @@ int Run::decoder_trunk(const TrunkW& w, const void* z, int B, int per, int T_tot
   }
   const int C0 = c.block_out_channels[0];
   IVG_TRY(gnorm(dt, a, b, N, side * side, C0, w.norm_out, 1e-6f, 1, nullptr, &sa));
-  {  // conv_out straight into the planar (B, T, 3, H, W) float32 clip
+  {  // conv_out straight into the planar (B, T, 3, H, W) clip: float32, or the decode path's own bfloat16 (ivg_detokenize_to)
+    const bool out32 = out_dt == F32;
     IgemmArgs g;
-    g.X = b; g.W = w.conv_out.w; g.Y = out_pixels + (long)t0 * 3 * res * res; g.bias = w.conv_out.b;
+    g.X = b; g.W = w.conv_out.w; g.Y = (char*)out_pixels + (size_t)t0 * 3 * res * res * (out32 ? 4 : 2); g.bias = w.conv_out.b;
     g.Nimg = N; g.Hin = side; g.Win = side; g.Cin = C0; g.ldx = C0; g.Hout = side; g.Wout = side;
     g.KH = 3; g.KW = 3; g.stride = 1; g.pad = 1;
     g.N = 3; g.ldw = 9 * C0;
     g.c_img = 3L * res * res; g.c_pix = 1; g.c_ch = (long)res * res;
     g.c_grp = per; g.c_grp_stride = (long)T_total * 3 * res * res;
-    g.flags = IG_BIAS_N | IG_OUT_F32 | (e->clamp_out ? IG_CLAMP01 : 0);   // clamp(0, 1) of predict.py:73 in the epilogue
-    IVG_TRY(gemm(dt, g, 2.0 * N * side * side * 27.0 * C0, (double)esz(dt) * N * side * side * C0 + 4.0 * N * 3 * side * side));
+    g.flags = IG_BIAS_N | (out32 ? IG_OUT_F32 : 0) | (e->clamp_out ? IG_CLAMP01 : 0);   // clamp(0, 1) of predict.py:73 in the epilogue
+    IVG_TRY(gemm(dt, g, 2.0 * N * side * side * 27.0 * C0, (double)esz(dt) * N * side * side * C0 + (out32 ? 4.0 : 2.0) * N * 3 * side * side));
   }
   e->ws.reset(m);
   return 0;
 }
 
-int Run::detokenize(const int64_t* ids, int B, int F, float* out_pixels, ivg_cache* cache, int cache_mode) {
+int Run::detokenize(const int64_t* ids, int B, int F, void* out_pixels, DType out_dt, ivg_cache* cache, int cache_mode) {
   Run& R = *this;
   x3 = e->dec_x3;
+  if (out_dt != F32 && out_dt != e->dec_dt)
+    return e->fail(IVG_ERR_INVALID, "detokenize: bfloat16 pixels are written by the bfloat16 decode path only (decode_dtype = IVG_BF16)");
+  const size_t psz = out_dt == F32 ? 4 : 2;
   const ivg_config& c = e->cfg;
   const DType dt = e->dec_dt;
   const int ctx = e->ctx, T = ctx + F, lat = c.latent_channels, dim = c.vq_embed_dim, p = c.patch_size;
@@ -558,6 +562,8 @@ int Run::detokenize(const int64_t* ids, int B, int F, float* out_pixels, ivg_cac
   if (use_cache && (!cache->filled || cache->B != B)) return e->fail(IVG_ERR_INVALID, "detokenize: cache is empty or was made for another batch size");
   // the kept context frames are pixels as they were written at fill time: reusing them under the other clamp mode would hand back
   // clamped context frames beside raw predicted ones (or the reverse) -- refuse instead of mixing
+  if (use_cache && cache->pix_dt != (int)out_dt)
+    return e->fail(IVG_ERR_INVALID, "detokenize: cache holds context pixels of another element type than this call writes (fill it again)");
   if (use_cache && cache->clamped != e->clamp_out)
     return e->fail(IVG_ERR_INVALID, std::string("detokenize: cache was filled with clamp ") + (cache->clamped ? "on" : "off") +
                                         ", this call runs with clamp " + (e->clamp_out ? "on" : "off") + " (fill it again in this mode)");
@@ -588,17 +594,18 @@ int Run::detokenize(const int64_t* ids, int B, int F, float* out_pixels, ivg_cac
       CK(launch_gather_rows(ids, mp, e->cb_c, qc, dt, N * 256, dim, 0, c.num_vq_embeddings, st));
     }
     IVG_TRY(conv(dt, qc, N, 16, 16, e->post_quant_conv, q2, 1, 0, nullptr, 0, 0));
-    IVG_TRY(decoder_trunk(e->dec, q2, B, ctx, T, 0, &feats, nullptr, out_pixels));
+    IVG_TRY(decoder_trunk(e->dec, q2, B, ctx, T, 0, &feats, nullptr, out_pixels, out_dt));
     if (cache && cache_mode == 1 && !planning) {
       // keep the decoded context frames: rows (b, t < ctx) of out_pixels
-      CK((int)hipMemcpy2DAsync(cache->ctx_pixels, (size_t)ctx * 3 * res * res * 4, out_pixels, (size_t)T * 3 * res * res * 4,
-                               (size_t)ctx * 3 * res * res * 4, B, hipMemcpyDeviceToDevice, st));
+      CK((int)hipMemcpy2DAsync(cache->ctx_pixels, (size_t)ctx * 3 * res * res * psz, out_pixels, (size_t)T * 3 * res * res * psz,
+                               (size_t)ctx * 3 * res * res * psz, B, hipMemcpyDeviceToDevice, st));
       cache->filled = true;
       cache->clamped = e->clamp_out;
+      cache->pix_dt = (int)out_dt;
     }
   } else if (!planning) {
-    CK((int)hipMemcpy2DAsync(out_pixels, (size_t)T * 3 * res * res * 4, cache->ctx_pixels, (size_t)ctx * 3 * res * res * 4,
-                             (size_t)ctx * 3 * res * res * 4, B, hipMemcpyDeviceToDevice, st));
+    CK((int)hipMemcpy2DAsync(out_pixels, (size_t)T * 3 * res * res * psz, cache->ctx_pixels, (size_t)ctx * 3 * res * res * psz,
+                             (size_t)ctx * 3 * res * res * psz, B, hipMemcpyDeviceToDevice, st));
   }
   if (F > 0) {
     const int M = B * F;
@@ -611,7 +618,7 @@ int Run::detokenize(const int64_t* ids, int B, int F, float* out_pixels, ivg_cac
     }
     IVG_TRY(linear(dt, qd, (long)M * 16, e->post_quant_linear, q2, nullptr, 0, 0));
     if (!planning) CK(launch_unpatchify(q2, z, dt, M, 16 / p, lat, p, st));
-    IVG_TRY(decoder_trunk(e->cdec, z, B, F, T, ctx, nullptr, &feats, out_pixels));
+    IVG_TRY(decoder_trunk(e->cdec, z, B, F, T, ctx, nullptr, &feats, out_pixels, out_dt));
   }
   e->ws.reset(m);
   return 0;

@@ -231,6 +231,7 @@ static int step_body(ivg_engine* e, hipStream_t st, const GenBuf& g, int B, cons
   };
   auto layer_args = [&](int l, SkinnyArgs* g) {
     const LayerW& w = e->layers[l];
+    for (int k = 0; k < 4; ++k) g[k].x3 = e->llm_x3 && sw().x3;
     SkinnyArgs& s = g[0];
     s.X = x; s.W = w.wqkv; s.Y = qkv; s.M = B; s.N = 3 * H; s.K = H; s.ldx = H; s.ldw = H; s.ldy = 3 * H;
     s.flags = SK_NORM; s.eps = c.rms_norm_eps;

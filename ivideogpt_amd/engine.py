@@ -149,7 +149,8 @@ class Engine:
             self.check(self.lib.ivg_set_output_clamp(self.h, int(bool(clamp))), "set_output_clamp")
             self._clamp_out = bool(clamp)
         with self.stream() as s:
-            self.check(self.lib.ivg_detokenize(self.h, _ptr(ids), ids.shape[0], int(F), _ptr(out), cache, int(cache_mode), s), "detokenize")
+            self.check(self.lib.ivg_detokenize_to(self.h, _ptr(ids), ids.shape[0], int(F), _ptr(out), dtype_code(out.dtype), cache, int(cache_mode), s),
+                       "detokenize")
             ids.record_stream(self._run); out.record_stream(self._run)
 
     def cache_create(self, B):

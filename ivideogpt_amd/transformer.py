@@ -111,6 +111,8 @@ class LlamaForCausalLM:
                              reward_prediction=self._reward)
         r.device = self.device
         r._sd_version = self._sd_version
+        if hasattr(self, "_wrapper_heads"):
+            r._wrapper_heads = self._wrapper_heads
         r._packed, r._packed_key = self._packed_weights(), self._pack_key()
         return r
 
@@ -122,7 +124,12 @@ class LlamaForCausalLM:
         return cls(cfg, sd, dtype=dtype)
 
     @classmethod
-    def from_config(cls, config, seed=None, dtype="bf16"):
+    def from_config(cls, config, seed=None, dtype="bf16", **unused):
+        """``AutoModelForCausalLM.from_config(config)`` (mbrl/video_predictor.py:72, train_gpt.py:593): ``config`` = a dict, an object
+        with the HF field names, or a path to a ``config.json`` / its directory (what ``AutoConfig.from_pretrained`` takes).
+        seed = None: no weights yet (load_state_dict follows); otherwise seeded random weights in the checkpoint schema."""
+        if isinstance(config, (str, bytes)) or hasattr(config, "__fspath__"):
+            config = W.load_llama_config(config)
         cfg = dict(W.LLAMA_SMALL)
         cfg.update({k: v for k, v in (vars(config) if not isinstance(config, dict) else config).items() if k in cfg})
         sd = W.random_llama_state_dict(cfg, seed) if seed is not None else None
@@ -134,7 +141,14 @@ class LlamaForCausalLM:
     def load_state_dict(self, sd, strict=True):
         if strict:
             W.validate_state_dict(sd, W.llama_param_shapes(self._cfg), "transformer")
-        self._sd, self._prefix = sd, ""
+        heads = getattr(self, "_wrapper_heads", None)
+        if heads is not None:   # ``model.llm.load_state_dict(...)`` of a HeadModelWithAction (mbrl/video_predictor.py:82-83, load_internal_llm):
+            # only the transformer's weights change, the wrapper's heads stay what they are
+            old = self._sd if (self._sd is not None and self._prefix == "llm.") else None
+            self._sd = HeadModelWithAction._with_fresh_heads(sd, self._cfg["hidden_size"], heads[0], heads[1], old=old)
+            self._prefix = "llm."
+        else:
+            self._sd, self._prefix = sd, ""
         self._drop_engine()
         self._invalidate_pack()
 
@@ -273,13 +287,42 @@ class HeadModelWithAction:
         self.reward_prediction = reward_prediction
         self.action_recon = action_recon
         if (llm._action_dim, llm._reward, llm._prefix) != (action_dim, reward_prediction, "llm."):
+            if llm._sd is not None and llm._prefix == "":
+                # wrapping an llm that already holds weights (AutoModelForCausalLM.from_config / from_pretrained, then
+                # HeadModelWithAction(model, ...): mbrl/video_predictor.py:74-79): its keys move under "llm." and the new heads get the
+                # reference constructor's initial values (action_model.py:36-42)
+                llm._sd = self._with_fresh_heads(llm._sd, llm._cfg["hidden_size"], action_dim, reward_prediction)
             llm._action_dim, llm._reward, llm._prefix = action_dim, reward_prediction, "llm."
             llm._invalidate_pack()   # other key prefix / extra heads: whatever was packed for the bare llm is stale
+        llm._wrapper_heads = (action_dim, reward_prediction)   # llm.load_state_dict(...) under this wrapper keeps the heads (load_internal_llm)
         llm._drop_engine()   # an engine built for the bare llm has no action / reward head
         self.device = llm.device
         self.action_linear = _ActionLinear(llm)
         if reward_prediction:
             self.reward_linear = _RewardLinear(llm)
+
+    @staticmethod
+    def _with_fresh_heads(llm_sd, hidden, action_dim, reward_prediction, old=None, seed=0):
+        """{"llm." + k: v} plus the heads: kept from ``old`` (a previous wrapper state dict) when present, else as the reference's
+        constructor leaves them -- ``action_linear`` zero-initialised (action_model.py:36-39), ``reward_linear`` with nn.Linear's
+        default initialiser (:41-42; seeded here, the reference draws from the global generator)."""
+        sd = {"llm." + k: v for k, v in llm_sd.items()}
+        old = old or {}
+        heads = {"action_linear.weight": torch.zeros(hidden, action_dim), "action_linear.bias": torch.zeros(hidden)}
+        if reward_prediction:
+            lin = torch.nn.Linear(hidden, 1)
+            g = torch.Generator().manual_seed(seed)
+            bound = 1.0 / hidden ** 0.5
+            with torch.no_grad():
+                lin.weight.uniform_(-bound, bound, generator=g)
+                lin.bias.uniform_(-bound, bound, generator=g)
+            heads["reward_linear.weight"], heads["reward_linear.bias"] = lin.weight.detach(), lin.bias.detach()
+        for k, v in heads.items():
+            sd[k] = old.get(k, v)
+        for k, v in old.items():
+            if k.startswith("action_recon_linear"):
+                sd[k] = v
+        return sd
 
     def get_input_embeddings(self, input_ids):
         """action_model.py:47-54."""

@@ -93,7 +93,15 @@ class CompressiveVQModel:
 
     @classmethod
     def from_config(cls, config, seed=0, codebook_std=None, **kw):
-        """Seeded random weights in the real checkpoint schema (no pretrained files are available offline)."""
+        """Seeded random weights in the real checkpoint schema (no pretrained files are available offline).  ``config``: a dict, or --
+        as the reference's MBRL loader passes it (mbrl/video_predictor.py:43: ``CompressiveVQModel.from_config(path)``) -- a
+        directory / file holding ``config.json``."""
+        if isinstance(config, (str, bytes)) or hasattr(config, "__fspath__"):
+            import json
+            import os
+            p = os.fspath(config)
+            with open(os.path.join(p, "config.json") if os.path.isdir(p) else p) as f:
+                config = json.load(f)
         cfg = W.tokenizer_config(**{k: v for k, v in dict(config).items() if k in W.TOKENIZER_DEFAULTS})
         return cls(cfg, W.random_tokenizer_state_dict(cfg, seed, codebook_std), **kw)
 
@@ -204,16 +212,18 @@ class CompressiveVQModel:
         return ids
 
     @torch.no_grad()
-    def detokenize(self, indices, context_length=0, cache=None, return_cache=False, clamp=False):
+    def detokenize(self, indices, context_length=0, cache=None, return_cache=False, clamp=False, out_dtype=torch.float32):
         """``clamp=True`` (not in the reference's signature): the frames come back as ``clamp(0, 1)`` -- the post-processing every
-        caller applies (predict.py:73) -- written by the epilogue of the decoders' last convolution instead of a pass over the clip."""
+        caller applies (predict.py:73) -- written by the epilogue of the decoders' last convolution instead of a pass over the clip.
+        ``out_dtype=torch.bfloat16`` (bf16 decode mode only): the clip in bfloat16, as the reference returns it under
+        ``torch.autocast(bfloat16)`` (vp/ivideogpt_interface.py:180, mbrl/video_predictor.py:269) -- half the bytes."""
         assert context_length == self.context_length
         assert (indices.shape[1] + 1 - CTX_TOKENS * context_length) % DYN_TOKENS == 0
         F = (indices.shape[1] + 1 - CTX_TOKENS * context_length) // DYN_TOKENS
         B = indices.shape[0]
         ids = indices.to(device=self.device, dtype=torch.int64).contiguous()
         res = self.config["resolution"]
-        out = torch.empty(B, context_length + F, 3, res, res, dtype=torch.float32, device=self.device)
+        out = torch.empty(B, context_length + F, 3, res, res, dtype=out_dtype, device=self.device)
         eng = self._ensure(B, context_length + F)
         handle, mode = None, 0
         if cache is not None and (cache.engine is not eng or cache.engine.h is None):

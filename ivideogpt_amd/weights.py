@@ -262,6 +262,19 @@ def save_tokenizer_checkpoint(path, cfg, sd, subfolder=None):
     save_file({k: v.contiguous() for k, v in sd.items()}, os.path.join(d, "diffusion_pytorch_model.safetensors"))
 
 
+def load_llama_config(path):
+    """``AutoConfig.from_pretrained(path)`` for the Llama configs the reference ships (configs/llama/config.json,
+    config_medium.json): a ``config.json`` file or the directory holding one -> config dict (unknown keys dropped)."""
+    p = os.fspath(path)
+    with open(os.path.join(p, "config.json") if os.path.isdir(p) else p) as f:
+        raw = json.load(f)
+    cfg = dict(LLAMA_SMALL)
+    cfg.update({k: raw[k] for k in cfg if k in raw})
+    if "rope_theta" not in raw and isinstance(raw.get("rope_parameters"), dict):
+        cfg["rope_theta"] = raw["rope_parameters"].get("rope_theta", cfg["rope_theta"])
+    return cfg
+
+
 def load_transformer_checkpoint(path, subfolder="transformer"):
     """<path>/<subfolder>/{config.json, model.safetensors} -> (llama config dict, state dict)."""
     from safetensors.torch import load_file

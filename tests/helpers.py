@@ -195,3 +195,30 @@ def matched_codebooks(ora, sd, px, ctx, kind, seed):
             mod.embedding.weight.copy_(w)
         stds.append(s)
     return stds
+
+
+# ------------------------------------------------------------------------------------------------ MBRL world-model checkpoint tree
+def world_model_files(tmp_path, load_internal_llm):
+    """A checkpoint directory tree laid out as the reference's mbrl/cfgs/mbpo_config.yaml expects it."""
+    import json
+    from safetensors.torch import save_file
+    from ivideogpt_amd import weights as W
+    tcfg = W.tokenizer_config(block_out_channels=(64, 64, 64), layers_per_block=1, latent_channels=64, num_vq_embeddings=64,
+                              num_dyn_embeddings=64, mid_block_add_attention=False, context_length=2, resolution=64, max_att_resolution=16)
+    tsd = W.random_tokenizer_state_dict(tcfg, 3, codebook_std=0.4)
+    W.save_tokenizer_checkpoint(str(tmp_path / "tokenizer"), tcfg, tsd)
+    lcfg = dict(W.LLAMA_SMALL, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, vocab_size=130)
+    (tmp_path / "configs" / "llama").mkdir(parents=True)
+    with open(tmp_path / "configs" / "llama" / "config.json", "w") as f:
+        json.dump(dict(lcfg, model_type="llama", vocab_size=32000), f)      # the shipped config's vocabulary is overwritten by load_models
+    full = W.random_llama_state_dict(lcfg, 5, action_dim=4, reward_prediction=True)
+    (tmp_path / "transformer").mkdir()
+    if load_internal_llm:    # an action-free pretrained transformer: bare HF keys
+        sd = {k[len("llm."):]: v for k, v in full.items() if k.startswith("llm.")}
+    else:
+        sd = full
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(tmp_path / "transformer" / "model.safetensors"))
+    args = dict(load_pretrained_model=True, config_name=str(tmp_path / "configs" / "llama" / "config.json"), vqgan_type="ctx_vqgan",
+                pretrained_model_name_or_path=str(tmp_path / "tokenizer"), pretrained_transformer_path=str(tmp_path / "transformer"),
+                load_internal_llm=load_internal_llm, llama_attn_drop=0.1, symlog=True, context_length=2, segment_length=12, action_dim=4)
+    return args, tcfg, tsd, lcfg, full

@@ -105,7 +105,7 @@ def test_mbrl_rollout_matches_oracle():
     head = HeadModelWithAction(LlamaForCausalLM(LLM_CFG, None, dtype="fp32"), 4, 513, 16, 2, 16, reward_prediction=True)
     head.load_state_dict(lsd, strict=True)
     head.to(DEV)
-    vp = VideoPredictor(tok, head, context_length=2, symlog=True)
+    vp = VideoPredictor.from_models(tok, head, context_length=2, symlog=True)
     g = torch.Generator().manual_seed(5)
     obs = torch.randint(0, 256, (2, 9, 64, 64), generator=g).float()
     acts = torch.randn(3, 2, 4, generator=g)
@@ -359,3 +359,31 @@ def test_config1_predict_cli_on_fractal_sample_full_width(tmp_path):
     # pixels: the oracle decodes the tokens the engine produced (rows that left the oracle's path at a near-tie included)
     rec_ref = tok.detokenize(toks, 2).clamp(0, 1)
     assert (rec - rec_ref).abs().max().item() < 1e-3
+
+
+def test_video_predictor_from_hydra_config_equals_from_models(tmp_path):
+    """``VideoPredictor('cuda', cfg.world_model)`` (reference mbrl/train_metaworld_mbpo.py:41-42): the constructor path -- checkpoint
+    tree, ``load_internal_llm`` -- yields the same imagined rollout as wrapping the same weights by hand."""
+    sys.path.insert(0, ROOT)
+    from helpers import world_model_files
+    from ivideogpt_amd import CompressiveVQModel, HeadModelWithAction, LlamaForCausalLM
+    from mbrl.video_predictor import VideoPredictor
+    args, tcfg, tsd, lcfg, full = world_model_files(tmp_path, True)
+    args.update(encode_dtype="fp32", decode_dtype="fp32", llm_dtype="fp32")
+    vp = VideoPredictor("cuda", args)
+    lcfg = dict(lcfg, vocab_size=130)
+    head = HeadModelWithAction(LlamaForCausalLM(lcfg, None, dtype="fp32"), 4, 513, 16, 2, 12, reward_prediction=True)
+    head.load_state_dict(vp.model.state_dict(), strict=True)
+    head.to(DEV)
+    tok = CompressiveVQModel(tcfg, tsd, encode_dtype="fp32", decode_dtype="fp32").to(DEV)
+    ref = VideoPredictor.from_models(tok, head, context_length=2, symlog=True)
+    g = torch.Generator().manual_seed(8)
+    obs = torch.randint(0, 256, (2, 9, 64, 64), generator=g).float()
+    acts = torch.randn(2, 2, 4, generator=g)
+    outs = []
+    for p in (vp, ref):
+        torch.manual_seed(33)
+        outs.append(p.rollout(obs, lambda o, t: acts[t], 2))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert vp.steps_with_kept_cache == 1

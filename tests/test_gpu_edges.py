@@ -242,3 +242,44 @@ def test_generate_without_action_matches_the_reference_loop():
     assert bool((out[:, 257 * ctx + 16::17] == sdf).all())
     with pytest.raises(ValueError):                                   # the gpt2 branch of the reference (action_model.py:30-33) is not a Llama: refused
         HeadModelWithAction(LlamaForCausalLM(cfg, None, dtype="fp32"), adim, 257 * ctx - 1, 16, ctx, ctx + F_, model_type="gpt2")
+
+
+def test_detokenize_bf16_output_and_cache_element_type():
+    """``ivg_detokenize_to`` / ``detokenize(out_dtype=torch.bfloat16)``: the bf16 decode path hands the clip back in bfloat16 (what the
+    reference's callers get under autocast, vp/ivideogpt_interface.py:180) -- equal to the float32 result rounded to bf16, cache paths
+    included; the fp32 decode path refuses it, and a cache filled with one element type refuses reuse with the other."""
+    from helpers import tokenizer_fixture
+    from ivideogpt_amd import CompressiveVQModel
+    cfg, sd, ctx, px, g = tokenizer_fixture("tok_mini64_ctx2.npz")
+    ids = torch.from_numpy(g["indices"]).to("cuda:0")
+    m = CompressiveVQModel(cfg, sd, encode_dtype="fp32", decode_dtype="bf16").to("cuda:0")
+    f32 = m.detokenize(ids, ctx)
+    b16 = m.detokenize(ids, ctx, out_dtype=torch.bfloat16)
+    assert b16.dtype == torch.bfloat16 and b16.shape == f32.shape
+    assert torch.equal(b16, f32.to(torch.bfloat16))
+    c16 = m.detokenize(ids, ctx, out_dtype=torch.bfloat16, clamp=True)
+    assert torch.equal(c16, f32.clamp(0, 1).to(torch.bfloat16))
+    a, cache = m.detokenize(ids, ctx, return_cache=True, out_dtype=torch.bfloat16)
+    b = m.detokenize(ids, ctx, cache=cache, out_dtype=torch.bfloat16)
+    assert torch.equal(a, b16) and torch.equal(b, b16)
+    with pytest.raises(AssertionError):
+        m.detokenize(ids, ctx, cache=cache)            # float32 call on a cache that holds bfloat16 context pixels
+    m32 = CompressiveVQModel(cfg, sd, encode_dtype="fp32", decode_dtype="fp32").to("cuda:0")
+    with pytest.raises(AssertionError):
+        m32.detokenize(ids, ctx, out_dtype=torch.bfloat16)
+
+
+def test_detokenize_cache_remembers_the_clamp_mode():
+    """A cache filled with clamp off and reused with clamp on (or the reverse) would hand back context frames in one mode beside
+    predicted frames in the other: refused (IVG_ERR_INVALID -> AssertionError), same mode works."""
+    from helpers import tokenizer_fixture
+    from ivideogpt_amd import CompressiveVQModel
+    cfg, sd, ctx, px, g = tokenizer_fixture("tok_mini64_ctx2.npz")
+    ids = torch.from_numpy(g["indices"]).to("cuda:0")
+    m = CompressiveVQModel(cfg, sd, encode_dtype="fp32", decode_dtype="fp32").to("cuda:0")
+    raw, cache = m.detokenize(ids, ctx, return_cache=True)
+    assert torch.equal(m.detokenize(ids, ctx, cache=cache), raw)
+    with pytest.raises(AssertionError):
+        m.detokenize(ids, ctx, cache=cache, clamp=True)
+    cl, cache2 = m.detokenize(ids, ctx, return_cache=True, clamp=True)
+    assert torch.equal(cl, raw.clamp(0, 1)) and torch.equal(m.detokenize(ids, ctx, cache=cache2, clamp=True), cl)

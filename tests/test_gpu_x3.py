@@ -96,6 +96,37 @@ def test_x3_full_width_llama_logits_vs_oracle():
     assert e3.max().item() > 0.0
 
 
+@pytest.mark.parametrize("width", ["small", "medium"])
+def test_x3_decode_path_at_released_widths_vs_oracle(width):
+    """The x3 DECODE path (dgemm3.hip X3: both fragments split in registers) at the released transformer widths: greedy rollouts from
+    a 514-token prompt through ``generate`` equal the oracle's token for token, sampled ones with the same uniforms too; rows do not
+    depend on their batch-mates (64-row batch vs shards)."""
+    from oracle.llama import generate_cached
+    from ivideogpt_amd import weights as W
+    cfg = dict(W.LLAMA_SMALL if width == "small" else W.LLAMA_MEDIUM)
+    cfg["num_hidden_layers"] = 4 if width == "small" else 3          # (keeps the CPU oracle quick: the GEMM shapes are what matters)
+    sd = W.random_llama_state_dict(cfg, 49)
+    g = torch.Generator().manual_seed(13)
+    prompt = torch.randint(0, 8192, (2, 514), generator=g)
+    prompt[:, 256], prompt[:, -1] = cfg["vocab_size"] - 2, cfg["vocab_size"] - 1
+    n_new = 40
+    u = torch.rand(2, n_new, generator=g)
+    ora = oracle_llama(cfg, sd)
+    m = make_llm(cfg, sd, "x3")
+    out_g = m.generate(prompt.to(DEV), do_sample=False, max_new_tokens=n_new).cpu()
+    ref_g = generate_cached(ora, prompt, n_new)
+    assert torch.equal(out_g, ref_g), f"greedy: {(out_g != ref_g).sum().item()} of {2 * n_new} tokens differ from the oracle"
+    out_s = m.generate(prompt.to(DEV), do_sample=True, top_k=100, max_new_tokens=n_new, uniforms=u.to(DEV)).cpu()
+    ref_s = generate_cached(ora, prompt, n_new, top_k=100, uniforms=u)
+    assert torch.equal(out_s, ref_s), f"sampled: {(out_s != ref_s).sum().item()} of {2 * n_new} tokens differ from the oracle"
+    p64 = torch.randint(0, 16384, (64, 40), generator=g)
+    u64 = torch.rand(64, 12, generator=g)
+    full = m.generate(p64.to(DEV), do_sample=True, top_k=100, max_new_tokens=12, uniforms=u64.to(DEV)).cpu()
+    for rows in (slice(0, 16), slice(63, 64)):
+        part = m.generate(p64[rows].to(DEV), do_sample=True, top_k=100, max_new_tokens=12, uniforms=u64[rows].to(DEV)).cpu()
+        assert torch.equal(part, full[rows]), f"{width}: rows {rows} differ between the 64-row batch and the shard"
+
+
 def test_x3_switch_off_is_the_fp32_path(switches):
     """IVG_X3=0: an engine created in x3 mode runs the f32-input MFMA kernels -- bit-identical to the fp32 mode."""
     cfg, sd, ctx, px, g = tokenizer_fixture("tok_mini64_ctx2.npz")

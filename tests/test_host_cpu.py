@@ -306,3 +306,37 @@ def test_turnstile_orders_tickets_and_releases_waiters_when_a_lane_dies():
     waiter = threading.Thread(target=lane, args=([1], 0.0))   # ticket 0 never comes: its lane "died"
     waiter.start(); time.sleep(0.05); turn.abort(); waiter.join(10)
     assert not waiter.is_alive() and errs and "aborted" in errs[0]
+
+
+@pytest.mark.parametrize("internal", [True, False])
+def test_video_predictor_constructor_follows_the_reference_loader(tmp_path, internal, capsys):
+    """``VideoPredictor(device, cfg.world_model)`` (reference mbrl/video_predictor.py:40-110, mbrl/train_metaworld_mbpo.py:41-42):
+    tokenizer from its checkpoint, vocabulary = codes + 2, Llama from ``config_name`` with that vocabulary, wrapped with
+    prelude 257 * ctx - 1 / 16 tokens per frame / reward head; weights into ``model.llm`` only (load_internal_llm: zero action
+    head, fresh reward head) or strictly into the whole wrapper; context-length mismatch -> the reference's warning + set_context_length."""
+    sys.path.insert(0, ROOT)
+    from types import SimpleNamespace
+    from helpers import world_model_files
+    from mbrl.video_predictor import VideoPredictor
+    args, tcfg, tsd, lcfg, full = world_model_files(tmp_path, internal)
+    vp = VideoPredictor("cpu", SimpleNamespace(**args))
+    assert vp.tokenizer.context_length == 2 and vp.model.llm.config.vocab_size == 64 + 64 + 2
+    assert vp.model.prelude_tokens_num == 513 and vp.model.tokens_num_per_dyna == 16 and vp.model.segment_length == 12
+    assert vp.model.model_type == "llama" and vp.model.reward_prediction and vp.context_length == 2 and vp.symlog
+    sd = vp.model.state_dict()
+    for k, v in full.items():
+        if k.startswith("llm."):
+            assert torch.equal(sd[k], v), k
+    if internal:
+        assert not sd["action_linear.weight"].any() and not sd["action_linear.bias"].any()      # action_model.py:36-39
+        assert sd["reward_linear.weight"].shape == (1, 128) and sd["reward_linear.weight"].abs().max() <= 128 ** -0.5
+    else:
+        assert torch.equal(sd["action_linear.weight"], full["action_linear.weight"]) and torch.equal(sd["reward_linear.bias"], full["reward_linear.bias"])
+    # context-length mismatch: warning + set_context_length (video_predictor.py:50-53)
+    vp1 = VideoPredictor("cpu", dict(args, context_length=1))
+    assert vp1.tokenizer.context_length == 1 and vp1.model.prelude_tokens_num == 256 and "mismatch" in capsys.readouterr().out
+    # load_pretrained_model off: random weights of the configured architectures (from_config)
+    vp0 = VideoPredictor("cpu", dict(args, load_pretrained_model=False))
+    assert set(vp0.model.state_dict()) == set(full) and vp0.tokenizer.state_dict().keys() == tsd.keys()
+    with pytest.raises(Exception):   # strict loading: an action-free checkpoint into the whole wrapper (or the reverse) must fail
+        VideoPredictor("cpu", dict(args, load_internal_llm=not internal))

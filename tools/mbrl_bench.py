@@ -24,7 +24,7 @@ head.to(dev)
 obs = torch.randint(0, 256, (B, 9, 64, 64)).float()
 policy = lambda o, t: torch.zeros(B, 4)  # noqa: E731
 for reuse in (False, True):
-    vp = VideoPredictor(tok, head, context_length=2, reuse_cache=reuse)
+    vp = VideoPredictor.from_models(tok, head, context_length=2, reuse_cache=reuse)
     for _ in range(2):
         vp.rollout(obs, policy, horizon)
     torch.cuda.synchronize()
