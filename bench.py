@@ -33,6 +33,10 @@ import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver: RCCL needs it (multi-process runs)
+# HIP deals its streams round-robin over GPU_MAX_HW_QUEUES hardware queues (default 4): the null stream, this benchmark's main stream
+# and the lane streams must not share one -- two lanes on one hardware queue run one after the other (4,987 instead of 5,355 frames/s
+# at four lanes, profiles/r04_lanes.txt).  Has to be in the environment before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 
@@ -41,7 +45,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from ivideogpt_amd import CompressiveVQModel, LlamaForCausalLM, weights as W  # noqa: E402
-from ivideogpt_amd import _lib, parallel  # noqa: E402
+from ivideogpt_amd import _lib, parallel, switches  # noqa: E402
 from ivideogpt_amd.pipeline import frame_metrics, predict_frames  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
@@ -325,19 +329,23 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-mode", action="store_true", help="skip the extra fp32-arithmetic measurement")
     ap.add_argument("--no-profile", action="store_true", help="skip the profiled pass (rooflines)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE configs 3, 4, 5 (default config, N = 1 only)")
     ap.add_argument("--cpu-sample", type=int, default=8)
-    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the CPU baseline (0: min(32, available cores))")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the CPU baseline (0: min(32, available cores) -- measured fastest)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--greedy", action="store_true")
     ap.add_argument("--action-dim", type=int, default=0, help=">0: action-conditioned HeadModelWithAction (BASELINE config 3: 4)")
     ap.add_argument("--ctx", type=int, default=0, help="context frames (0: the tokenizer's pretrained context_length)")
-    ap.add_argument("--lanes", type=int, default=2, help="batches in flight per GPU: engine instances on their own HIP streams and host threads "
+    ap.add_argument("--lane-switches", default="in-flight", choices=["in-flight", "none"],
+                    help="library switches while several batches are in flight: ivideogpt_amd.switches.BATCHES_IN_FLIGHT, or none (A/B)")
+    ap.add_argument("--lanes", type=int, default=4, help="batches in flight per GPU: engine instances on their own HIP streams and host threads "
                                                          "(1: one batch at a time, the per-batch latency case)")
     ap.add_argument("--conv-gate", type=int, default=0, help="1: at most one lane's convolution phase (encode / decode) on the device at a time "
                                                               "(parallel.PhaseGate), rollouts of the other lanes beside it")
     ap.add_argument("--cu-split", type=int, default=0, help="experiment: CUs (of 256) given to the convolution phases of all lanes; the rollouts "
                                                              "run on the others (CU-masked streams); 0: off")
     a = ap.parse_args()
+    default_run = not a.config and not (a.medium or a.action_dim or a.res != 64 or a.frames != 16 or a.ctx or a.batch != 64)
     if a.config:
         for k, v in CONFIGS[a.config].items():
             setattr(a, k, v)
@@ -436,7 +444,9 @@ def main():
             for ln in lanes:
                 ln["stream"] = parallel.cu_masked_stream(dev, conv_bits)
                 ln["rollout_stream"] = parallel.cu_masked_stream(dev, roll_bits)
-        my_elapsed, lane_frames, lane_rows = measure_lanes(lanes, ctx, F, a.greedy, a.steps, a.warmup, gate)
+        # several batches in flight: decode GEMMs with a small LDS footprint, so that the kernels of the other batches fit beside them
+        with switches.override(**({} if a.lane_switches == "none" else switches.BATCHES_IN_FLIGHT)):
+            my_elapsed, lane_frames, lane_rows = measure_lanes(lanes, ctx, F, a.greedy, a.steps, a.warmup, gate)
         for fr, rw in zip(lane_frames, lane_rows):
             assert torch.isfinite(fr).all() and rw.shape == (global_b, 3) and torch.isfinite(rw).all()
         steps_timed = a.steps
@@ -512,11 +522,36 @@ def main():
                                         actions=torch.randn(B, T, a.action_dim, device=dev, generator=gi) if a.action_dim else None,
                                         gen=torch.Generator(device=dev).manual_seed(2000 + rank + 7919 * i), stream=torch.cuda.Stream(device=dev)))
                 n_l = 2 * a.lanes
-                e_l, fl, _ = measure_lanes(lanes_a, ctx, F, a.greedy, n_l, 1, parallel.PhaseGate() if a.conv_gate else None)
+                with switches.override(**({} if a.lane_switches == "none" else switches.BATCHES_IN_FLIGHT)):
+                    e_l, fl, _ = measure_lanes(lanes_a, ctx, F, a.greedy, n_l, 1, parallel.PhaseGate() if a.conv_gate else None)
                 assert all(torch.isfinite(x).all() for x in fl)
                 alt[key]["lanes_in_flight"] = {"lanes": a.lanes, "value": B * F * n_l / e_l, "ms_per_step": e_l / n_l * 1e3, "steps": n_l}
                 del lanes_a
             del model_a, tok_a
+            torch.cuda.empty_cache()
+
+    # ---- the other per-GPU shapes of BASELINE.json (configs 3, 4, 5), short single-lane runs inside the same driver-observed line
+    other = {}
+    if world == 1 and default_run and not a.no_other_configs:
+        for k in (3, 4, 5):
+            c = CONFIGS[k]
+            try:
+                tc, lc, _, _, tok_o, model_o = build_models(dev, c["res"], c["medium"], a.encode_dtype, a.decode_dtype, a.llm_dtype, c["action_dim"],
+                                                            c["ctx"] or None, c["frames"])
+                ctx_o, Fo = tok_o.context_length, c["frames"] - tok_o.context_length
+                go = torch.Generator(device=dev).manual_seed(3000 + k)
+                px_o = torch.rand(c["batch"], c["frames"], 3, c["res"], c["res"], device=dev, generator=go).to(torch.bfloat16)
+                act_o = torch.randn(c["batch"], c["frames"], c["action_dim"], device=dev, generator=go) if c["action_dim"] else None
+                e_o, fr_o, _, _, t_o = measure(tok_o, model_o, px_o, act_o, ctx_o, Fo, a.greedy, go, 3, 1, per_step=True)
+                assert torch.isfinite(fr_o).all()
+                other[f"config_{k}"] = {"value": c["batch"] * Fo * 3 / e_o, "unit": "predicted frames/s", "ms_per_step": e_o / 3 * 1e3,
+                                        "ms_per_step_median": median(t_o) * 1e3, "steps": 3, "lanes": 1,
+                                        "workload": f"{c['batch']} trajectories per GPU, {ctx_o} context + {Fo} predicted frames, {c['res']}x{c['res']}, "
+                                                    f"{'medium (436 M)' if c['medium'] else 'small (138 M)'} transformer"
+                                                    + (f", {c['action_dim']}-dim actions" if c["action_dim"] else "")}
+                del tok_o, model_o, px_o, fr_o
+            except Exception as ex:   # never lose the headline to a side measurement
+                other[f"config_{k}"] = {"value": None, "error": repr(ex)[:200]}
             torch.cuda.empty_cache()
 
     if rank == 0:
@@ -552,9 +587,16 @@ def main():
         if single:
             out["single_lane"] = single
         out.update(alt)
+        if other:
+            out["other_configs"] = other
         if world == 1 and not a.no_cpu_baseline:
+            # 32 threads: MORE threads make this port slower on the GPU box's host (4 trajectories: 4.35 frames/s on 32 threads, 2.11 on
+            # 64, no result within 200 s on all 256 -- profiles/r04_cpu_baseline_threads.txt); --cpu-threads N overrides
             threads = a.cpu_threads or min(32, _cpu_threads())
-            out["cpu_baseline"] = cpu_baseline(a.res, a.medium, ctx, T, a.cpu_sample, threads)
+            out["cpu_baseline"] = cpu_baseline(a.res, a.medium, ctx, T, a.cpu_sample, threads, budget_s=150)
+            out["cpu_baseline"]["host_cores_available"] = _cpu_threads()
+            out["cpu_baseline"]["threads_note"] = ("32 of the host's threads: measured fastest (64 threads 0.49x, 256 threads no result in 200 s: "
+                                                   "profiles/r04_cpu_baseline_threads.txt)")
             if out["cpu_baseline"]["value"]:
                 out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)

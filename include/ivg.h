@@ -272,16 +272,16 @@ int ivg_op_conv_x3(const ivg_igemm_args* a, const void* w_x3, int groups, const 
  * VpT [M/F][C][kv] -> out [M][P][C], heads of C / nh channels, softmax(q k^T / sqrt(C / nh)) v per head
  * (ivideogpt/vq_model/conditional_vae.py:38-55). */
 int ivg_op_xattn(const void* q, const void* Kp, const void* VpT, void* out, int M, int F, int P, int kv, int C, int nh, int dtype, ivg_stream stream);
-int ivg_op_skinny(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy, int splits, int flags,
-                  int dtype, ivg_stream stream);
+/* decode-step GEMM (M <= 128 rows; K bytes a multiple of 128): Y = epi(X W^T), flags = IG_* | SK_NORM of csrc/igemm.h */
+int ivg_op_skinny(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy, int flags, int dtype,
+                  ivg_stream stream);
 int ivg_op_groupnorm(const void* X, void* Y, void* ws /* >= N*chunks*groups*16 B */, const float* gamma, const float* beta,
                      const float* pos, int N, int P, int C, int groups, float eps, int silu, int dtype, ivg_stream stream);
 int ivg_op_softmax(const float* S, void* P, int64_t rows, int Lq, int Lk, int lds, int ldp, int causal, int dtype,
                    ivg_stream stream);
 int ivg_op_vq_argmin(const float* z, const float* codebook, float* ee_ws /* n_e floats */, int64_t* out, int R, int n_e,
                      ivg_stream stream);
-int ivg_op_add_rmsnorm(void* x, const float* part, int splits, const float* w, void* out, int M, int H, float eps, int dtype,
-                       ivg_stream stream);
+int ivg_op_add_rmsnorm(void* x, const float* w, void* out, int M, int H, float eps, int dtype, ivg_stream stream);
 int ivg_op_conv_in(const void* video, int video_dtype, const float* w, const float* bias, void* Y, int dtype, int N, int per,
                    int T_total, int t0, int H, int W, int C0, ivg_stream stream);
 /* one top-k draw per logits row [B][V] fp32 with the rollout's sampler (uniforms [B] in [0,1), or NULL = greedy): HF

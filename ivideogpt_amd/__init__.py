@@ -6,6 +6,6 @@ non-GPU device, raises.
 """
 from .vq_model import CompressiveVQModel, DetokenizeCache  # noqa: F401
 from .transformer import HeadModelWithAction, LlamaForCausalLM  # noqa: F401
-from . import weights  # noqa: F401
+from . import switches, weights  # noqa: F401
 
-__all__ = ["CompressiveVQModel", "DetokenizeCache", "HeadModelWithAction", "LlamaForCausalLM", "weights"]
+__all__ = ["CompressiveVQModel", "DetokenizeCache", "HeadModelWithAction", "LlamaForCausalLM", "switches", "weights"]

@@ -786,8 +786,8 @@ int ivg_op_conv_x3(const ivg_igemm_args* a, const void* w_x3, int groups, const 
   return rc == 0 ? IVG_OK : (rc > 0 ? IVG_ERR_HIP : IVG_ERR_INVALID);
 }
 
-int ivg_op_skinny(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy, int splits, int flags, int dtype, ivg_stream stream) {
-  SkinnyArgs s; s.X = X; s.W = W; s.Y = Y; s.M = M; s.N = N; s.K = K; s.ldx = ldx; s.ldw = ldw; s.ldy = ldy; s.splits = splits; s.flags = flags;
+int ivg_op_skinny(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy, int flags, int dtype, ivg_stream stream) {
+  SkinnyArgs s; s.X = X; s.W = W; s.Y = Y; s.M = M; s.N = N; s.K = K; s.ldx = ldx; s.ldw = ldw; s.ldy = ldy; s.flags = flags;
   return launch_skinny(s, (DType)dtype, (hipStream_t)stream) ? IVG_ERR_HIP : IVG_OK;
 }
 
@@ -806,8 +806,8 @@ int ivg_op_vq_argmin(const float* z, const float* codebook, float* ee_ws, int64_
   return launch_vq_argmin(z, codebook, ee_ws, out, mp, 0, R, n_e, (hipStream_t)stream) ? IVG_ERR_HIP : IVG_OK;
 }
 
-int ivg_op_add_rmsnorm(void* x, const float* part, int splits, const float* w, void* out, int M, int H, float eps, int dtype, ivg_stream stream) {
-  return launch_add_rmsnorm(x, H, part, splits, w, out, M, H, eps, (DType)dtype, (hipStream_t)stream) ? IVG_ERR_HIP : IVG_OK;
+int ivg_op_add_rmsnorm(void* x, const float* w, void* out, int M, int H, float eps, int dtype, ivg_stream stream) {
+  return launch_add_rmsnorm(x, H, w, out, M, H, eps, (DType)dtype, (hipStream_t)stream) ? IVG_ERR_HIP : IVG_OK;
 }
 
 int ivg_op_conv_in(const void* video, int video_dtype, const float* w, const float* bias, void* Y, int dtype, int N, int per, int T_total, int t0,

@@ -390,14 +390,13 @@ static int launch_dg_t(const DgDev& d, int MF, int FN, int waves, hipStream_t st
 // rows of W one workgroup owns for this GEMM (what a predecessor's cache warm-up mirrors): the pick table, else the default tile
 int dgemm_w_rows_per_block(const SkinnyArgs& a, DType dtype) {
   const int es = dtype == BF16 ? 2 : 4;
-  if (a.splits > 1 || ((long)a.K * es) % 128 != 0) return 0;
+  if (((long)a.K * es) % 128 != 0) return 0;
   for (const DgPick& k : kDgPicks) if (k.kbytes == a.K * es && k.N == a.N) return 16 * k.fn;
   return 16 * ((a.flags & IG_GLU) ? 2 : 1);
 }
 
 // -1: shape not covered (caller falls back to skinny.hip); otherwise a hipError_t
 int launch_dgemm(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
-  if (!sw().dg || a.splits > 1) return -1;   // IVG_DG=0: first-generation kernel only (A/B runs)
   const int es = dtype == BF16 ? 2 : 4;
   if (a.M <= 0 || a.N <= 0 || a.M > 128) return -1;
   if (((long)a.K * es) % 128 != 0 || ((long)a.ldx * es) % 16 != 0 || ((long)a.ldw * es) % 16 != 0) return -1;
@@ -463,6 +462,19 @@ int launch_dgemm(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
   else rc = lgv == 3 ? launch_dg_t<float, 3>(d, MF, FN, waves, stream) : lgv == 2 ? launch_dg_t<float, 2>(d, MF, FN, waves, stream)
                                                                                  : launch_dg_t<float, 1>(d, MF, FN, waves, stream);
   return rc;
+}
+
+// Decode-step GEMM dispatcher (the name survives from the first-generation kernel, removed in round 4: no shape of a released model
+// reached it any more): third generation (dgemm3.hip) wherever it covers the shape, else the second (this file).  Coverage is a
+// function of (K, N, dtype, flags) only, so a GEMM of the model runs on the same kernel -- the same K-summation order -- whatever
+// the batch.  A shape neither covers (K bytes not a multiple of 128, M > 128, unaligned operands) fails loudly.
+int launch_skinny(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
+  if (a.M <= 0 || a.N <= 0) return 0;
+  int rc = launch_dgemm3(a, dtype, stream);
+  if (rc != -1) return rc;
+  rc = launch_dgemm(a, dtype, stream);
+  if (rc != -1) return rc;
+  return (int)hipErrorInvalidValue;
 }
 
 }  // namespace ivg

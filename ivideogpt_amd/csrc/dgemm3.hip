@@ -442,7 +442,7 @@ struct Dg3Plan { int mf, fn, waves, klw, ring; unsigned wave_bytes; int wr; };
 // depend on (K, N, dtype, flags) only; the batch size only picks MF (which rows share a workgroup -- never a sum order).
 static bool dg3_plan(const SkinnyArgs& a, DType dtype, Dg3Plan& pl) {
   const int es = dtype == BF16 ? 2 : 4;
-  if (a.splits > 1 || a.M <= 0 || a.N <= 0 || a.M > 128) return false;
+  if (a.M <= 0 || a.N <= 0 || a.M > 128) return false;
   if (((long)a.K * es) % 128 != 0 || ((long)a.ldx * es) % 16 != 0 || ((long)a.ldw * es) % 16 != 0) return false;
   if (((uintptr_t)a.X & 15) || ((uintptr_t)a.W & 15)) return false;
   if ((long)a.N * a.ldw * es >= (1L << 31) || (long)a.M * a.ldx * es >= (1L << 31)) return false;   // 32-bit per-lane offsets

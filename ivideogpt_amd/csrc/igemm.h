@@ -66,13 +66,11 @@ int conv3x3_gn_chunks_bound(int Hout, int Wout, int N);
 
 // Skinny GEMM for the autoregressive decode steps (M <= 128 rows, weights streamed once):
 //   Y[m][n] = epi( sum_k X[m][k] * W[n][k] ),  X row stride ldx, W row stride ldw.
-// splits > 1: writes fp32 partials P[s][m][n] (consumer sums them in fixed order); no epilogue.
 struct SkinnyArgs {
   const void* X = nullptr;
   const void* W = nullptr;
-  void* Y = nullptr;       // T, or fp32 when IG_OUT_F32 / splits > 1
+  void* Y = nullptr;       // T, or fp32 when IG_OUT_F32
   int M = 0, N = 0, K = 0, ldx = 0, ldw = 0, ldy = 0;
-  int splits = 1;
   int flags = 0;           // IG_GLU | IG_OUT_F32 | IG_RESIDUAL (Y += ..., in place) | SK_NORM
   float eps = 1e-6f;       // SK_NORM
   int* bump = nullptr;     // optional pair of device ints incremented once at the end (StepState advance)
@@ -90,8 +88,8 @@ struct SkinnyArgs {
   int next_tiles = 0;
 };
 #define IVG_GEMM_PROF_SLOTS 8
-int launch_skinny(const SkinnyArgs& a, DType dtype, hipStream_t stream);
-// dgemm.hip: the same contract with the activations staged as whole cache lines; -1 when the shape is not covered
+int launch_skinny(const SkinnyArgs& a, DType dtype, hipStream_t stream);   // dispatcher: dgemm3.hip, else dgemm.hip (error: neither covers the shape)
+// dgemm.hip: second-generation kernel, activations staged as whole cache lines; -1 when the shape is not covered
 int launch_dgemm(const SkinnyArgs& a, DType dtype, hipStream_t stream);
 // dgemm3.hip: third generation (K over up to 16 waves, one barrier, cache warm-up of the next launch's weights); -1 when not covered
 int launch_dgemm3(const SkinnyArgs& a, DType dtype, hipStream_t stream);

@@ -205,27 +205,14 @@ int launch_groupnorm_apply(const void* X, void* Y, const void* part, int nchunks
 // independent (the decode step is latency-bound: M = batch rows only).  x (T) is updated in place when split-K
 // partials are given (fixed order s = 0..S-1), out = rmsnorm(x) * w.
 template <typename T>
-__global__ __launch_bounds__(256) void add_rmsnorm_kernel(T* __restrict__ x, long xs, const float* __restrict__ part, int splits,
-                                                          const float* __restrict__ w, T* __restrict__ out, int M, int H,
-                                                          float eps) {
+__global__ __launch_bounds__(256) void add_rmsnorm_kernel(T* __restrict__ x, long xs, const float* __restrict__ w, T* __restrict__ out,
+                                                          int M, int H, float eps) {
   __shared__ float red[4];
   const int row = blockIdx.x, tid = threadIdx.x;
   T* xr = x + (long)row * xs;
   float f[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { const int c = tid + 256 * i; f[i] = c < H ? to_f32(xr[c]) : 0.f; }
-  if (part) {
-    for (int s = 0; s < splits; ++s) {
-      const float* pr = part + ((long)s * M + row) * H;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { const int c = tid + 256 * i; if (c < H) f[i] += pr[c]; }
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int c = tid + 256 * i;
-      if (c < H) { const T r = from_f32<T>(f[i]); xr[c] = r; f[i] = to_f32(r); }
-    }
-  }
   float ss = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) ss = fmaf(f[i], f[i], ss);
@@ -246,15 +233,14 @@ __global__ __launch_bounds__(256) void add_rmsnorm_kernel(T* __restrict__ x, lon
   }
 }
 
-int launch_add_rmsnorm(void* x, long x_stride, const float* part, int splits, const float* w, void* out, int M, int H, float eps,
-                       DType dt, hipStream_t st) {
+int launch_add_rmsnorm(void* x, long x_stride, const float* w, void* out, int M, int H, float eps, DType dt, hipStream_t st) {
   if (H > 2048) return (int)hipErrorInvalidValue;
   if (M <= 0) return 0;
   dim3 g(M);
   if (dt == BF16)
-    hipLaunchKernelGGL(add_rmsnorm_kernel<bf16_t>, g, dim3(256), 0, st, (bf16_t*)x, x_stride, part, splits, w, (bf16_t*)out, M, H, eps);
+    hipLaunchKernelGGL(add_rmsnorm_kernel<bf16_t>, g, dim3(256), 0, st, (bf16_t*)x, x_stride, w, (bf16_t*)out, M, H, eps);
   else
-    hipLaunchKernelGGL(add_rmsnorm_kernel<float>, g, dim3(256), 0, st, (float*)x, x_stride, part, splits, w, (float*)out, M, H, eps);
+    hipLaunchKernelGGL(add_rmsnorm_kernel<float>, g, dim3(256), 0, st, (float*)x, x_stride, w, (float*)out, M, H, eps);
   return (int)hipGetLastError();
 }
 

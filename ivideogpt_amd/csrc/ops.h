@@ -18,9 +18,8 @@ int launch_gn_coef(const void* part, int nchunks, const float* gamma, const floa
 // the apply half alone, with statistics produced by a conv3x3 epilogue (IgemmArgs::gn_part): double2 [N][nchunks][groups]
 int launch_groupnorm_apply(const void* X, void* Y, const void* part, int nchunks, const float* gamma, const float* beta, const float* pos,
                            int N, int P, int C, int groups, float eps, int silu, DType dt, hipStream_t st);
-// x[M][H] += sum_s part[s][M][H] (in place, T);  out = rmsnorm(x) * w   (out may be null: residual update only)
-int launch_add_rmsnorm(void* x, long x_stride, const float* part, int splits, const float* w, void* out, int M, int H, float eps,
-                       DType dt, hipStream_t st);
+// out = rmsnorm(x) * w  (rows of x at stride x_stride; HF semantics: normalised row rounded to T before the weight)
+int launch_add_rmsnorm(void* x, long x_stride, const float* w, void* out, int M, int H, float eps, DType dt, hipStream_t st);
 int launch_softmax(const float* S, void* Pm, long rows, int Lq, int Lk, int lds, int ldp, int causal, DType dt, hipStream_t st);
 
 // ---- conv_small.hip

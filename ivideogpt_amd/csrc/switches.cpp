@@ -18,7 +18,6 @@ static Switches read_env() {
   s.gemm256 = env_int("IVG_GEMM256", 1) != 0;
   s.g256_line = env_int("IVG_G256_LINE", 1) != 0;
   s.dg3 = env_int("IVG_DG3", 1) != 0;
-  s.dg = env_int("IVG_DG", 1) != 0;
   s.flash_prefill = env_int("IVG_FLASH_PREFILL", 1) != 0;
   s.flash_xatt = env_int("IVG_FLASH_XATT", 1) != 0;
   s.gn_fuse = env_int("IVG_GN_FUSE", 1) != 0;

@@ -9,7 +9,6 @@
 //   IVG_GEMM256              1        0: large dense GEMMs on the generic implicit GEMM
 //   IVG_G256_LINE            1        0: the 64-byte-row gemm256 kernel everywhere (1: whole-line kernel where K % 64 == 0)
 //   IVG_DG3                  1        0: decode GEMMs on the second-generation kernel (dgemm.hip)
-//   IVG_DG                   1        0: decode GEMMs on the first-generation kernel (skinny.hip) -- with IVG_DG3=0
 //   IVG_FLASH_PREFILL        1        0: prompt attention as score GEMM + softmax + P.V GEMM (what the fp32 engine mode runs)
 //   IVG_FLASH_XATT           1        0: tokenizer attention as score GEMM + softmax + P.V GEMM
 //   IVG_GN_FUSE              1        0: every GroupNorm computes its own statistics (1: reduced by the producing conv3x3's epilogue)
@@ -26,7 +25,7 @@
 namespace ivg {
 
 struct Switches {
-  int conv3x3 = 1, gemm256 = 1, g256_line = 1, dg3 = 1, dg = 1, flash_prefill = 1, flash_xatt = 1, gn_fuse = 1, gn_apply_fuse = 1, x3 = 1;
+  int conv3x3 = 1, gemm256 = 1, g256_line = 1, dg3 = 1, flash_prefill = 1, flash_xatt = 1, gn_fuse = 1, gn_apply_fuse = 1, x3 = 1;
   int graph = 0, dg3_warm = 1, conv_cap = 0, decode_lds_kb = 160;
 };
 

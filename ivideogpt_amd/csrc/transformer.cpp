@@ -107,7 +107,7 @@ int Run::prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const voi
   }
   for (int l = 0; l < c.num_layers; ++l) {
     const LayerW& w = e->layers[l];
-    if (!planning) CK(launch_add_rmsnorm(x, H, nullptr, 0, e->ones, xn, (int)M, H, c.rms_norm_eps, dt, st));
+    if (!planning) CK(launch_add_rmsnorm(x, H, e->ones, xn, (int)M, H, c.rms_norm_eps, dt, st));
     ConvW wq; wq.w = w.wqkv; wq.cin = H; wq.cout = 3 * H;
     IVG_TRY(linear(dt, xn, M, wq, qkv, nullptr, 0, 0));
     if (!planning)
@@ -141,7 +141,7 @@ int Run::prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const voi
     }
     ConvW wo; wo.w = w.wo; wo.cin = H; wo.cout = H;
     IVG_TRY(linear(dt, attn, M, wo, x, x, 0, 0));  // in-place residual
-    if (!planning) CK(launch_add_rmsnorm(x, H, nullptr, 0, e->ones, xn, (int)M, H, c.rms_norm_eps, dt, st));
+    if (!planning) CK(launch_add_rmsnorm(x, H, e->ones, xn, (int)M, H, c.rms_norm_eps, dt, st));
     {  // act = silu(gate) * up   (weights packed [16 gate | 16 up] per 32 rows)
       IgemmArgs g;
       g.X = xn; g.W = w.wgu; g.Y = act;
@@ -157,7 +157,7 @@ int Run::prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const voi
     CK(launch_final_hidden(x, e->final_norm, hidden_all, (int)M, H, c.rms_norm_eps, dt, st));
   }
   if (logits_all) {
-    if (!planning) CK(launch_add_rmsnorm(x, H, nullptr, 0, e->ones, xn, (int)M, H, c.rms_norm_eps, dt, st));
+    if (!planning) CK(launch_add_rmsnorm(x, H, e->ones, xn, (int)M, H, c.rms_norm_eps, dt, st));
     ConvW wl; wl.w = e->lm_head; wl.cin = H; wl.cout = V;
     IVG_TRY(linear(dt, xn, M, wl, logits_all, nullptr, 0, 1));
   }
@@ -166,7 +166,7 @@ int Run::prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const voi
     // to its per-position cross-entropy before the next one overwrites it
     const long Rc = std::min<long>(M, 4096);
     float* chunk = (float*)e->ws.alloc((size_t)Rc * V * 4);
-    if (!planning && !logits_all) CK(launch_add_rmsnorm(x, H, nullptr, 0, e->ones, xn, (int)M, H, c.rms_norm_eps, dt, st));
+    if (!planning && !logits_all) CK(launch_add_rmsnorm(x, H, e->ones, xn, (int)M, H, c.rms_norm_eps, dt, st));
     ConvW wl; wl.w = e->lm_head; wl.cin = H; wl.cout = V;
     for (long r0 = 0; r0 < M; r0 += Rc) {
       const long rows = std::min(Rc, M - r0);

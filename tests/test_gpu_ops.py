@@ -196,22 +196,18 @@ def test_skinny_gemm(dt, M):
     ref = x.double() @ w.double().T
     xd, wd = x.to(DEV, tdt(dt)), w.to(DEV, tdt(dt))
     Y = torch.full((M, N), float("nan"), device=DEV, dtype=tdt(dt))
-    assert l.ivg_op_skinny(P(xd), P(wd), P(Y), M, N, K, K, K, N, 1, 0, code(dt), stream()) == 0
+    assert l.ivg_op_skinny(P(xd), P(wd), P(Y), M, N, K, K, K, N, 0, code(dt), stream()) == 0
     torch.cuda.synchronize()
     assert rel_err(Y.float(), ref) < TOL[dt]
     Yf = torch.full((M, N), float("nan"), device=DEV)
-    assert l.ivg_op_skinny(P(xd), P(wd), P(Yf), M, N, K, K, K, N, 1, 32, code(dt), stream()) == 0
+    assert l.ivg_op_skinny(P(xd), P(wd), P(Yf), M, N, K, K, K, N, 32, code(dt), stream()) == 0
     torch.cuda.synchronize()
     assert rel_err(Yf, ref) < 2e-5  # fp32 output: only accumulation-order error
-    parts = torch.full((2, M, N), float("nan"), device=DEV)
-    assert l.ivg_op_skinny(P(xd), P(wd), P(parts), M, N, K, K, K, N, 2, 32, code(dt), stream()) == 0
-    torch.cuda.synchronize()
-    assert rel_err(parts.sum(0), ref) < 2e-5
     gate, up = q(torch.randn(I, K, generator=g) / K ** 0.5, dt), q(torch.randn(I, K, generator=g) / K ** 0.5, dt)
     wgu = torch.stack([gate.view(I // 16, 16, K), up.view(I // 16, 16, K)], 1).reshape(2 * I, K).contiguous().to(DEV, tdt(dt))
     refg = F.silu(x.double() @ gate.double().T) * (x.double() @ up.double().T)
     Yg = torch.full((M, I), float("nan"), device=DEV, dtype=tdt(dt))
-    assert l.ivg_op_skinny(P(xd), P(wgu), P(Yg), M, 2 * I, K, K, K, I, 1, 16, code(dt), stream()) == 0
+    assert l.ivg_op_skinny(P(xd), P(wgu), P(Yg), M, 2 * I, K, K, K, I, 16, code(dt), stream()) == 0
     torch.cuda.synchronize()
     assert rel_err(Yg.float(), refg) < TOL[dt]
 
@@ -293,22 +289,20 @@ def test_vq_argmin_matches_cdist_argmin():
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
-def test_add_rmsnorm(dt):
+def test_rmsnorm_rows(dt):
+    """HF LlamaRMSNorm of the prompt pass: x * rsqrt(mean(x^2) + eps) rounded to the model dtype, then * weight."""
     L, l = lib()
     g = torch.Generator().manual_seed(5)
-    M, H, S_ = 37, 768, 3
+    M, H = 37, 768
     x, w = q(torch.randn(M, H, generator=g), dt), torch.randn(H, generator=g)
-    part = torch.randn(S_, M, H, generator=g)
-    xs = q(((x + part[0]) + part[1]) + part[2], dt)   # fixed summation order s = 0, 1, 2
-    xf = xs.double()
+    xf = x.double()
     nrm = q((xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).float(), dt)
     ref = w.double() * nrm.double()
     X = x.to(DEV, tdt(dt))
     out = torch.full((M, H), float("nan"), device=DEV, dtype=tdt(dt))
-    pd, wd = part.to(DEV), w.to(DEV)
-    assert l.ivg_op_add_rmsnorm(P(X), P(pd), S_, P(wd), P(out), M, H, 1e-6, code(dt), stream()) == 0
+    assert l.ivg_op_add_rmsnorm(P(X), P(w.to(DEV)), P(out), M, H, 1e-6, code(dt), stream()) == 0
     torch.cuda.synchronize()
-    assert rel_err(X.float(), xs) < (1e-6 if dt == "fp32" else 1e-2)
+    assert torch.equal(X.float().cpu(), x), "the input rows are read only"
     assert rel_err(out.float(), ref) < (1e-5 if dt == "fp32" else 1.5e-2)
 
 
@@ -413,7 +407,7 @@ def test_skinny_gemm_lm_head_shape_with_ragged_vocab(M):
     ref = x.double() @ w.double().T
     xd, wd = x.to(DEV, torch.bfloat16), w.to(DEV, torch.bfloat16)
     Yf = torch.full((M, N), float("nan"), device=DEV)
-    assert l.ivg_op_skinny(P(xd), P(wd), P(Yf), M, N, K, K, K, N, 1, 32, code("bf16"), stream()) == 0
+    assert l.ivg_op_skinny(P(xd), P(wd), P(Yf), M, N, K, K, K, N, 32, code("bf16"), stream()) == 0
     torch.cuda.synchronize()
     assert torch.isfinite(Yf).all() and rel_err(Yf, ref) < 2e-5
     assert rel_err(Yf[:, -2:], ref[:, -2:]) < 2e-5
@@ -426,16 +420,15 @@ DECODE_SHAPES = [  # (K, N, flags): every decode-step GEMM of the small (768 / 3
 ]
 
 
-@pytest.mark.parametrize("gen", ["gen3", "gen2", "gen1"])
+@pytest.mark.parametrize("gen", ["gen3", "gen2"])
 @pytest.mark.parametrize("dt", ["bf16", "fp32"])
 @pytest.mark.parametrize("K,N,mode", DECODE_SHAPES)
 def test_decode_gemm_model_shapes(K, N, mode, dt, gen, switches):
     """The decode-step GEMMs at the shapes the rollouts run (BASELINE configs 2 and 5), with their fused epilogues -- RMSNorm row
     scale, in-place residual, SiLU(gate) * up, fp32 logits -- against fp64, for the third-generation kernel (dgemm3.hip: K over up
-    to 16 waves, one barrier; the default), the second (IVG_DG3=0, dgemm.hip: activations as whole lines through LDS) and the
-    first (IVG_DG=0, skinny.hip)."""
+    to 16 waves, one barrier; the default) and the second (IVG_DG3=0, dgemm.hip: activations as whole lines through LDS)."""
     L, l = lib()
-    switches(IVG_DG3="0" if gen in ("gen2", "gen1") else None, IVG_DG="0" if gen == "gen1" else None, IVG_DECODE_LDS_KB=None)
+    switches(IVG_DG3="0" if gen == "gen2" else None, IVG_DECODE_LDS_KB=None)
     g = torch.Generator().manual_seed(K + N)
     for M in (64, 37, 128):
         x = q(torch.randn(M, K, generator=g) * 1.7, dt)
@@ -466,7 +459,7 @@ def test_decode_gemm_model_shapes(K, N, mode, dt, gen, switches):
             flags |= 4
         else:
             Y = torch.full((M, ldy), float("nan"), device=DEV, dtype=out_dt)
-        assert l.ivg_op_skinny(P(xd), P(wd), P(Y), M, N, K, K, K, ldy, 1, flags, code(dt), stream()) == 0
+        assert l.ivg_op_skinny(P(xd), P(wd), P(Y), M, N, K, K, K, ldy, flags, code(dt), stream()) == 0
         torch.cuda.synchronize()
         assert torch.isfinite(Y.float()).all()
         tol = 2e-5 if (dt == "fp32" or mode == "norm_f32") else TOL[dt]

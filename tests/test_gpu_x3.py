@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import llama_fixture, oracle_llama, oracle_tokenizer, tokenizer_fixture
+from helpers import assert_sampled_rollout_matches, llama_fixture, oracle_llama, oracle_tokenizer, tokenizer_fixture
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -99,8 +99,10 @@ def test_x3_full_width_llama_logits_vs_oracle():
 @pytest.mark.parametrize("width", ["small", "medium"])
 def test_x3_decode_path_at_released_widths_vs_oracle(width):
     """The x3 DECODE path (dgemm3.hip X3: both fragments split in registers) at the released transformer widths: greedy rollouts from
-    a 514-token prompt through ``generate`` equal the oracle's token for token, sampled ones with the same uniforms too; rows do not
-    depend on their batch-mates (64-row batch vs shards)."""
+    a 514-token prompt through ``generate`` equal the oracle's token for token; sampled ones with the same uniforms equal it up to
+    near-ties of the inverse CDF (a draw within what the 1e-3 logits bar allows of a boundary may fall to the neighbouring kept
+    token: tests/helpers.py assert_sampled_rollout_matches, the rule the fp32 mode's long rollouts are held to); rows do not depend
+    on their batch-mates (64-row batch vs shards)."""
     from oracle.llama import generate_cached
     from ivideogpt_amd import weights as W
     cfg = dict(W.LLAMA_SMALL if width == "small" else W.LLAMA_MEDIUM)
@@ -118,7 +120,8 @@ def test_x3_decode_path_at_released_widths_vs_oracle(width):
     assert torch.equal(out_g, ref_g), f"greedy: {(out_g != ref_g).sum().item()} of {2 * n_new} tokens differ from the oracle"
     out_s = m.generate(prompt.to(DEV), do_sample=True, top_k=100, max_new_tokens=n_new, uniforms=u.to(DEV)).cpu()
     ref_s = generate_cached(ora, prompt, n_new, top_k=100, uniforms=u)
-    assert torch.equal(out_s, ref_s), f"sampled: {(out_s != ref_s).sum().item()} of {2 * n_new} tokens differ from the oracle"
+    diverged = assert_sampled_rollout_matches(out_s, ref_s, ora, u, 100, prompt.shape[1], what=f"x3 {width} sampled rollout")
+    RECORD[f"sampled_{width}"] = f"{diverged} of 2 rows left the oracle's rollout at a near-tie of the inverse CDF (margin < 3e-3)"
     p64 = torch.randint(0, 16384, (64, 40), generator=g)
     u64 = torch.rand(64, 12, generator=g)
     full = m.generate(p64.to(DEV), do_sample=True, top_k=100, max_new_tokens=12, uniforms=u64.to(DEV)).cpu()
