@@ -513,19 +513,19 @@ def main():
             assert torch.isfinite(fr_a).all()
             alt[key] = {"value": B * F * n_a / e_a, "unit": "predicted frames/s", "ms_per_step": e_a / n_a * 1e3, "ms_per_step_median": median(t_a) * 1e3,
                         "steps": n_a, "lanes": 1, "arith": {"encode": a.encode_dtype, "rollout": llm, "decode": dec}, "note": note}
-            if key == "compliant_mode" and a.lanes > 1:   # the same mode with the headline's batches in flight
+            if key == "compliant_mode" and a.lanes > 1:   # the same mode with two batches in flight (more do not pay with fp32 tensors: r04_lanes.txt)
+                n_x3 = min(a.lanes, 2)
                 lanes_a = [dict(tok=tok_a, model=model_a, pixels=pixels, actions=actions, gen=sample_gen, stream=main_stream)]
-                for i in range(1, a.lanes):
+                for i in range(1, n_x3):
                     gi = torch.Generator(device=dev).manual_seed(1000 + rank + 7919 * i)
                     lanes_a.append(dict(tok=tok_a.replica(), model=model_a.replica(),
                                         pixels=torch.rand(B, T, 3, a.res, a.res, device=dev, generator=gi).to(torch.bfloat16),
                                         actions=torch.randn(B, T, a.action_dim, device=dev, generator=gi) if a.action_dim else None,
                                         gen=torch.Generator(device=dev).manual_seed(2000 + rank + 7919 * i), stream=torch.cuda.Stream(device=dev)))
-                n_l = 2 * a.lanes
-                with switches.override(**({} if a.lane_switches == "none" else switches.BATCHES_IN_FLIGHT)):
-                    e_l, fl, _ = measure_lanes(lanes_a, ctx, F, a.greedy, n_l, 1, parallel.PhaseGate() if a.conv_gate else None)
+                n_l = 3 * n_x3
+                e_l, fl, _ = measure_lanes(lanes_a, ctx, F, a.greedy, n_l, 1, parallel.PhaseGate() if a.conv_gate else None)
                 assert all(torch.isfinite(x).all() for x in fl)
-                alt[key]["lanes_in_flight"] = {"lanes": a.lanes, "value": B * F * n_l / e_l, "ms_per_step": e_l / n_l * 1e3, "steps": n_l}
+                alt[key]["lanes_in_flight"] = {"lanes": n_x3, "value": B * F * n_l / e_l, "ms_per_step": e_l / n_l * 1e3, "steps": n_l}
                 del lanes_a
             del model_a, tok_a
             torch.cuda.empty_cache()

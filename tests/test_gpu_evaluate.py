@@ -102,13 +102,22 @@ def test_eval_cli_runs_full_width_with_forced_collectives():
     assert math.isfinite(logs["eval/eval_loss"]) and 0 < logs["eval/ssim"] <= 1 and logs["eval/psnr"] > 0
 
 
-def test_two_engines_in_flight_equal_sequential_runs():
-    """bench.py --lanes 2 keeps two batches in flight on one GPU: two engine sets, two host threads, two HIP streams.  libivg has no
+@pytest.mark.parametrize("profile", ["default", "batches_in_flight"])
+def test_two_engines_in_flight_equal_sequential_runs(profile):
+    """bench.py --lanes keeps several batches in flight on one GPU: one engine set, host thread and HIP stream each.  libivg has no
     global mutable state on the data path (an engine handle is not thread-safe, two handles are independent): the frames and tokens
-    of two pipelines running CONCURRENTLY must equal, bit for bit, those of the same pipelines run one after the other."""
+    of two pipelines running CONCURRENTLY must equal, bit for bit, those of the same pipelines run one after the other -- with the
+    library's default switches and with the small decode-GEMM footprint bench.py sets while its lanes run
+    (ivideogpt_amd.switches.BATCHES_IN_FLIGHT; the second engine of each pair is a replica() over the first one's weights in HBM)."""
+    import contextlib
     import threading
-    from ivideogpt_amd import CompressiveVQModel, LlamaForCausalLM, weights as W
+    from ivideogpt_amd import CompressiveVQModel, LlamaForCausalLM, switches, weights as W
     from ivideogpt_amd.pipeline import predict_frames
+    with (switches.override(**switches.BATCHES_IN_FLIGHT) if profile == "batches_in_flight" else contextlib.nullcontext()):
+        _two_engines_in_flight(CompressiveVQModel, LlamaForCausalLM, W, predict_frames, threading, replica=profile == "batches_in_flight")
+
+
+def _two_engines_in_flight(CompressiveVQModel, LlamaForCausalLM, W, predict_frames, threading, replica):
     tcfg = W.tokenizer_config(**TOK_CFG)
     tsd = W.random_tokenizer_state_dict(tcfg, 91, codebook_std=0.4)
     lsd = W.random_llama_state_dict(LLM_CFG, 92)
@@ -116,8 +125,11 @@ def test_two_engines_in_flight_equal_sequential_runs():
     g = torch.Generator().manual_seed(93)
     sets = []
     for i in range(2):
-        tok = CompressiveVQModel(tcfg, tsd, encode_dtype="fp32", decode_dtype="bf16").to(DEV)
-        llm = LlamaForCausalLM(dict(LLM_CFG), lsd, dtype="bf16").to(DEV)
+        if replica and sets:
+            tok, llm = sets[0][0].replica(), sets[0][1].replica()
+        else:
+            tok = CompressiveVQModel(tcfg, tsd, encode_dtype="fp32", decode_dtype="bf16").to(DEV)
+            llm = LlamaForCausalLM(dict(LLM_CFG), lsd, dtype="bf16").to(DEV)
         px = torch.rand(6, ctx + F_, 3, 64, 64, generator=g).to(DEV)
         u = torch.rand(6, 17 * F_ - 1, generator=g).to(DEV)
         sets.append((tok, llm, px, u, torch.cuda.Stream(device=DEV)))
@@ -143,6 +155,7 @@ def test_two_engines_in_flight_equal_sequential_runs():
 
 def test_bench_two_lanes_small_run():
     """``bench.py --lanes 2`` end to end at a small shape: one JSON line with both figures (two batches in flight / one)."""
+    # (custom shapes: no other_configs block; the fp32 / x3 modes are skipped explicitly)
     import json
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--lanes", "2", "--batch", "4", "--frames", "6", "--steps", "4", "--warmup", "1",
                         "--no-cpu-baseline", "--no-fp32-mode", "--no-profile"], capture_output=True, text=True, timeout=900,
