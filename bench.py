@@ -257,7 +257,7 @@ def measure(tok, model, pixels, actions, ctx, F, greedy, gen, steps, warmup, per
     return (el, frames, rows, step, times) if per_step else (el, frames, rows, step)
 
 
-def measure_lanes(lanes, ctx, F, greedy, steps, warmup, gate=None):
+def measure_lanes(lanes, ctx, F, greedy, steps, warmup, gate=None, gatherer=None):
     """Several batches in flight on one GPU: lane i = its own engines (KV cache, workspace), its own resident batch, its own HIP
     stream and host thread; the `steps` timed steps are dealt round-robin to the lanes (step g -> lane g % L) and run concurrently --
     the MFMA-bound convolutions of one batch's encode / decode fill the matrix pipes the latency- and HBM-bound rollout of the other
@@ -273,7 +273,10 @@ def measure_lanes(lanes, ctx, F, greedy, steps, warmup, gate=None):
         ln = lanes[i]
         frames, rows = predict_frames(ln["tok"], ln["model"], ln["pixels"], ctx, F, actions=ln["actions"], do_sample=not greedy, top_k=100,
                                       generator=ln["gen"], conv_gate=gate, metrics_of=ln["pixels"], rollout_stream=ln.get("rollout_stream"))
-        rows = turn.run(g, lambda: parallel.gather_metric_rows_even(rows))
+        if gatherer is not None:     # the collective is issued by the gatherer's thread on its own stream, in step order
+            gatherer.submit(g, rows)
+        else:
+            rows = turn.run(g, lambda: parallel.gather_metric_rows_even(rows))
         last[i] = (frames, rows)
 
     def lane_body(i, first, n):
@@ -286,21 +289,34 @@ def measure_lanes(lanes, ctx, F, greedy, steps, warmup, gate=None):
             errors.append(e)
             turn.abort()
 
+    gathered = {}
+
     def run(n_steps):
         turn.reset(0)
+        if gatherer is not None:
+            gatherer.start(0)
         ths = [threading.Thread(target=lane_body, args=(i, i, len(range(i, n_steps, L)))) for i in range(L)]
         for t in ths:
             t.start()
         for t in ths:
             t.join()
         if errors:
+            if gatherer is not None:
+                gatherer.abort()
             raise errors[0]
+        if gatherer is not None:
+            gathered.clear()
+            gathered.update(gatherer.finish(n_steps))
 
     for i in range(L):            # warm-up lane by lane on the main thread (engine build, one-time attribute setup), then together
         for _ in range(max(1, warmup)):
             with torch.cuda.stream(lanes[i]["stream"]):
                 turn.reset(0)
+                if gatherer is not None:
+                    gatherer.start(0)
                 lane_step(i, 0)
+                if gatherer is not None:
+                    gatherer.finish(1)
     torch.cuda.synchronize()
     run(L)
     parallel.barrier()
@@ -309,7 +325,11 @@ def measure_lanes(lanes, ctx, F, greedy, steps, warmup, gate=None):
     run(steps)
     torch.cuda.synchronize()
     parallel.barrier()
-    return time.perf_counter() - t0, [x[0] for x in last], [x[1] for x in last]
+    el = time.perf_counter() - t0
+    if gatherer is not None:      # the gathered rows of the lanes' last steps
+        rows_last = [gathered[max(g for g in gathered if g % L == i)] if any(g % L == i for g in gathered) else last[i][1] for i in range(L)]
+        return el, [x[0] for x in last], rows_last
+    return el, [x[0] for x in last], [x[1] for x in last]
 
 
 def main():
@@ -342,6 +362,9 @@ def main():
                                                          "(1: one batch at a time, the per-batch latency case)")
     ap.add_argument("--conv-gate", type=int, default=0, help="1: at most one lane's convolution phase (encode / decode) on the device at a time "
                                                               "(parallel.PhaseGate), rollouts of the other lanes beside it")
+    ap.add_argument("--gather-mode", default="thread", choices=["thread", "lanes"],
+                    help="several lanes + a process group: the per-step metric all-gather is issued by one thread on its own stream in step "
+                         "order (parallel.OrderedGatherer; default) or by the lanes themselves in ticket order (parallel.Turnstile; A/B)")
     ap.add_argument("--cu-split", type=int, default=0, help="experiment: CUs (of 256) given to the convolution phases of all lanes; the rollouts "
                                                              "run on the others (CU-masked streams); 0: off")
     a = ap.parse_args()
@@ -387,6 +410,8 @@ def main():
     # create their dedicated one.  Streams are dealt round-robin over the (4) hardware queues in creation order -- a stream nobody
     # uses still takes a slot, and two lanes whose streams share a hardware queue run one after the other.
     main_stream = torch.cuda.Stream(device=dev)
+    lane_streams = [main_stream] + [torch.cuda.Stream(device=dev) for _ in range(max(0, a.lanes - 1))]   # all of them NOW, next to each other
+    gatherer = parallel.OrderedGatherer(dev) if (a.lanes > 1 and torch.distributed.is_initialized()) else None   # (+ its stream)
     main_stream.wait_stream(torch.cuda.current_stream(dev))   # (the resident inputs were written on the default stream)
     torch.cuda.set_stream(main_stream)
 
@@ -431,7 +456,7 @@ def main():
             gi = torch.Generator(device=dev).manual_seed(1000 + rank + 7919 * i)
             lanes.append(dict(tok=tok_i, model=model_i, pixels=torch.rand(B, T, 3, a.res, a.res, device=dev, generator=gi).to(torch.bfloat16),
                               actions=torch.randn(B, T, a.action_dim, device=dev, generator=gi) if a.action_dim else None,
-                              gen=torch.Generator(device=dev).manual_seed(2000 + rank + 7919 * i), stream=torch.cuda.Stream(device=dev)))
+                              gen=torch.Generator(device=dev).manual_seed(2000 + rank + 7919 * i), stream=lane_streams[i]))
         gate = parallel.PhaseGate() if a.conv_gate else None
         if a.cu_split:   # experiment: convolution phases on `cu_split` CUs, rollouts on the other 256 - cu_split (CU-masked streams)
             inter = os.environ.get("IVG_CU_SPLIT_MODE", "block") == "interleave"
@@ -446,7 +471,8 @@ def main():
                 ln["rollout_stream"] = parallel.cu_masked_stream(dev, roll_bits)
         # several batches in flight: decode GEMMs with a small LDS footprint, so that the kernels of the other batches fit beside them
         with switches.override(**({} if a.lane_switches == "none" else switches.BATCHES_IN_FLIGHT)):
-            my_elapsed, lane_frames, lane_rows = measure_lanes(lanes, ctx, F, a.greedy, a.steps, a.warmup, gate)
+            my_elapsed, lane_frames, lane_rows = measure_lanes(lanes, ctx, F, a.greedy, a.steps, a.warmup, gate,
+                                                               gatherer if a.gather_mode == "thread" else None)
         for fr, rw in zip(lane_frames, lane_rows):
             assert torch.isfinite(fr).all() and rw.shape == (global_b, 3) and torch.isfinite(rw).all()
         steps_timed = a.steps
@@ -521,7 +547,7 @@ def main():
                     lanes_a.append(dict(tok=tok_a.replica(), model=model_a.replica(),
                                         pixels=torch.rand(B, T, 3, a.res, a.res, device=dev, generator=gi).to(torch.bfloat16),
                                         actions=torch.randn(B, T, a.action_dim, device=dev, generator=gi) if a.action_dim else None,
-                                        gen=torch.Generator(device=dev).manual_seed(2000 + rank + 7919 * i), stream=torch.cuda.Stream(device=dev)))
+                                        gen=torch.Generator(device=dev).manual_seed(2000 + rank + 7919 * i), stream=lane_streams[i]))
                 n_l = 3 * n_x3
                 e_l, fl, _ = measure_lanes(lanes_a, ctx, F, a.greedy, n_l, 1, parallel.PhaseGate() if a.conv_gate else None)
                 assert all(torch.isfinite(x).all() for x in fl)

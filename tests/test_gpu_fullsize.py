@@ -244,3 +244,39 @@ def test_config5_medium_30_frame_rollout_properties():
     assert torch.equal(llm.generate(prompt[32:], do_sample=True, top_k=100, max_new_tokens=n_new, uniforms=u[32:]), out[32:])
     short = llm.generate(prompt[:16], do_sample=True, top_k=100, max_new_tokens=60, uniforms=u[:16, :60].contiguous())
     assert torch.equal(short, out[:16, :514 + 60])
+
+
+def test_x3_mode_at_config2_size_against_the_fp32_engine(models):
+    """The compliant (x3, split-bf16) arithmetic at BASELINE config 2's full size -- 64 trajectories x (2 + 14) frames, 114 M tokenizer,
+    12-layer transformer, 514-token prompts -- where the CPU oracle cannot run: against the fp32 engine mode (itself pinned to the
+    reference at small sizes and full width), decoded pixels and prompt-pass logits within 1e-3, greedy rollouts of 40 tokens
+    token-identical up to the first near-tie; an x3 trajectory does not depend on its batch-mates."""
+    from ivideogpt_amd import CompressiveVQModel, LlamaForCausalLM
+    from ivideogpt_amd import weights as W
+    tok_b, llm_b, px, tcfg, lcfg = models
+    tsd, lsd = W.random_tokenizer_state_dict(tcfg, 5, codebook_std=0.4), W.random_llama_state_dict(lcfg, 6)
+    ids, _ = tok_b.tokenize(px, CTX)
+    out = {}
+    for mode in ("fp32", "x3"):
+        tok = CompressiveVQModel(tcfg, tsd, encode_dtype="fp32", decode_dtype=mode).to(DEV)
+        out[mode, "px"] = tok.detokenize(ids, CTX)
+        if mode == "x3":
+            one = tok.detokenize(ids[5:6], CTX)
+            assert torch.equal(one[0], out[mode, "px"][5]), "x3 decode: row 5 depends on its batch"
+        del tok
+        torch.cuda.empty_cache()
+    d = (out["x3", "px"] - out["fp32", "px"]).abs()
+    assert 0 < d.max().item() < 1e-3, f"x3 vs fp32 decode at B = 64: max {d.max():.2e} mean {d.mean():.2e}"
+    prompt = ids[:, :257 * CTX]
+    for mode in ("fp32", "x3"):
+        llm = LlamaForCausalLM(lcfg, lsd, dtype=mode).to(DEV)
+        out[mode, "lg"] = llm.logits(prompt[:8])[:, -4:].clone()          # (the full (64, 514, 16386) fp32 tensor is 2.2 GB: 8 rows suffice)
+        out[mode, "tok"] = llm.generate(prompt, do_sample=False, max_new_tokens=40)
+        if mode == "x3":
+            assert torch.equal(llm.generate(prompt[9:10], do_sample=False, max_new_tokens=40)[0], out[mode, "tok"][9])
+        del llm
+        torch.cuda.empty_cache()
+    e = (out["x3", "lg"] - out["fp32", "lg"]).abs().max().item()
+    assert 0 < e < 1e-3, f"x3 vs fp32 logits at L = 514: max {e:.2e}"
+    same = (out["x3", "tok"] == out["fp32", "tok"]).all(dim=1)
+    assert same.float().mean().item() >= 0.9, f"only {int(same.sum())} of 64 greedy rollouts identical between x3 and fp32"

@@ -286,6 +286,44 @@ def test_two_lanes_issue_their_gathers_in_step_order_world2_gloo(tmp_path):
     assert "LANES-OK 0" in outs[0] and "LANES-OK 1" in outs[1]
 
 
+GATHERER_WORKER = r"""
+import os, sys, threading, time, random, torch
+sys.path.insert(0, sys.argv[1])
+from ivideogpt_amd import parallel
+rank, world, local = parallel.init_from_env("gloo")
+L, steps = 3, 11
+gat = parallel.OrderedGatherer("cpu")
+gat.start(0)
+def lane(i):
+    for g in range(i, steps, L):
+        time.sleep(random.random() * 0.02 * (1 + (rank + i) % 3))        # lanes and ranks drift apart; a lane never waits for a collective
+        gat.submit(g, torch.full((3, 2), float(100 * g + rank)))
+ths = [threading.Thread(target=lane, args=(i,)) for i in range(L)]
+[t.start() for t in ths]; [t.join() for t in ths]
+seen = gat.finish(steps)
+for g in range(steps):
+    want = torch.cat([torch.full((3, 2), float(100 * g + r)) for r in range(world)], 0)
+    assert torch.equal(seen[g], want), (rank, g, seen[g])
+parallel.barrier()
+print("GATHERER-OK", rank)
+"""
+
+
+def test_ordered_gatherer_issues_the_lanes_gathers_in_step_order_world2_gloo(tmp_path):
+    """bench.py --lanes with a process group: the per-step metric all-gathers of all lanes are issued by ONE thread in global step
+    order (parallel.OrderedGatherer) -- same order on every rank, and no lane waits for a collective."""
+    script = tmp_path / "gatherer.py"
+    script.write_text(GATHERER_WORKER)
+    port = 29000 + (os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "GATHERER-OK 0" in outs[0] and "GATHERER-OK 1" in outs[1]
+
+
 def test_turnstile_orders_tickets_and_releases_waiters_when_a_lane_dies():
     import threading, time
     from ivideogpt_amd import parallel
@@ -340,3 +378,20 @@ def test_video_predictor_constructor_follows_the_reference_loader(tmp_path, inte
     assert set(vp0.model.state_dict()) == set(full) and vp0.tokenizer.state_dict().keys() == tsd.keys()
     with pytest.raises(Exception):   # strict loading: an action-free checkpoint into the whole wrapper (or the reverse) must fail
         VideoPredictor("cpu", dict(args, load_internal_llm=not internal))
+
+
+def test_switch_table_set_override_and_restore():
+    """ivideogpt_amd.switches: IVG_* variables are published to the loaded library (ivg_reload_switches); override() restores what was
+    there before -- set or unset -- and only IVG_* names are accepted."""
+    from ivideogpt_amd import switches
+    os.environ.pop("IVG_DECODE_LDS_KB", None)
+    os.environ["IVG_GRAPH"] = "1"
+    try:
+        with switches.override(**switches.BATCHES_IN_FLIGHT, IVG_GRAPH=None):
+            assert os.environ["IVG_DECODE_LDS_KB"] == switches.BATCHES_IN_FLIGHT["IVG_DECODE_LDS_KB"] and "IVG_GRAPH" not in os.environ
+        assert "IVG_DECODE_LDS_KB" not in os.environ and os.environ["IVG_GRAPH"] == "1"
+        with pytest.raises(KeyError):
+            switches.set(PATH="/tmp")
+    finally:
+        os.environ.pop("IVG_GRAPH", None)
+        switches.set()
