@@ -33,10 +33,11 @@ import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver: RCCL needs it (multi-process runs)
-# HIP deals its streams round-robin over GPU_MAX_HW_QUEUES hardware queues (default 4): the null stream, this benchmark's main stream
-# and the lane streams must not share one -- two lanes on one hardware queue run one after the other (4,987 instead of 5,355 frames/s
-# at four lanes, profiles/r04_lanes.txt).  Has to be in the environment before the runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# HIP deals its streams round-robin over GPU_MAX_HW_QUEUES hardware queues (default 4): the null stream, this benchmark's main stream,
+# the lane streams, the gatherer's stream and RCCL's own must not share one -- two lanes on one hardware queue run one after the other
+# (4,987 instead of 5,355 frames/s at four lanes with 4 queues; with a process group 5,069 at 8 queues, 5,617 at 16:
+# profiles/r04_lanes.txt).  Has to be in the environment before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import torch  # noqa: E402
 
