@@ -1,4 +1,5 @@
-"""Time one conv shape through the C ABI (development aid).  python tools/conv_bench.py H Cin Cout [ups] [N] [dtype]"""
+"""Time one conv shape through the C ABI (development aid).  python tools/conv_bench.py H Cin Cout [ups] [N] [dtype] [gn]
+gn = 1: conv3x3(silu(GroupNorm(x))) with the normalisation inside the staging (ivg_op_gn_conv; IVG_GNA_UNIFORM selects the map)."""
 import ctypes as C
 import os
 import sys
@@ -14,6 +15,7 @@ def main():
     ups = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     N = int(sys.argv[5]) if len(sys.argv) > 5 else 896
     dt = sys.argv[6] if len(sys.argv) > 6 else "bf16"
+    gn = int(sys.argv[7]) if len(sys.argv) > 7 else 0
     tdt = torch.bfloat16 if dt == "bf16" else torch.float32
     lib = _lib.load()
     dev = "cuda:0"
@@ -28,19 +30,29 @@ def main():
         setattr(a, k, v)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     code = 1 if dt == "bf16" else 0
+    if gn:
+        groups = 32
+        gam, bet = torch.ones(Cin, device=dev), torch.zeros(Cin, device=dev)
+        ws = torch.empty(N * (((H * H + 1023) // 1024) * groups * 16 + Cin * 8) + 256, dtype=torch.uint8, device=dev)
+        ws_p, g_p, b_p = C.c_void_p(ws.data_ptr()), C.c_void_p(gam.data_ptr()), C.c_void_p(bet.data_ptr())
+        # the statistics / coefficient kernels run once; the timed loop repeats the convolution with the coefficients in place
+        assert lib.ivg_op_gn_conv(C.byref(a), code, groups, g_p, b_p, 1e-6, ws_p, st) == 0
+        call = lambda: lib.ivg_op_gn_conv(C.byref(a), code, groups, g_p, b_p, 1e-6, ws_p, st)   # noqa: E731
+    else:
+        call = lambda: lib.ivg_op_igemm(C.byref(a), code, st)   # noqa: E731
     for _ in range(3):
-        assert lib.ivg_op_igemm(C.byref(a), code, st) == 0
+        assert call() == 0
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     iters = 10
     e0.record()
     for _ in range(iters):
-        lib.ivg_op_igemm(C.byref(a), code, st)
+        call()
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     fl = 2.0 * N * Ho * Ho * Cout * 9 * Cin
-    print(f"H={H} Cin={Cin} Cout={Cout} ups={ups} N={N} {dt} abl={os.environ.get('IVG_C3_ABLATE', '0')} c3={os.environ.get('IVG_CONV3X3', '1')}: "
+    print(f"H={H} Cin={Cin} Cout={Cout} ups={ups} N={N} {dt} gn={gn} uniform={os.environ.get('IVG_GNA_UNIFORM', '0')} c3={os.environ.get('IVG_CONV3X3', '1')}: "
           f"{ms:.3f} ms  {fl / ms / 1e9:.0f} TFLOP/s")
 
 
