@@ -6,7 +6,7 @@
 //   * with the kernel's development stamps on (SkinnyArgs::dbg): where a launch's time goes -- entry -> DMA issued -> first line
 //     group landed -> last group landed -> MFMAs done -> combine -> stores issued, per wave, min / median / max over the
 //     workgroups, plus the spread of the workgroups' start and end times on the 100 MHz wall clock.
-// Usage: dgemm_phase [small|medium] [M]      (env IVG_DG_FORCE etc. act as in the product)
+// Usage: dgemm_phase [small|medium] [M]      (IVG_DG3 / IVG_DG3_WARM / IVG_DECODE_LDS_KB act as in the product: csrc/switches.h)
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
@@ -16,6 +16,7 @@
 #include <chrono>
 #include <thread>
 
+#include "../../ivideogpt_amd/csrc/switches.cpp"
 #include "../../ivideogpt_amd/csrc/dgemm.hip"
 #include "../../ivideogpt_amd/csrc/dgemm3.hip"
 
@@ -188,7 +189,7 @@ int main(int argc, char** argv) {
   };
   const char* names[4] = {"q/k/v", "o-proj", "gate/up", "down"};
   const float all_s = time_chain(15, true, 8), all = time_chain(15, false, 8), str = time_chain(0, true, 8);
-  printf("GENMASK=%s generation %d%s, IVG_DG3_FORCE=%s: ", getenv("GENMASK") ? getenv("GENMASK") : "-", gen, gen == 3 ? (warm ? " + L2 warm-up" : ", no warm-up") : "", getenv("IVG_DG3_FORCE") ? getenv("IVG_DG3_FORCE") : "-");
+  printf("GENMASK=%s generation %d%s, IVG_DECODE_LDS_KB=%s: ", getenv("GENMASK") ? getenv("GENMASK") : "-", gen, gen == 3 ? (warm ? " + L2 warm-up" : ", no warm-up") : "", getenv("IVG_DECODE_LDS_KB") ? getenv("IVG_DECODE_LDS_KB") : "160");
   printf("%s transformer, M = %d: layer chain %.2f us (4 GEMMs + streamer), streamer alone %.2f, 4 GEMMs alone %.2f us per layer\n",
          medium ? "medium" : "small", M, all_s, str, all);
   for (int k = 0; k < 4; ++k) {
