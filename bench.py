@@ -132,7 +132,7 @@ KERNEL_NAMES = {
     "decode_attn": "ivg::decode_attn_kernel (RoPE + KV append + single-query attention over the KV cache)",
     "decode_gemm": "ivg::dgemm_kernel (decode-step GEMMs: q/k/v, o-proj, gate/up, down, lm_head; weights streamed once per launch)",
     "conv3x3": "ivg::conv3x3_kernel (LDS-halo 3x3 convolution, MFMA)",
-    "igemm": "ivg::gemm256_kernel + ivg::igemm_kernel<128,128,64> (dense GEMMs / implicit-GEMM convs other than 3x3, MFMA)",
+    "igemm": "ivg::gemm256l_kernel + ivg::igemm_kernel<128,128,64> (dense GEMMs / implicit-GEMM convs other than 3x3, MFMA)",
 }
 PMC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json")
 TRACE_FILES = ("r04_kernel_trace_classes.json", "r03_kernel_trace_classes.json")

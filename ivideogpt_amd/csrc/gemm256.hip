@@ -44,16 +44,6 @@ __device__ __forceinline__ void g256_tile(const G256Dev& p, int v, int& tile_m, 
 
 __device__ __attribute__((aligned(16))) unsigned char g_zero_chunk_g256[16];
 
-__device__ __forceinline__ void g256_dma16(const void* gsrc, unsigned char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-__device__ __forceinline__ int g256_key(int row) { return (row >> 1) & 3; }
-__device__ __forceinline__ int g256_swz(int row, int chunk) { return row * 64 + ((chunk ^ g256_key(row)) << 4); }
-
-constexpr int G256_STAGES = 4;
-constexpr int G256_SLAB = 256 * 64;               // bytes of one 256-row x 32-element slab
-constexpr int G256_STAGE = 2 * G256_SLAB;         // A | W
 constexpr int G256_PITCH = 256 * 2 + 16;          // staged output row (bytes): + 16 spreads the 16 rows of a fragment over banks
 
 // epilogue shared by both kernels: lane holds 4 consecutive columns n of row (wm*64 + b*16 + lr); bias, residual, SiLU, SiLU(gate) * up
@@ -108,77 +98,11 @@ __device__ __forceinline__ void g256_epilogue(const G256Dev& p, f32x4 (&acc)[4][
   }
 }
 
-__global__ __launch_bounds__(1024) void gemm256_kernel(const G256Dev p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int lr = lane & 15, lg = lane >> 4;
-  const int wm = wave & 3, wn = wave >> 2;
-  const int nwg = gridDim.x;
-  int v;
-  {  // blocks b, b + 8, ... share an XCD: give each XCD a contiguous run of tiles with the N tile fastest (bijective)
-    const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-    v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-  }
-  int tile_m, tile_n;
-  g256_tile(p, v, tile_m, tile_n);
-  const int m0 = tile_m * 256, n0 = tile_n * 256;
-  const int steps = p.K >> 5;
+// (Round 2's kernel of this file -- 64-byte rows, K steps of 32 elements, four 32 KiB stages -- was removed in round 4: every dense GEMM of
+// the released models has K % 64 == 0 and runs on the whole-line kernel below, which replaced it at +7 % on the class,
+// profiles/r03_gemm256_line_ab.txt; other K fall to the generic implicit GEMM.)
 
-  // DMA of one step: thread -> (row = tid / 4, source chunk = (tid % 4) ^ key(row)); a wave fills 16 rows = 1 KiB, lane-linear
-  const int drow = tid >> 2, dslot = tid & 3;
-  const int dchunk = dslot ^ g256_key(drow);
-  const bool a_ok = (m0 + drow) < p.M;
-  const bf16_t* a_src = p.X + (long)(a_ok ? m0 + drow : 0) * p.ldx + dchunk * 8;
-  const bf16_t* w_src = p.W + (long)(n0 + drow) * p.ldw + dchunk * 8;
-  auto issue = [&](int step) {
-    unsigned char* st = smem + (step % G256_STAGES) * G256_STAGE + wave * 1024;
-    g256_dma16(a_ok ? (const void*)(a_src + step * 32) : (const void*)g_zero_chunk_g256, st);
-    g256_dma16((const void*)(w_src + step * 32), st + G256_SLAB);
-  };
-
-  f32x4 acc[4][4];   // [a: N fragment][b: M fragment]
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  auto mma_step = [&](int s) {
-    const unsigned char* sa = smem + (s % G256_STAGES) * G256_STAGE;
-    const unsigned char* sw = sa + G256_SLAB;
-    Chunk16 xa[4], wv[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) xa[b] = *(const Chunk16*)(sa + g256_swz(wm * 64 + b * 16 + lr, lg));
-#pragma unroll
-    for (int a = 0; a < 4; ++a) wv[a] = *(const Chunk16*)(sw + g256_swz(wn * 64 + a * 16 + lr, lg));
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[a]), __builtin_bit_cast(bf16x8, xa[b]),
-                                                            acc[a][b], 0, 0, 0);
-  };
-  for (int s = 0; s < G256_STAGES - 1 && s < steps; ++s) issue(s);
-  // step 0 must have landed: at most the (min(steps, STAGES - 1) - 1) younger steps (2 DMA instructions each) stay in flight
-  if (steps >= 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if (steps == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  for (int s = 0; s < steps; ++s) {
-    if (s + G256_STAGES - 1 < steps) issue(s + G256_STAGES - 1);   // its stage was read at step s - 1, before the last barrier
-    mma_step(s);
-    // step s + 1 must have landed before anyone reads it: everything but the younger steps still allowed in flight
-    const int young = min(G256_STAGES - 2, steps - 2 - s);   // steps s + 2 .. in flight after this wait
-    if (young >= 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-    else if (young == 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-
-  g256_epilogue(p, acc, smem, m0, n0, wm, wn, lr, lg, tid);
-}
-
-// ---- whole-line variant (round 3).  The kernel above requests 64-byte rows (K steps of 32 elements): half a cache line per row and
+// ---- whole-line kernel (round 3).  Its predecessor requested 64-byte rows (K steps of 32 elements): half a cache line per row and
 // request, the shape the round-2 decode micro-benchmarks measured at 12-16 B/clk/CU out of L2 against 25-49 for whole 128-byte
 // lines -- and 32 KiB per 1,030 MFMA clocks is exactly what this kernel was getting (11 B/clk/CU, MFMA pipe 25-41 % busy).  Here a
 // step is 64 elements of K: every LDS-DMA instruction fetches 8 rows x one whole line, with the source-side chunk permutation of
@@ -284,19 +208,13 @@ int launch_gemm256(const IgemmArgs& a, DType dtype, hipStream_t stream) {
     const long slab = 256L * d.K * 2;
     d.gn = (int)std::max(1L, std::min<long>((5L << 19) / slab, d.tiles_n));
   }
-  const int smem = 256 * G256_PITCH > G256_STAGES * G256_STAGE ? 256 * G256_PITCH : G256_STAGES * G256_STAGE;
   const long tiles = (long)cdiv(M, 256) * d.tiles_n;
-  // whole-line requests (K steps of 64 elements) wherever K allows; IVG_G256_LINE=0: the 64-byte-row kernel (A/B, tests)
-  if (sw().g256_line && d.K % 64 == 0 && (long)d.M * d.ldx * 2 < (1L << 31) && (long)d.N * d.ldw * 2 < (1L << 31)) {
-    static DynLdsOnce once_l;
-    if (hipError_t e = ensure_dyn_lds(once_l, (const void*)gemm256l_kernel, 160 * 1024); e != hipSuccess) return (int)e;
-    const int smem_l = 256 * G256_PITCH > 2 * G256L_STAGE ? 256 * G256_PITCH : 2 * G256L_STAGE;
-    hipLaunchKernelGGL(gemm256l_kernel, dim3((unsigned)tiles), dim3(1024), smem_l, stream, d);
-    return (int)hipGetLastError();
-  }
-  static DynLdsOnce once;
-  if (hipError_t e = ensure_dyn_lds(once, (const void*)gemm256_kernel, 160 * 1024); e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(gemm256_kernel, dim3((unsigned)tiles), dim3(1024), smem, stream, d);
+  // whole-line requests: K steps of 64 elements; other K (no released shape) -> generic implicit GEMM
+  if (d.K % 64 != 0 || (long)d.M * d.ldx * 2 >= (1L << 31) || (long)d.N * d.ldw * 2 >= (1L << 31)) return -1;
+  static DynLdsOnce once_l;
+  if (hipError_t e = ensure_dyn_lds(once_l, (const void*)gemm256l_kernel, 160 * 1024); e != hipSuccess) return (int)e;
+  const int smem_l = 256 * G256_PITCH > 2 * G256L_STAGE ? 256 * G256_PITCH : 2 * G256L_STAGE;
+  hipLaunchKernelGGL(gemm256l_kernel, dim3((unsigned)tiles), dim3(1024), smem_l, stream, d);
   return (int)hipGetLastError();
 }
 

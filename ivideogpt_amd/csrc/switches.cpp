@@ -16,7 +16,6 @@ static Switches read_env() {
   Switches s;
   s.conv3x3 = env_int("IVG_CONV3X3", 1) != 0;
   s.gemm256 = env_int("IVG_GEMM256", 1) != 0;
-  s.g256_line = env_int("IVG_G256_LINE", 1) != 0;
   s.dg3 = env_int("IVG_DG3", 1) != 0;
   s.flash_prefill = env_int("IVG_FLASH_PREFILL", 1) != 0;
   s.flash_xatt = env_int("IVG_FLASH_XATT", 1) != 0;

@@ -7,7 +7,6 @@
 //   ---- which kernel runs a shape (A/B runs and the tests of the alternative paths)
 //   IVG_CONV3X3              1        0: every 3x3 convolution on the generic implicit GEMM (igemm.hip)
 //   IVG_GEMM256              1        0: large dense GEMMs on the generic implicit GEMM
-//   IVG_G256_LINE            1        0: the 64-byte-row gemm256 kernel everywhere (1: whole-line kernel where K % 64 == 0)
 //   IVG_DG3                  1        0: decode GEMMs on the second-generation kernel (dgemm.hip)
 //   IVG_FLASH_PREFILL        1        0: prompt attention as score GEMM + softmax + P.V GEMM (what the fp32 engine mode runs)
 //   IVG_FLASH_XATT           1        0: tokenizer attention as score GEMM + softmax + P.V GEMM
@@ -25,7 +24,7 @@
 namespace ivg {
 
 struct Switches {
-  int conv3x3 = 1, gemm256 = 1, g256_line = 1, dg3 = 1, flash_prefill = 1, flash_xatt = 1, gn_fuse = 1, gn_apply_fuse = 1, x3 = 1;
+  int conv3x3 = 1, gemm256 = 1, dg3 = 1, flash_prefill = 1, flash_xatt = 1, gn_fuse = 1, gn_apply_fuse = 1, x3 = 1;
   int graph = 0, dg3_warm = 1, conv_cap = 0, decode_lds_kb = 160;
 };
 

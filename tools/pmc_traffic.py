@@ -9,7 +9,7 @@ CLASSES = {
     "decode_attn": ["decode_attn"],
     "decode_gemm": ["dgemm_kernel", "dg3_kernel"],
     "conv3x3": ["conv3x3_kernelIDF16b"],
-    "igemm": ["igemm_kernelIDF16b", "gemm256_kernel", "gemm256l_kernel"],
+    "igemm": ["igemm_kernelIDF16b", "gemm256l_kernel"],
 }
 
 

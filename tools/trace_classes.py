@@ -10,7 +10,7 @@ CLASSES = {
     "decode_attn": ["decode_attn_kernel"],
     "decode_gemm": ["dgemm_kernel", "dg3_kernel"],
     "conv3x3": ["conv3x3_kernelIDF16b", "conv3x3_kernel<__bf16", "conv3x3_kernel<bool"],
-    "igemm": ["igemm_kernelIDF16b", "gemm256_kernel", "gemm256l_kernel"],
+    "igemm": ["igemm_kernelIDF16b", "gemm256l_kernel"],
     "sampler": ["sample_embed_kernel"],
 }
 
