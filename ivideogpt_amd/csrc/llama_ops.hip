@@ -1073,13 +1073,8 @@ int launch_sample_embed(const SampleArgs& a, int B, DType dt, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
-__global__ void step_advance_kernel(StepState* s) { s->pos += 1; s->j += 1; }
 __global__ void state_set_kernel(StepState* s, int pos, int j) { s->pos = pos; s->j = j; }
 
-int launch_step_advance(StepState* state, hipStream_t st) {
-  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, st, state);
-  return (int)hipGetLastError();
-}
 int launch_state_set(StepState* state, int pos, int j, hipStream_t st) {
   hipLaunchKernelGGL(state_set_kernel, dim3(1), dim3(1), 0, st, state, pos, j);
   return (int)hipGetLastError();

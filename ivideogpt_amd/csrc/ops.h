@@ -47,7 +47,6 @@ int launch_gather_rows(const int64_t* ids, const TokMap& map, const float* E, vo
 int launch_unpatchify(const void* q, void* out, DType dt, int M, int np, int C, int p, hipStream_t st);
 // special tokens (scf / sdf slots) and labels (-100 over the context part)                    (compressive_vq_model.py:205-218)
 int launch_finish_tokens(int64_t* ids, long stride, int64_t* labels, int B, int L, int ctx, int64_t scf, int64_t sdf, hipStream_t st);
-int launch_cast(const void* src, DType sdt, void* dst, DType ddt, long n, hipStream_t st);
 
 // ---- llama_ops.hip
 struct StepState {  // device-resident per-generate state (so one captured step graph can be replayed)
@@ -90,7 +89,6 @@ struct SampleArgs {
   float temperature;                           // logits / temperature before the top-k filter (HF TemperatureLogitsWarper); 1.0: none
 };
 int launch_sample_embed(const SampleArgs& a, int B, DType dt, hipStream_t st);
-int launch_step_advance(StepState* state, hipStream_t st);
 int launch_state_set(StepState* state, int pos, int j, hipStream_t st);
 // y[b][t][:] = W[H][A] a[b][t][:] + bias  (tiny; fp32 in, T out)
 int launch_action_embed(const float* act, const float* W, const float* bias, void* out, DType dt, int BT, int A, int H,

@@ -207,20 +207,4 @@ int launch_finish_tokens(int64_t* ids, long stride, int64_t* labels, int B, int 
   return (int)hipGetLastError();
 }
 
-template <typename S, typename D>
-__global__ __launch_bounds__(256) void cast_kernel(const S* __restrict__ s, D* __restrict__ d, long n) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) d[i] = from_f32<D>(to_f32(s[i]));
-}
-
-int launch_cast(const void* src, DType sdt, void* dst, DType ddt, long n, hipStream_t st) {
-  if (n <= 0) return 0;
-  dim3 g(cdiv(n, 256));
-  if (sdt == F32 && ddt == BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), g, dim3(256), 0, st, (const float*)src, (bf16_t*)dst, n);
-  else if (sdt == BF16 && ddt == F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), g, dim3(256), 0, st, (const bf16_t*)src, (float*)dst, n);
-  else if (sdt == F32) hipLaunchKernelGGL((cast_kernel<float, float>), g, dim3(256), 0, st, (const float*)src, (float*)dst, n);
-  else hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), g, dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
-  return (int)hipGetLastError();
-}
-
 }  // namespace ivg
