@@ -1,7 +1,7 @@
 // Decode-step GEMM, second generation (SURVEY.md 2.4 K14/K17 at L = 1):  Y[m][n] = epi( sum_k X[m][k] * W[n][k] ),  M <= 128.
 //
 // What the round-2 micro-benchmarks (tools/ubench/decode_ubench.hip, profiles/r02_decode_ubench.txt) showed about the
-// first-generation kernel (skinny.hip): it pulled the ACTIVATION rows in MFMA-fragment shape -- 16 rows x 64 bytes per
+// first-generation kernel (removed in round 4): it pulled the ACTIVATION rows in MFMA-fragment shape -- 16 rows x 64 bytes per
 // wave instruction, half a cache line per row -- and that shape runs at 12-16 B/clk/CU out of L2, while whole 128-byte
 // lines run at 25-49 B/clk/CU (3x).  The activations are 60 % of the bytes a workgroup ingests, so here:
 //   * activations arrive by LDS-DMA (global_load_lds, 16 B per lane) as WHOLE LINES: 8 consecutive lanes fetch the 8 chunks
@@ -14,7 +14,7 @@
 //     128 bytes of K run while the rest of the wave's slice is still arriving;
 //   * the residual rows the epilogue updates are requested at kernel start instead of after the K reduction.
 // Waves split K (fixed partition per (K, dtype): a trajectory's result does not depend on its batch-mates), combine
-// through LDS in a fixed order; epilogues as in skinny.hip: RMSNorm row scale (weight folded into W), residual, SiLU(gate)*up,
+// through LDS in a fixed order; epilogues: RMSNorm row scale (weight folded into W), residual, SiLU(gate)*up,
 // step-counter advance.
 #include <algorithm>
 #include <cstdio>
@@ -395,7 +395,7 @@ int dgemm_w_rows_per_block(const SkinnyArgs& a, DType dtype) {
   return 16 * ((a.flags & IG_GLU) ? 2 : 1);
 }
 
-// -1: shape not covered (caller falls back to skinny.hip); otherwise a hipError_t
+// -1: shape not covered (launch_skinny below answers hipErrorInvalidValue); otherwise a hipError_t
 int launch_dgemm(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
   const int es = dtype == BF16 ? 2 : 4;
   if (a.M <= 0 || a.N <= 0 || a.M > 128) return -1;
@@ -429,7 +429,7 @@ int launch_dgemm(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
   }
   // The wave count (the K partition) is a function of (K bytes, N) only; the register class that holds it bounds the fragments a
   // workgroup may own (launch_dg_t: <= 4 waves any tile, <= 8 waves MF * FN <= 8, 16 waves MF * FN <= 2).  A tile the batch size
-  // asked for that does not fit is CLAMPED here -- never answered with -1: falling back to skinny.hip for some batch sizes only
+  // asked for that does not fit is CLAMPED here -- never answered with -1: a different kernel for some batch sizes only
   // would give a trajectory a different K-summation order depending on its batch-mates (fp32 parity mode: M = 64 vs a 16-row shard).
   {
     const int allowed = waves <= 4 ? 16 : (waves <= 8 ? 8 : 2);

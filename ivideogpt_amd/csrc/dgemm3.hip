@@ -438,7 +438,7 @@ static const Dg3Skip kDg3Skip[] = {
 
 struct Dg3Plan { int mf, fn, waves, klw, ring; unsigned wave_bytes; int wr; };
 
-// shape -> launch plan; false: not covered (the caller falls back to dgemm.hip / skinny.hip).  Coverage and the K partition
+// shape -> launch plan; false: not covered (launch_skinny falls back to dgemm.hip).  Coverage and the K partition
 // depend on (K, N, dtype, flags) only; the batch size only picks MF (which rows share a workgroup -- never a sum order).
 static bool dg3_plan(const SkinnyArgs& a, DType dtype, Dg3Plan& pl) {
   const int es = dtype == BF16 ? 2 : 4;
