@@ -395,3 +395,25 @@ def test_switch_table_set_override_and_restore():
     finally:
         os.environ.pop("IVG_GRAPH", None)
         switches.set()
+
+
+def test_pack_x3_slot_layout_and_split_accuracy():
+    """packing.pack_x3: 4 consecutive K elements -> one 16-byte slot [hi(4) | lo(4)]; hi + lo restores the fp32 weight to 2^-16 relative
+    (what the 1e-3 bars of the x3 mode rest on), and a dot product over split operands (all four partial products, fp32 accumulate --
+    the arithmetic of the X3 kernels) stays within 1e-5 relative of the fp64 one at the K of the largest decoder convolution."""
+    from ivideogpt_amd.packing import pack_x3
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(8, 9 * 512, generator=g) * 0.05
+    p = pack_x3(w)
+    assert p.dtype == torch.bfloat16 and p.shape == (8, 2 * 9 * 512)
+    slots = p.view(8, -1, 2, 4)
+    hi, lo = slots[:, :, 0].reshape(8, -1).float(), slots[:, :, 1].reshape(8, -1).float()
+    assert torch.equal(hi, w.to(torch.bfloat16).float())
+    assert ((hi + lo) - w).abs().max() <= 2.0 ** -16 * w.abs().max()
+    a = torch.rand(9 * 512, generator=g)
+    a_hi = a.to(torch.bfloat16).float(); a_lo = (a - a_hi).to(torch.bfloat16).float()
+    y = (hi * a_hi + hi * a_lo + lo * a_hi + lo * a_lo).sum(1)
+    ref = (w.double() * a.double()).sum(1)
+    assert (y.double() - ref).abs().max() <= 1e-5 * (w.double().abs() * a.double()).sum(1).max()
+    with pytest.raises(AssertionError):
+        pack_x3(torch.zeros(4, 6))
