@@ -1,5 +1,5 @@
 """Time one conv shape through the C ABI (development aid).  python tools/conv_bench.py H Cin Cout [ups] [N] [dtype] [gn]
-gn = 1: conv3x3(silu(GroupNorm(x))) with the normalisation inside the staging (ivg_op_gn_conv; IVG_GNA_UNIFORM selects the map)."""
+gn = 1: conv3x3(silu(GroupNorm(x))) with the normalisation inside the staging (ivg_op_gn_conv)."""
 import ctypes as C
 import os
 import sys
@@ -52,7 +52,7 @@ def main():
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     fl = 2.0 * N * Ho * Ho * Cout * 9 * Cin
-    print(f"H={H} Cin={Cin} Cout={Cout} ups={ups} N={N} {dt} gn={gn} uniform={os.environ.get('IVG_GNA_UNIFORM', '0')} c3={os.environ.get('IVG_CONV3X3', '1')}: "
+    print(f"H={H} Cin={Cin} Cout={Cout} ups={ups} N={N} {dt} gn={gn} c3={os.environ.get('IVG_CONV3X3', '1')}: "
           f"{ms:.3f} ms  {fl / ms / 1e9:.0f} TFLOP/s")
 
 
