@@ -190,6 +190,42 @@ int launch_rope_kv(void* qkv, void* kc, void* vc, void* vt, int ldvt, const floa
   return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ V^T tile of the one-pass attention kernels
+// The P.V MFMA of flash_prefill_kernel / xattn_kernel enumerates the keys of a 32-key step as (4*lg + r, 16 + 4*lg + r) -- the order a
+// lane's own S registers have -- so its V^T fragment is two groups of four consecutive keys, 16 apart.  Read as two 8-byte halves
+// (rounds 2-4) the compiler merged them into ds_read2_b64: two accesses of 4 x 16 CONTIGUOUS lanes with banks mod 32, half the rate
+// of ds_read_b128, and 2-way conflicted for 16 consecutive rows of the 144-byte pitch (the 32-38 % bank-conflict cycles of the PMC
+// tables).  Now the keys of every 32-key block are PERMUTED when the tile is staged -- position lg*8 + half*4 + r holds key
+// half*16 + lg*4 + r -- so a fragment is ONE conflict-free ds_read_b128.  Rows of 64 keys carry 32 bytes of pad; rows of 32 keys
+// (64 bytes: the single-head 512- / 768-channel instances) use the XOR key of conv3x3's 64-byte rows instead, without pad (the
+// 512-channel instance keeps two workgroups per CU).  The staging stores become two ds_write_b64 per 16-byte chunk, odd rows of the
+// padded form in the other order (16 contiguous lanes = two rows then touch 32 distinct banks).  Model: tools/lds_vt_layout_check.py
+// (function of the permutation + bank cycles of both access shapes).
+template <int KT>
+struct VtTile {
+  static constexpr bool SWZ = KT == 32;
+  static constexpr int PITCH = SWZ ? KT : KT + 16;   // elements
+  static __device__ __forceinline__ int quad_off(int row, int quad) {   // element offset of 16-byte quad `quad` of row `row`
+    if constexpr (SWZ) quad ^= (row >> 1) & 3;
+    return row * PITCH + (quad << 3);
+  }
+  // source chunk cc of a row = its keys 8cc .. 8cc+7
+  static __device__ __forceinline__ void store(bf16_t* sV, int row, int cc, Chunk16 c) {
+    typedef uint32_t U2 __attribute__((ext_vector_type(2)));
+    const int qa = (cc >> 2) * 4 + 2 * (cc & 1), e = ((cc >> 1) & 1) * 4;
+    bf16_t* a = sV + quad_off(row, qa) + e;
+    bf16_t* b = sV + quad_off(row, qa + 1) + e;
+    const U2 lo = {c.x, c.y}, hi = {c.z, c.w};
+    const bool odd = !SWZ && (row & 1);
+    bf16_t* p0 = odd ? b : a;
+    bf16_t* p1 = odd ? a : b;
+    *(U2*)p0 = odd ? hi : lo;
+    *(U2*)p1 = odd ? lo : hi;
+  }
+  // fragment of K-step pr for lane (lr, lg) of the 16-row block d: frag(sV, d * 16 + lr, pr * 4 + lg)
+  static __device__ __forceinline__ bf16x8 frag(const bf16_t* sV, int row, int quad) { return *(const bf16x8*)(sV + quad_off(row, quad)); }
+};
+
 // ------------------------------------------------------------------------------------------------ prefill attention
 // Causal self-attention of a prompt (positions 0 .. L-1) in one pass, bf16 / head_dim 64: replaces the score GEMM, the row
 // softmax and the P.V GEMM of the prefill (and their fp32 score matrix in HBM: 910 MB per layer at config 2).
@@ -222,12 +258,12 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(const bf16_t* __rest
   // from L2 by every wave, and the next tile travels from global memory into registers while the current one is consumed.
   // Row pitches per access shape (bank model of MI355X_MICROARCH.md, tools/lds_swizzle_check.py): the K rows are read back as
   // 16-byte MFMA fragments (ds_read_b128: 4 groups of 16 lanes) -- a pad of 32 bytes is conflict-free, the 16 bytes of round 2
-  // cost every read a second LDS cycle (PMC: 41 % bank-conflict cycles); the V^T rows are read as 8-byte halves (ds_read_b64:
-  // 2 groups of 32 lanes), conflict-free at 16 bytes of pad.
-  constexpr int PITCH = HD + 8;       // V^T rows
+  // cost every read a second LDS cycle (PMC: 41 % bank-conflict cycles); the V^T rows are staged key-permuted (VtTile above) and
+  // read back the same way.
+  using VT = VtTile<64>;
   constexpr int PITCHK = HD + 16;     // K rows
   __shared__ __attribute__((aligned(16))) bf16_t sK[64 * PITCHK];
-  __shared__ __attribute__((aligned(16))) bf16_t sV[64 * PITCH];
+  __shared__ __attribute__((aligned(16))) bf16_t sV[64 * VT::PITCH];
   const int srow0 = tid >> 3, scol = (tid & 7) * 8;   // this thread stages chunks (srow0, scol) and (srow0 + 32, scol)
   Chunk16 pk[2], pv[2];
   auto fetch = [&](int kt) {
@@ -247,7 +283,7 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(const bf16_t* __rest
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       *(Chunk16*)(sK + (srow0 + i * 32) * PITCHK + scol) = pk[i];
-      *(Chunk16*)(sV + (srow0 + i * 32) * PITCH + scol) = pv[i];
+      VT::store(sV, srow0 + i * 32, tid & 7, pv[i]);
     }
     __syncthreads();
     if (kt < qt) fetch(kt + 1);
@@ -258,15 +294,11 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(const bf16_t* __rest
       kf[sub][0] = *(const bf16x8*)(krow + lg * 8);
       kf[sub][1] = *(const bf16x8*)(krow + 32 + lg * 8);
     }
-    bf16x4 vf[4][2][2];
+    bf16x8 vf[4][2];
 #pragma unroll
     for (int d = 0; d < 4; ++d)
 #pragma unroll
-      for (int pr = 0; pr < 2; ++pr) {
-        const bf16_t* vrow = sV + (d * 16 + lr) * PITCH + pr * 32 + lg * 4;
-        vf[d][pr][0] = *(const bf16x4*)vrow;
-        vf[d][pr][1] = *(const bf16x4*)(vrow + 16);
-      }
+      for (int pr = 0; pr < 2; ++pr) vf[d][pr] = VT::frag(sV, d * 16 + lr, pr * 4 + lg);
     f32x4 sc[4];
     float mt = -INFINITY;
 #pragma unroll
@@ -302,10 +334,7 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(const bf16_t* __rest
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[d][r] *= alpha;
 #pragma unroll
-      for (int pr = 0; pr < 2; ++pr) {
-        const bf16x8 va = __builtin_shufflevector(vf[d][pr][0], vf[d][pr][1], 0, 1, 2, 3, 4, 5, 6, 7);
-        o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pf[pr], o[d], 0, 0, 0);
-      }
+      for (int pr = 0; pr < 2; ++pr) o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[d][pr], pf[pr], o[d], 0, 0, 0);
     }
   }
   lsum += __shfl_xor(lsum, 16, 64);
@@ -364,9 +393,9 @@ __global__ __launch_bounds__(256) void xattn_kernel(const bf16_t* __restrict__ q
   float mx = -INFINITY, lsum = 0.f;
   constexpr int PK = HD + 16;   // staged K row (elements), read back as 16-byte fragments: 32 bytes of pad are conflict-free for
                                 // ds_read_b128's lane groups (16 bytes cost every read a second cycle: 42 % conflict cycles in round 2)
-  constexpr int PV = KT + 8;    // staged V^T row, read as 8-byte halves: conflict-free at 16 bytes of pad (KT = 64 and 32)
+  using VT = VtTile<KT>;        // staged V^T rows: key-permuted, one ds_read_b128 per fragment (above)
   __shared__ __attribute__((aligned(16))) bf16_t sK[KT * PK];
-  __shared__ __attribute__((aligned(16))) bf16_t sV[HD * PV];
+  __shared__ __attribute__((aligned(16))) bf16_t sV[HD * VT::PITCH];
   constexpr int KC = KT * HD / 8 / 256;   // 16-byte chunks of the K tile per thread
   constexpr int VC = HD * KT / 8 / 256;   // ... of the V^T tile
   constexpr int VCH = KT / 8;             // chunks per V^T row
@@ -393,7 +422,7 @@ __global__ __launch_bounds__(256) void xattn_kernel(const bf16_t* __restrict__ q
 #pragma unroll
     for (int i = 0; i < KC; ++i) { const int c = i * 256 + tid; *(Chunk16*)(sK + (c / (HD / 8)) * PK + (c % (HD / 8)) * 8) = pk[i]; }
 #pragma unroll
-    for (int i = 0; i < VC; ++i) { const int c = i * 256 + tid; *(Chunk16*)(sV + (c / VCH) * PV + (c % VCH) * 8) = pvv[i]; }
+    for (int i = 0; i < VC; ++i) { const int c = i * 256 + tid; VT::store(sV, c / VCH, c % VCH, pvv[i]); }
     __syncthreads();
     if constexpr (PRE) { if (kt + 1 < ntiles) fetch(kt + 1); }
     f32x4 sc[SUB];
@@ -428,12 +457,8 @@ __global__ __launch_bounds__(256) void xattn_kernel(const bf16_t* __restrict__ q
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[d][r] *= alpha;
 #pragma unroll
-      for (int pr = 0; pr < NPF; ++pr) {
-        const bf16_t* vrow = sV + (d * 16 + lr) * PV + pr * 32 + lg * 4;
-        const bf16x4 v0 = *(const bf16x4*)vrow, v1 = *(const bf16x4*)(vrow + 16);
-        const bf16x8 va = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-        o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pf[pr], o[d], 0, 0, 0);
-      }
+      for (int pr = 0; pr < NPF; ++pr)
+        o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(VT::frag(sV, d * 16 + lr, pr * 4 + lg), pf[pr], o[d], 0, 0, 0);
     }
   }
   lsum += __shfl_xor(lsum, 16, 64);
