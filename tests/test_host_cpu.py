@@ -247,6 +247,21 @@ def test_lds_swizzle_keys_are_conflict_free_for_their_access_shapes():
             assert ((a + 512) ^ 16) == b
 
 
+def test_attention_vt_tile_layout_is_a_permutation_and_conflict_free():
+    """csrc/llama_ops.hip VtTile: the V^T tile of the one-pass attention kernels is staged key-permuted so that a lane's P.V fragment is
+    one ds_read_b128.  tools/lds_vt_layout_check.py restates the index functions: every (row, key) lands once, every lane reads the
+    keys (32 pr + 4 lg + r, 32 pr + 16 + 4 lg + r) its P fragment enumerates, and both access shapes (fragment ds_read_b128, staging
+    ds_write_b64) take the conflict-free 4 LDS cycles per wave instruction at every tile shape the kernels instantiate."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import lds_vt_layout_check as V
+    for KT, HD in ((64, 64), (64, 128), (64, 192), (64, 32), (32, 512), (32, 768)):
+        assert V.check(KT, HD) == (4, 4), (KT, HD)
+    # the layout rounds 2-4 used (two 8-byte halves at a 144-byte pitch, merged into ds_read2_b64: 16 contiguous lanes, banks mod 32) was
+    # 2-way conflicted: rows r and r + 8 of a fragment meet on the same banks
+    pairs = [((row * 144) >> 3) & 15 for row in range(16)]
+    assert len(set(pairs)) == 8
+
+
 LANES_WORKER = r"""
 import os, sys, threading, time, random, torch
 sys.path.insert(0, sys.argv[1])
