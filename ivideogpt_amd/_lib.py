@@ -102,6 +102,7 @@ EXPORTS = {
     "ivg_op_add_rmsnorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "ivg_op_conv_in": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]),
     "ivg_op_sample": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ivg_debug_counter": (C.c_int64, [C.c_char_p]),
 }
 
 _lib = None

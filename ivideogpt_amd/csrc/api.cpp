@@ -786,6 +786,11 @@ int ivg_op_conv_x3(const ivg_igemm_args* a, const void* w_x3, int groups, const 
   return rc == 0 ? IVG_OK : (rc > 0 ? IVG_ERR_HIP : IVG_ERR_INVALID);
 }
 
+int64_t ivg_debug_counter(const char* name) {
+  if (name && !strcmp(name, "conv3x3_wide")) return conv3x3_wide_launches();
+  return -1;
+}
+
 int ivg_op_skinny(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy, int flags, int dtype, ivg_stream stream) {
   SkinnyArgs s; s.X = X; s.W = W; s.Y = Y; s.M = M; s.N = N; s.K = K; s.ldx = ldx; s.ldw = ldw; s.ldy = ldy; s.flags = flags;
   return launch_skinny(s, (DType)dtype, (hipStream_t)stream) ? IVG_ERR_HIP : IVG_OK;

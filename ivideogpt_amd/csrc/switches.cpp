@@ -22,6 +22,8 @@ static Switches read_env() {
   s.gn_fuse = env_int("IVG_GN_FUSE", 1) != 0;
   s.gn_apply_fuse = env_int("IVG_GN_APPLY_FUSE", 1) != 0;
   s.x3 = env_int("IVG_X3", 1) != 0;
+  s.conv_wide = env_int("IVG_CONV_WIDE", 1) != 0;
+  s.conv_wide_grid = env_int("IVG_CONV_WIDE_GRID", 0);
   s.graph = env_int("IVG_GRAPH", 0) == 1;
   s.dg3_warm = env_int("IVG_DG3_WARM", 1) != 0;
   s.conv_cap = env_int("IVG_CONV_CAP", 0) == 1;
