@@ -86,6 +86,13 @@ typedef struct {
   int32_t max_batch;       /* trajectories per call */
   int32_t max_frames;      /* frames per clip (T) */
   int32_t max_seq;         /* KV-cache length (0: max_position_embeddings) */
+  /* ---- launch policy of THIS engine (no process-global state on the data path: a latency engine and a throughput engine can
+   * live in one process, e.g. mbrl/video_predictor.py's step-wise rollout beside a batch evaluator) */
+  int32_t decode_lds_kb;   /* LDS budget of a decode-step GEMM workgroup in KiB (16 .. 160); 0: the process default (IVG_DECODE_LDS_KB,
+                            * 160 = a whole CU: fastest for one batch alone; <= 52: three or four workgroups of DIFFERENT engines share a CU --
+                            * what several batches in flight on one GPU want).  Best effort: shapes whose smallest plan is larger keep it.
+                            * The budget picks the kernel generation and therefore the fp32 summation order: tokens of two budgets are
+                            * each deterministic and batch-invariant but not bit-comparable with one another. */
 } ivg_config;
 
 int ivg_create(const ivg_config* cfg, const ivg_tensor* weights, int n_weights, int device, ivg_engine** out);
@@ -101,6 +108,8 @@ void ivg_reload_switches(void);
  * ivideogpt/transformer/action_model.py:61,89,104,128,143): the logits are divided by it before the top-k filter
  * (TemperatureLogitsWarper).  Engine state, default 1.0; IVG_ERR_INVALID unless strictly positive and finite (HF raises). */
 int ivg_set_temperature(ivg_engine* e, float temperature);
+/* ivg_config.decode_lds_kb of a live engine (0 = back to the process default); takes effect at the next generate call */
+int ivg_set_decode_lds_kb(ivg_engine* e, int kb);
 
 /* CompressiveVQModel.set_context_length (compressive_vq_model.py:154-158): keeps the LAST k frames of kv_pos_emb. */
 int ivg_set_context_length(ivg_engine* e, int context_length);

@@ -29,6 +29,7 @@ class IvgConfig(C.Structure):
         ("rms_norm_eps", C.c_float), ("action_dim", C.c_int32), ("reward_head", C.c_int32),
         ("encode_dtype", C.c_int32), ("decode_dtype", C.c_int32), ("llm_dtype", C.c_int32),
         ("max_batch", C.c_int32), ("max_frames", C.c_int32), ("max_seq", C.c_int32),
+        ("decode_lds_kb", C.c_int32),
     ]
 
 
@@ -58,6 +59,7 @@ EXPORTS = {
     "ivg_destroy": (None, [C.c_void_p]),
     "ivg_reload_switches": (None, []),
     "ivg_set_temperature": (C.c_int, [C.c_void_p, C.c_float]),
+    "ivg_set_decode_lds_kb": (C.c_int, [C.c_void_p, C.c_int]),
     "ivg_set_context_length": (C.c_int, [C.c_void_p, C.c_int]),
     "ivg_tokenize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ivg_encode_context": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -295,6 +295,8 @@ int ivg_create(const ivg_config* cfg, const ivg_tensor* weights, int n_weights, 
   // issues a launch in ~4 us against ~10 us of device time per kernel, so it stays ahead).  IVG_GRAPH=1 captures the step into
   // a hipGraph (8 steps per launch) for callers that need the host thread back early.
   e->use_graph = sw().graph != 0;
+  if (cfg->decode_lds_kb != 0 && (cfg->decode_lds_kb < 16 || cfg->decode_lds_kb > 160)) { e->err = "ivg_create: decode_lds_kb must be 0 (process default) or 16 .. 160"; return bail(IVG_ERR_INVALID); }
+  e->decode_lds_kb = cfg->decode_lds_kb;
   if (cfg->encode_dtype == IVG_F32X3) { e->err = "ivg_create: encode_dtype cannot be IVG_F32X3 (bit-exact VQ indices need the exact fp32 chain)"; return bail(IVG_ERR_INVALID); }
   // IVG_F32X3: fp32 tensors, split-bf16 matrix arithmetic (conv3x3.hip / igemm.hip X3 instances)
   e->dec_x3 = cfg->decode_dtype == IVG_F32X3; e->llm_x3 = cfg->llm_dtype == IVG_F32X3;
@@ -379,6 +381,13 @@ int ivg_set_temperature(ivg_engine* e, float temperature) {
   if (!e) return IVG_ERR_INVALID;
   if (!(temperature > 0.0f) || !std::isfinite(temperature)) return e->fail(IVG_ERR_INVALID, "temperature must be a strictly positive float");   // HF raises the same
   e->temperature = temperature;
+  return IVG_OK;
+}
+
+int ivg_set_decode_lds_kb(ivg_engine* e, int kb) {
+  if (!e) return IVG_ERR_INVALID;
+  if (kb != 0 && (kb < 16 || kb > 160)) return e->fail(IVG_ERR_INVALID, "decode_lds_kb must be 0 (process default) or 16 .. 160");
+  e->decode_lds_kb = kb;
   return IVG_OK;
 }
 
@@ -821,7 +830,7 @@ int ivg_op_conv_in(const void* video, int video_dtype, const float* w, const flo
 }
 
 int ivg_op_sample(const float* logits, int B, int V, int top_k, float temperature, const float* uniforms, int64_t* out, ivg_stream stream) {
-  if (!(temperature > 0.0f)) return IVG_ERR_INVALID;
+  if (!(temperature > 0.0f) || !std::isfinite(temperature)) return IVG_ERR_INVALID;   // as ivg_set_temperature
   // one draw per row through the rollout's sampler kernel (token j = 1 of a prompt of length 0; no embedding: H = 0)
   StepState* state = nullptr;
   if (hipMalloc((void**)&state, sizeof(StepState)) != hipSuccess) return IVG_ERR_HIP;

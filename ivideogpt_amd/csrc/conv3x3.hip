@@ -583,7 +583,7 @@ int launch_conv3x3(const IgemmArgs& a, DType dtype, hipStream_t stream) {
     d.gn_part = (double2*)a.gn_part; d.gn_groups = a.gn_groups;
     a.gn_chunks = d.tiles_per_img * d.tiles_n;
   }
-  d.sp_total = 0; d.sp_pairs = 0;
+  d.sp_total = 0; d.sp_pairs = 0; d.probe = 0; d.stagger = 0;
   if (dtype == BF16 && bn == 128 && !a.W_x3) {   // persistent two-tile kernel (conv3x3w.hip) where it covers the shape
     const int rc = launch_conv3x3_wide(d, a.Nimg, a.ups != 0, TW, gna, stream);
     if (rc != -1) return rc;

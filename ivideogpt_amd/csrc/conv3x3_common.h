@@ -18,6 +18,8 @@ struct Conv3Dev {
   double2* gn_part;                  // GroupNorm statistics of the output (null: off): [img][chunk = spatial tile x N tile][group]
   int gn_groups, gn_off;             // gn_off: byte offset of the per-channel partial sums in LDS (behind everything else)
   int sp_total, sp_pairs;            // conv3x3w.hip: spatial tiles of the launch (images x tiles per image) and pairs of them
+  int stagger;                       // conv3x3w.hip: start phases of the persistent workgroups (see the kernel)
+  int probe;                         // conv3x3w.hip, measurement only (IVG_CONV_WIDE_PROBE): 1 = no epilogue, 2 = no input normalisation
 };
 
 

@@ -1,27 +1,36 @@
-// Persistent two-tile 3x3 convolution for gfx950 (bf16, 128 output channels per workgroup) -- the decoder trunks' FLOP majority
-// (vae.py:298-371, conditional_vae.py:186-212: ResnetBlock2D.conv1 / conv2, Upsample2D.conv).
+// Persistent two-tile 3x3 convolution for gfx950 (bf16, 128 output channels per workgroup) -- an ALTERNATIVE to conv3x3.hip's kernel for
+// the decoder trunks (vae.py:298-371, conditional_vae.py:186-212), selected by IVG_CONV_WIDE (default OFF).
 //
-// Why a second generation of conv3x3.hip's kernel.  That kernel (256 pixels x 128 channels per workgroup, two workgroups per CU)
-// asks the L2 for 8 KiB of weights per (tap, chunk) step of 16 MFMAs per wave: at the matrix pipe's full rate a CU would have to
-// ingest (72 KiB weights + 22 KiB halo) per 4,608 clocks = 20 B/clk through LDS-DMA, and every measured instance sits where that
-// product is 8-11 B/clk/CU whatever its shape (38-54 % MFMA-busy on the plain / fused-GroupNorm instances with their 340-row halo,
-// 61-68 % on the upsampling ones whose halo is a third of that; the f32 and split-bf16 instances, 8 x / 2 x the MFMA clocks on the
-// same bytes, run at 85-92 %).  The two co-resident workgroups of a CU stream the SAME weight tiles (N tile fastest in the block
-// order) into two private rings.  Here ONE workgroup per CU owns TWO spatial tiles (2 x 256 pixels, any two consecutive tiles of the
-// launch: neighbours in an image or tiles of two images) against ONE weight ring:
-//   * weight bytes per FLOP halved (12.5 B/clk/CU at the full MFMA rate), LDS fragment reads per MFMA down by a quarter (a wave
-//     reads 4 weight fragments for 32 MFMAs instead of 16),
-//   * 8 waves x 256 registers: a wave holds a 2 x (64 pixels x 64 channels) accumulator tile (128 registers),
-//   * PERSISTENT: the grid is one workgroup per CU, each walks its items (tile pair x N tile; the N tile is fixed per workgroup so
-//     the weight stream simply wraps around) -- the first halo chunk, the first two weight tiles and (fused GroupNorm) the first
-//     chunk's normalisation of item i + 1 are requested under the LAST chunk of item i exactly like any next chunk, so the main
-//     loop never drains; what is exposed per item is the epilogue alone,
-//   * epilogue without workgroup barriers around the stores: every wave stages its own 64 x 64 sub-tile in a private LDS region
-//     (the parity-1 halo buffers, dead by then) and stores whole 128-byte runs; one barrier per item (staging region -> halo again).
-// Everything else is conv3x3.hip's design (its header has the measurements behind each choice): halo tile of a 32-channel chunk
-// staged once by LDS-DMA and reused by nine taps, source-side XOR swizzle, three-slot weight ring requested two steps ahead,
-// counted s_waitcnt vmcnt(n) + raw s_barrier, tap loop unrolled with immediate offsets, GroupNorm + SiLU of the input applied in
-// place in LDS (GNA), GroupNorm statistics of the output from the epilogue (fixed order, no atomics).
+// What it is.  conv3x3.hip: 256 pixels x 128 channels per workgroup, two workgroups per CU, both streaming the SAME weight tiles into
+// private rings.  Here ONE workgroup per CU owns TWO spatial tiles (2 x 256 pixels, any two consecutive tiles of the launch) against ONE
+// weight ring:
+//   * weight bytes per FLOP halved, LDS fragment reads per MFMA down by a quarter (a wave reads 4 weight + 8 halo fragments for 32 MFMAs),
+//   * 8 waves x 256 registers: a wave holds a 2 x (64 pixels x 64 channels) accumulator tile (128 registers), MFMAs written as in-place
+//     inline asm (the register allocator otherwise rotates the accumulators through ~190 registers and spills addresses),
+//   * PERSISTENT: the grid is one workgroup per CU, each walks its items (tile pair x N tile; the N tile is fixed per workgroup so the
+//     weight stream simply wraps around) -- the first halo chunk, the first two weight tiles and (fused GroupNorm) the first chunk's
+//     normalisation of item i + 1 are requested under the LAST chunk of item i exactly like any next chunk: the main loop never drains,
+//   * the halo fragments of step s + 1 are read under the MFMAs of step s (PF), into the registers step s has just finished with,
+//   * epilogue without workgroup barriers around the stores: every wave stages its own 64 x 64 sub-tile in a private LDS region (the
+//     parity-1 halo buffers, dead by then) and stores whole 128-byte runs; one barrier per item.
+// Everything else is conv3x3.hip's design: halo tile of a 32-channel chunk staged once by LDS-DMA and reused by nine taps, source-side
+// XOR swizzle, three-slot weight ring requested two steps ahead, counted s_waitcnt vmcnt(n) + raw s_barrier, unrolled taps with
+// immediate offsets, GroupNorm + SiLU of the input in place in LDS (GNA), output statistics from the epilogue (fixed order, no atomics).
+// Same bf16 products in the same fp32 summation order: bit-identical to conv3x3.hip (tests/test_gpu_conv_wide.py).
+//
+// What round 5 measured with it (profiles/r05_conv_*.txt, r05_mfma_power.txt; DESIGN.md "what bounds the convolutions"):
+//   * in isolation (tools/conv_ab.py, no residual / statistics): +13 % on the 64 x 64 fused-GroupNorm layers, +1 ... +3 % on the
+//     upsampling ones, level or -3 % elsewhere; probes with the epilogue / the in-place normalisation switched off price them at
+//     0.05-0.46 ms and 0.19-0.43 ms per launch -- both exposed here (one workgroup per CU: nothing overlaps them), both hidden by the
+//     co-resident workgroup in conv3x3.hip;
+//   * inside the decode stage (residual reads, statistics, kernel trace of tools/quick_bench.py): 38.4 ms of conv3x3 per decode
+//     against 37.9 -- 1 % BEHIND, hence off by default;
+//   * why no structure moves these kernels: they run at the socket's power limit.  tools/conv_power.py: the 256-pixel kernel on random
+//     data draws 1,400 W (the cap) at 1,770 MHz for 1,473 TFLOP/s; the SAME launch on all-zero data 1,125 W at 2,383 MHz for 1,965; this
+//     kernel 1,381 W at 2,089 MHz for 1,438 (fewer LDS / DMA bytes, more stalls: the firmware trades them for clock).
+//     tools/ubench/mfma_power.hip: a pure stream of these MFMAs reaches 2,417 TFLOP/s on zeros (790 W), 1,950-2,000 on random operands
+//     (1,305 W, sclk 2.03 GHz), 1,670-1,770 with the fragment reads of either kernel beside it.  MFMA-busy x clock, not MFMA-busy, is what
+//     a launch delivers, and the product is set by the energy the launch spends.
 #include <algorithm>
 #include <type_traits>
 
@@ -39,7 +48,14 @@ __device__ __forceinline__ void mfma_bf16_acc(f32x4& c, const Chunk16& w, const 
   asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(w), "v"(x));
 }
 
-template <bool UPS, int TW, bool GNA>
+template <int N> __device__ __forceinline__ void wait_dma_keep4() {   // as wait_dma_keep, but the newest FOUR LDS operations may stay in flight
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(4)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(4)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(4)" ::: "memory");
+}
+
+template <bool UPS, int TW, bool GNA, bool PF>
 __global__ __launch_bounds__(512, 2) void conv3x3w_kernel(const Conv3Dev p) {
   using T = bf16_t;
   constexpr int BN = 128, CK = 32, WN = 64, FM = 4, FN = 4, NT = 2;
@@ -227,6 +243,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3w_kernel(const Conv3Dev p) {
   };
 
   const int nchunks = p.Cin / CK;   // even (launcher)
+  // Every item of a launch costs the same, so workgroups that start together reach their epilogues together: 256 CUs x 128 KiB of
+  // stores (+ the residual reads) hit the memory system in one burst while it idles during the main loops.  p.stagger > 0: the
+  // workgroups start in eight phases, p.stagger x ~0.75 us apart, and keep that offset for the whole launch.
+  for (int i = (slot & 7) * p.stagger; i > 0; --i) __builtin_amdgcn_s_sleep(24);
   // ---- prologue of the workgroup's FIRST item (every later item's first chunk arrives under its predecessor's last one)
   setup_H(sp2);
   zero_fill(0);
@@ -246,9 +266,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3w_kernel(const Conv3Dev p) {
   }
   const bool early = wave < 4;   // the two waves of a SIMD (w, w + 4) issue their DMA at different points of a step
 
+  // PF: the halo fragments of step s + 1 are read UNDER the MFMAs of step s, into the registers step s has just finished with (tile 0's
+  // after its 16 MFMAs, tile 1's before the barrier): two waves per SIMD that meet at every barrier cannot hide each other's LDS
+  // latency, and without this a step starts with twelve fragment reads in front of its first MFMA (only the four weight fragments are
+  // left there: the weight tile of a step is only known to have landed at the barrier in front of it).
+  Chunk16 xa[NT][FM];
+  auto load_xa = [&](int par, int t, int tap) {
+#pragma unroll
+    for (int b = 0; b < FM; ++b) xa[t][b] = par ? read_a(1, t, tap, b) : read_a(0, t, tap, b);
+  };
   // one 32-channel chunk = nine steps, consumed from the halo buffers of parity PAR (compile time: buffer addresses are immediates).
-  // cnext: the chunk whose halo is staged under this one -- chunk + 1 of this item, or chunk 0 of the next item (H was switched)
-  auto run_chunk = [&](int chunk, int cnext, bool more, auto par) {
+  // cnext: the chunk whose halo is staged under this one -- chunk + 1 of this item, or chunk 0 of the next item (H was switched);
+  // item_end: this is the item's last chunk (its last step prefetches nothing: the epilogue comes first)
+  auto run_chunk = [&](int chunk, int cnext, bool more, bool item_end, auto par) {
     constexpr int PAR = decltype(par)::value;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -264,30 +294,48 @@ __global__ __launch_bounds__(512, 2) void conv3x3w_kernel(const Conv3Dev p) {
       if constexpr (GNA) {
         if (more) {
           if (tap == 0) issued += load_coef(cnext);
-          // piece pc was requested at tap pc and has landed by the end of tap pc + 1: normalised at tap pc + 3
-          if (tap >= 3 && tap - 3 < NP) transform_piece(cnext, tap - 3, 1 - PAR);
+          // piece pc was requested at tap pc and has landed by the end of tap pc + 1: normalised at tap pc + 2 (the last one at tap 7:
+          // tap 8 already reads the next chunk's fragments)
+          // (normalising in the second wave of every SIMD AFTER its MFMAs instead -- exponentials and reciprocals of one wave beside the
+          // MFMAs of the other -- changes nothing: the launch is bound by the energy it spends, not by what overlaps what; header)
+          if (tap >= 2 && tap - 2 < NP && !(p.probe & 2)) transform_piece(cnext, tap - 2, 1 - PAR);
         }
       }
       if (!GNA && !early) issue_dma();
       __builtin_amdgcn_sched_barrier(0);
-      Chunk16 wv[FN], xa[NT][FM];
+      Chunk16 wv[FN];
 #pragma unroll
       for (int a = 0; a < FN; ++a) wv[a] = *(const Chunk16*)(wbuf0 + w_base + ((tap % 3) * W_BYTES + a * 1024));
+      if constexpr (!PF) {
+        load_xa(PAR, 0, tap);
+        load_xa(PAR, 1, tap);
+      }
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int b = 0; b < FM; ++b) xa[t][b] = read_a(PAR, t, tap, b);
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
+      for (int t = 0; t < NT; ++t) {
 #pragma unroll
         for (int b = 0; b < FM; ++b)
 #pragma unroll
-          for (int a = 0; a < FN; ++a)
-            mfma_bf16_acc(acc[t][a][b], wv[a], xa[t][b]);
-      if (issued == 0) wait_dma_keep<0>();
-      else if (issued == 1) wait_dma_keep<1>();
-      else if (issued == 2) wait_dma_keep<2>();
-      else wait_dma_keep<3>();
+          for (int a = 0; a < FN; ++a) mfma_bf16_acc(acc[t][a][b], wv[a], xa[t][b]);
+        if constexpr (PF) {
+          __builtin_amdgcn_sched_barrier(0);   // the reads below reuse xa[t]: not before its last MFMA has been issued
+          if (tap < 8) load_xa(PAR, t, tap + 1);
+          else if (!item_end) load_xa(1 - PAR, t, 0);
+        }
+      }
+      // everything issued BEFORE this step has landed once at most `issued` transfers are still in flight.  LDS: this step's weight
+      // fragments were consumed by its MFMAs and an in-place normalisation was issued before them (LDS operations of a wave complete in
+      // order) -- only the four fragment reads of tile 1's NEXT step may stay in flight across the barrier (PF)
+      if (PF && !(tap == 8 && item_end)) {
+        if (issued == 0) wait_dma_keep4<0>();
+        else if (issued == 1) wait_dma_keep4<1>();
+        else if (issued == 2) wait_dma_keep4<2>();
+        else wait_dma_keep4<3>();
+      } else {
+        if (issued == 0) wait_dma_keep<0>();
+        else if (issued == 1) wait_dma_keep<1>();
+        else if (issued == 2) wait_dma_keep<2>();
+        else wait_dma_keep<3>();
+      }
       __builtin_amdgcn_s_barrier();
     }
   };
@@ -301,8 +349,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3w_kernel(const Conv3Dev p) {
     const int sp2n = sp2 + L;
     const bool has_next = sp2n < p.sp_pairs;
     clear_acc();
+    if constexpr (PF) { load_xa(0, 0, 0); load_xa(0, 1, 0); }   // step 0's fragments (every later step's arrive under its predecessor)
     for (int chunk = 0; chunk < nchunks; chunk += 2) {
-      run_chunk(chunk, chunk + 1, true, std::integral_constant<int, 0>{});
+      run_chunk(chunk, chunk + 1, true, false, std::integral_constant<int, 0>{});
       const bool last = chunk + 2 >= nchunks;
       if (last && has_next) {
         // the halo source state moves on to the next item: its chunk 0 arrives in the parity-0 buffers (free since the barrier
@@ -310,7 +359,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3w_kernel(const Conv3Dev p) {
         setup_H(sp2n);
         zero_fill(0);
       }
-      run_chunk(chunk + 1, last ? 0 : chunk + 2, !last || has_next, std::integral_constant<int, 1>{});
+      run_chunk(chunk + 1, last ? 0 : chunk + 2, !last || has_next, last, std::integral_constant<int, 1>{});
     }
 
     // ---- epilogue of item sp2: bias, residual, SiLU, GroupNorm statistics, per-wave staged stores
@@ -323,7 +372,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3w_kernel(const Conv3Dev p) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const TileGeo g = tile_geo(sp2, t);
-      if (!g.valid) continue;   // (odd number of spatial tiles: the last pair's second tile repeats the first and stores nothing)
+      if (!g.valid || (p.probe & 1)) continue;   // (odd number of spatial tiles: the last pair's second tile repeats the first and stores nothing)
       const long ibase = (long)g.img * p.c_grp_stride;
       float gs[FN][4], gq[FN][4];
 #pragma unroll
@@ -409,7 +458,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3w_kernel(const Conv3Dev p) {
   }
 }
 
-template <bool UPS, int TW, bool GNA>
+template <bool UPS, int TW, bool GNA, bool PF>
 static int launch_c3w(const Conv3Dev& d, int grid, hipStream_t stream) {
   constexpr int TH = 256 / TW;
   constexpr int HROWS = (UPS ? TH / 2 + 2 : TH + 2) * (UPS ? TW / 2 + 2 : TW + 2);
@@ -417,7 +466,7 @@ static int launch_c3w(const Conv3Dev& d, int grid, hipStream_t stream) {
   constexpr int SMEM = 8 * 64 * (64 * 2 + 16) + 2 * HB + 3 * 128 * 64 + 8192 + 1024;
   static_assert(SMEM <= 160 * 1024, "one workgroup per CU");
   static DynLdsOnce once;
-  auto kfn = conv3x3w_kernel<UPS, TW, GNA>;
+  auto kfn = conv3x3w_kernel<UPS, TW, GNA, PF>;
   if (hipError_t e = ensure_dyn_lds(once, (const void*)kfn, 160 * 1024); e != hipSuccess) return (int)e;
   // (always more than half of a CU's LDS: a second workgroup of this grid never shares the CU)
   hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(512), std::max(SMEM, 82 * 1024), stream, d);
@@ -448,17 +497,27 @@ int launch_conv3x3_wide(const Conv3Dev& d0, int nimg, bool ups, int TW, bool gna
   if (((uintptr_t)d0.Y & 15) || ((d0.flags & IG_RESIDUAL) && ((uintptr_t)d0.R & 7)) || ((d0.flags & IG_BIAS_N) && ((uintptr_t)d0.bias & 15))) return -1;
   if ((long)d0.c_grp_stride % 8 != 0) return -1;
   if (gna && ups) return -1;
+  // IVG_CONV_WIDE=1: where it is the faster of the two IN ISOLATION (tools/conv_ab.py, profiles/r05_conv_ab_*.txt): ONE N tile (the
+  // 64 x 64 / 256 x 256 levels, Cout = 128: +9 ... +16 %) and the upsampling convolutions up to four N tiles (+1 ... +3 %).  =2: wherever
+  // it covers the shape (fused-GroupNorm layers with two and four N tiles are level or 1-3 % behind the 256-pixel kernel: every N tile
+  // normalises the halo again, and nothing overlaps a workgroup's epilogue; 768-channel upsampling 6 % behind).
+  if (sw().conv_wide != 2 && !(d0.tiles_n == 1 || (ups && d0.tiles_n <= 4))) return -1;
   Conv3Dev d = d0;
   d.sp_total = nimg * d.tiles_per_img;
   d.sp_pairs = (d.sp_total + 1) / 2;
+  d.probe = sw().conv_wide_probe;
   // grid: one workgroup per CU, a multiple of 8 XCDs x N tiles; launches that would leave CUs without an item stay on the
   // two-workgroups-per-CU kernel
   const int unit = 8 * d.tiles_n;
   int grid = device_cus() / unit * unit;
   if (sw().conv_wide_grid > 0 && sw().conv_wide_grid % unit == 0) grid = sw().conv_wide_grid;   // development: another grid size
   if (grid <= 0 || (long)d.sp_pairs * d.tiles_n < grid) return -1;
+  // start phases (see the kernel): worth +5 % where a workgroup walks many short items (64 x 64, 36 steps, 28 items), a loss on launches
+  // of a few items per workgroup (the context decoder's 128 frames)
+  const long items_per_wg = (long)d.sp_pairs * d.tiles_n / grid;
+  d.stagger = sw().conv_wide_stagger >= 0 ? sw().conv_wide_stagger : (items_per_wg >= 12 ? 2 : 0);
   g_wide_launches.fetch_add(1, std::memory_order_relaxed);
-#define IVG_C3W(U, W_, G_) launch_c3w<U, W_, G_>(d, grid, stream)
+#define IVG_C3W(U, W_, G_) (sw().conv_wide_pf ? launch_c3w<U, W_, G_, true>(d, grid, stream) : launch_c3w<U, W_, G_, false>(d, grid, stream))
   if (gna) return TW == 16 ? IVG_C3W(false, 16, true) : IVG_C3W(false, 32, true);
   if (ups) return TW == 16 ? IVG_C3W(true, 16, false) : IVG_C3W(true, 32, false);
   return TW == 16 ? IVG_C3W(false, 16, false) : IVG_C3W(false, 32, false);

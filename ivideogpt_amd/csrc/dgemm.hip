@@ -437,8 +437,11 @@ int launch_dgemm(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
     while (MF * FN > allowed && FN > (glu ? 2 : 1)) FN >>= 1;
   }
   // staging budget: waves * LG * (MF + FN) * 2 KiB of LDS.  Over budget: first more (shorter) bursts per wave -- the K partition over
-  // the waves, and so every sum order, stays what it is -- then fewer row tiles per workgroup
-  const int budget = sw().decode_lds_kb * 1024;   // (IVG_DECODE_LDS_KB: room left for another batch's conv3x3 workgroup on the CU)
+  // the waves, and so every sum order, stays what it is -- then fewer row tiles per workgroup.  BEST EFFORT: the wave count of a shape is
+  // never changed for the budget (it is the K partition), so a pick whose smallest form (one line group, one row tile) is still larger
+  // launches with that form -- 16 waves x FN = 2 is 96 KiB whatever the budget says (lm_head and the medium transformer's o-proj /
+  // gate-up; the q/k/v, gate-up and down GEMMs of the small transformer do fit 40 KiB)
+  const int budget = (a.lds_kb > 0 ? a.lds_kb : sw().decode_lds_kb) * 1024;   // (IVG_DECODE_LDS_KB: room left for another batch's conv3x3 workgroup on the CU)
   while (lgv > 1 && waves * lgv * (MF + FN) * 2048 > budget) {
     const int total = lgv * nburst;           // lines per wave
     --lgv;

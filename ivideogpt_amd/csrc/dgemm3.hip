@@ -478,7 +478,7 @@ static bool dg3_plan(const SkinnyArgs& a, DType dtype, Dg3Plan& pl) {
   // everything in flight at once needs waves * (MF + FN) * 2 KiB per line of K; over budget: fewer row tiles per workgroup (never
   // another K partition: MF only picks which rows share a workgroup).  The budget is the whole LDS of a CU unless the caller wants
   // these workgroups to fit BESIDE a capped conv3x3 workgroup of another batch in flight (IVG_DECODE_LDS_KB, switches.h).
-  const int budget = sw().decode_lds_kb * 1024;
+  const int budget = (a.lds_kb > 0 ? a.lds_kb : sw().decode_lds_kb) * 1024;
   while (MF > 1 && waves * (MF + FN) * 2048 > budget) MF >>= 1;
   if (waves * (MF + FN) * 2048 > budget) return false;
   const int ring = klw >= 2 && waves * 2 * (MF + FN) * 2048 <= budget ? 2 : 1;

@@ -91,6 +91,7 @@ struct ivg_engine {
   size_t gen_bytes = 0;
   std::unordered_map<std::string, hipGraphExec_t> graphs;
   bool use_graph = false;     // IVG_GRAPH=1 at ivg_create (switches.h)
+  int decode_lds_kb = 0;      // LDS budget of this engine's decode GEMMs (ivg_config.decode_lds_kb / ivg_set_decode_lds_kb; 0: process default)
   float temperature = 1.0f;   // sampling temperature of the rollout (ivg_set_temperature; HF TemperatureLogitsWarper semantics)
   ivg::ProfClass prof[IVG_K_COUNT];
   unsigned long long* attn_prof = nullptr;  // [layers][IVG_ATTN_PROF_SLOTS][2][Lmax] wall-clock stamps of the decode attention

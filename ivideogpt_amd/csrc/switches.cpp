@@ -22,8 +22,13 @@ static Switches read_env() {
   s.gn_fuse = env_int("IVG_GN_FUSE", 1) != 0;
   s.gn_apply_fuse = env_int("IVG_GN_APPLY_FUSE", 1) != 0;
   s.x3 = env_int("IVG_X3", 1) != 0;
-  s.conv_wide = env_int("IVG_CONV_WIDE", 1) != 0;
+  s.conv_wide = env_int("IVG_CONV_WIDE", 0);
+  if (s.conv_wide < 0 || s.conv_wide > 2) s.conv_wide = 0;
   s.conv_wide_grid = env_int("IVG_CONV_WIDE_GRID", 0);
+  s.conv_wide_pf = env_int("IVG_CONV_WIDE_PF", 1) != 0;
+  s.conv_wide_probe = env_int("IVG_CONV_WIDE_PROBE", 0);
+  s.conv_wide_stagger = env_int("IVG_CONV_WIDE_STAGGER", -1);
+  if (s.conv_wide_stagger > 64) s.conv_wide_stagger = -1;
   s.graph = env_int("IVG_GRAPH", 0) == 1;
   s.dg3_warm = env_int("IVG_DG3_WARM", 1) != 0;
   s.conv_cap = env_int("IVG_CONV_CAP", 0) == 1;
@@ -32,18 +37,18 @@ static Switches read_env() {
   return s;
 }
 
-// A reload publishes a NEW table and leaves the old one alive (a launcher on another host thread may still be reading it): a few
-// dozen bytes per ivg_create, bounded by a small ring that is only recycled after 64 further reloads.
+// Every reload publishes a NEW immutable table through one atomic pointer and never frees or rewrites an old one (a launcher on
+// another host thread may hold a reference for the length of a launch; ~60 bytes per ivg_create / ivg_reload_switches, deliberately
+// leaked).  getenv() is only called here, under the mutex -- a Python thread changing os.environ while another thread reloads is the
+// caller's race (ivideogpt_amd/switches.py: set / override are not to be called while batches are in flight).
 static std::atomic<const Switches*> g_cur{nullptr};
+static std::atomic<unsigned> g_gen{0};
 static std::mutex g_mu;
-static Switches g_ring[64];
-static unsigned g_next = 0;
 
 void reload_switches() {
   std::lock_guard<std::mutex> lk(g_mu);
-  Switches& slot = g_ring[g_next++ & 63];
-  slot = read_env();
-  g_cur.store(&slot, std::memory_order_release);
+  g_cur.store(new Switches(read_env()), std::memory_order_release);
+  g_gen.fetch_add(1, std::memory_order_release);
 }
 
 const Switches& sw() {
@@ -51,5 +56,7 @@ const Switches& sw() {
   if (!p) { reload_switches(); p = g_cur.load(std::memory_order_acquire); }
   return *p;
 }
+
+unsigned switches_generation() { return g_gen.load(std::memory_order_acquire); }
 
 }  // namespace ivg

@@ -12,8 +12,12 @@
 //   IVG_FLASH_XATT           1        0: tokenizer attention as score GEMM + softmax + P.V GEMM
 //   IVG_GN_FUSE              1        0: every GroupNorm computes its own statistics (1: reduced by the producing conv3x3's epilogue)
 //   IVG_GN_APPLY_FUSE        1        0: GroupNorm + SiLU as a separate apply pass (1: inside the consuming conv3x3's halo staging)
-//   IVG_CONV_WIDE            1        0: bf16 3x3 convolutions on conv3x3.hip's 256-pixel kernel only (1: the persistent two-tile kernel
-//                                        of conv3x3w.hip where it covers the shape);  IVG_CONV_WIDE_GRID: its grid size (development)
+//   IVG_CONV_WIDE            0        0: bf16 3x3 convolutions on conv3x3.hip's 256-pixel kernel only; 1: the persistent two-tile kernel of
+//                                        conv3x3w.hip for the shapes it is faster on IN ISOLATION (one N tile, upsampling); 2: wherever it covers the
+//                                        shape.  Off by default: inside the decode stage (residuals, output statistics) it is 1 % behind. Development:
+//                                        IVG_CONV_WIDE_GRID its grid size, IVG_CONV_WIDE_PF=0 no fragment prefetch across the step barrier,
+//                                        IVG_CONV_WIDE_STAGGER start phases (-1 = by items per workgroup), IVG_CONV_WIDE_PROBE timing probes with
+//                                        WRONG results (1: no epilogue, 2: no input normalisation)
 //   IVG_X3                   1        0: the fp32 decode path of the tokenizer on f32-input MFMAs (1: split-bf16 "x3" convolutions)
 //   ---- launch policy
 //   IVG_GRAPH                0        1: decode steps replayed from hipGraphs (8 steps per launch) instead of eager launches
@@ -26,11 +30,12 @@
 namespace ivg {
 
 struct Switches {
-  int conv3x3 = 1, gemm256 = 1, dg3 = 1, flash_prefill = 1, flash_xatt = 1, gn_fuse = 1, gn_apply_fuse = 1, x3 = 1, conv_wide = 1, conv_wide_grid = 0;
+  int conv3x3 = 1, gemm256 = 1, dg3 = 1, flash_prefill = 1, flash_xatt = 1, gn_fuse = 1, gn_apply_fuse = 1, x3 = 1, conv_wide = 0, conv_wide_grid = 0, conv_wide_pf = 1, conv_wide_probe = 0, conv_wide_stagger = -1;
   int graph = 0, dg3_warm = 1, conv_cap = 0, decode_lds_kb = 160;
 };
 
-const Switches& sw();       // the published table (never null; atomically replaced by reload_switches)
-void reload_switches();     // re-read the environment and publish a new table
+const Switches& sw();             // the published table: immutable, never freed or rewritten (every reload publishes a NEW one)
+void reload_switches();           // re-read the environment and publish a new table
+unsigned switches_generation();   // incremented by every reload (part of the key of captured step graphs)
 
 }  // namespace ivg

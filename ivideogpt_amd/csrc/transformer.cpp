@@ -14,6 +14,7 @@
 //     (deterministic, no partials in HBM);
 //   * the prompt pass uses the 256 x 256-tile GEMM (gemm256.hip), a vectorised RoPE + cache append and, in bf16, a one-pass
 //     causal attention kernel; step-wise callers (MBRL) keep the KV cache across calls (ivg_generate_continue).
+#include <cstring>
 #include "engine_impl.h"
 #include "switches.h"
 
@@ -180,7 +181,7 @@ int Run::prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const voi
                              (size_t)H * esz(dt), B, hipMemcpyDeviceToDevice, st));
     SkinnyArgs s;
     s.X = hidden_last; s.W = e->lm_head; s.Y = logits_last; s.M = B; s.N = V; s.K = H; s.ldx = H; s.ldw = H; s.ldy = V;
-    s.flags = IG_OUT_F32 | SK_NORM; s.eps = c.rms_norm_eps;
+    s.flags = IG_OUT_F32 | SK_NORM; s.eps = c.rms_norm_eps; s.lds_kb = e->decode_lds_kb;
     CK(launch_skinny(s, dt, st));
   }
   e->ws.reset(m);
@@ -231,7 +232,7 @@ static int step_body(ivg_engine* e, hipStream_t st, const GenBuf& g, int B, cons
   };
   auto layer_args = [&](int l, SkinnyArgs* g) {
     const LayerW& w = e->layers[l];
-    for (int k = 0; k < 4; ++k) g[k].x3 = e->llm_x3 && sw().x3;
+    for (int k = 0; k < 4; ++k) { g[k].x3 = e->llm_x3 && sw().x3; g[k].lds_kb = e->decode_lds_kb; }
     SkinnyArgs& s = g[0];
     s.X = x; s.W = w.wqkv; s.Y = qkv; s.M = B; s.N = 3 * H; s.K = H; s.ldx = H; s.ldw = H; s.ldy = 3 * H;
     s.flags = SK_NORM; s.eps = c.rms_norm_eps;
@@ -245,7 +246,7 @@ static int step_body(ivg_engine* e, hipStream_t st, const GenBuf& g, int B, cons
   };
   SkinnyArgs lm;
   lm.X = x; lm.W = e->lm_head; lm.Y = logits; lm.M = B; lm.N = V; lm.K = H; lm.ldx = H; lm.ldw = H; lm.ldy = V;
-  lm.flags = IG_OUT_F32 | SK_NORM; lm.eps = c.rms_norm_eps;
+  lm.flags = IG_OUT_F32 | SK_NORM; lm.eps = c.rms_norm_eps; lm.lds_kb = e->decode_lds_kb;
   lm.bump = (int*)state;  // pos += 1, j += 1 once the last reader of this chain's state (its last attention) is done
   SkinnyArgs cur[4], nxt[4];
   layer_args(0, cur);
@@ -340,7 +341,11 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
     sa.state = g.state;
     sa.temperature = e->temperature;
     // step 1 eagerly (also performs every kernel's one-time attribute setup), then replay a captured step graph
-    const std::string key = std::to_string(Bc) + ":" + std::to_string(e->temperature) + ":" + (uniforms ? "s" : "g") + ":" + std::to_string(top_k) + ":" +
+    // (everything a captured step bakes in: the temperature by its BIT PATTERN -- to_string keeps six decimals --, this engine's LDS
+    // budget and the generation of the switch table, whose kernel-selection switches a replayed graph would otherwise keep ignoring)
+    uint32_t t_bits; memcpy(&t_bits, &e->temperature, 4);
+    const std::string key = std::to_string(Bc) + ":" + std::to_string(t_bits) + ":" + std::to_string(e->decode_lds_kb) + ":" + std::to_string(switches_generation()) +
+                            ":" + (uniforms ? "s" : "g") + ":" + std::to_string(top_k) + ":" +
                             std::to_string(sa.forced_period) + ":" + std::to_string(ctx) + ":" + std::to_string(act_T) + ":" +
                             std::to_string(L0) + (e->attn_prof_on ? ":p" : "") + (e->gemm_prof_on ? ":q" : "");   // (the same step graph serves both entry modes)
     // reward head: reads the residual stream left by the LAST forward pass, i.e. before the final decide-only step

@@ -14,7 +14,8 @@ def _ptr(t):
 
 class Engine:
     def __init__(self, device, tensors, tok_cfg=None, llm_cfg=None, action_dim=0, reward_head=False,
-                 encode_dtype="fp32", decode_dtype="bf16", llm_dtype="bf16", max_batch=1, max_frames=16, max_seq=0):
+                 encode_dtype="fp32", decode_dtype="bf16", llm_dtype="bf16", max_batch=1, max_frames=16, max_seq=0,
+                 decode_lds_kb=0):
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -38,6 +39,7 @@ class Engine:
             cfg.action_dim, cfg.reward_head = int(action_dim or 0), int(bool(reward_head))
         cfg.encode_dtype, cfg.decode_dtype, cfg.llm_dtype = config_code(encode_dtype), config_code(decode_dtype), config_code(llm_dtype)
         cfg.max_batch, cfg.max_frames, cfg.max_seq = int(max_batch), int(max_frames), int(max_seq)
+        cfg.decode_lds_kb = int(decode_lds_kb or 0)   # this engine's launch policy (include/ivg.h): 0 = the process default
         self.cfg = cfg
         names = [n.encode() for n in tensors]
         table = (_lib.IvgTensor * len(tensors))()
@@ -124,6 +126,11 @@ class Engine:
         if t != self._temperature:
             self.check(self.lib.ivg_set_temperature(self.h, t), "set_temperature")
             self._temperature = t
+        return self
+
+    def set_decode_lds_kb(self, kb):
+        """LDS budget of this engine's decode-step GEMMs (``ivg_config.decode_lds_kb``; 0 = process default, 16 .. 160 KiB)."""
+        self.check(self.lib.ivg_set_decode_lds_kb(self.h, int(kb or 0)), "set_decode_lds_kb")
         return self
 
     def set_context_length(self, k):

@@ -264,8 +264,12 @@ class _GatedPhase:
 
     def __enter__(self):
         self.gate._lock.acquire()
-        if self.gate._last is not None:
-            self.stream.wait_event(self.gate._last)
+        try:
+            if self.gate._last is not None:
+                self.stream.wait_event(self.gate._last)
+        except BaseException:
+            self.gate._lock.release()   # __exit__ does not run when __enter__ raises: every other lane would wait forever
+            raise
         return self
 
     def __exit__(self, *exc):

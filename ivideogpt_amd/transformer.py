@@ -73,7 +73,8 @@ class _RewardLinear:
 
 
 class LlamaForCausalLM:
-    def __init__(self, config, state_dict=None, dtype="bf16", prefix="", action_dim=None, reward_prediction=False):
+    def __init__(self, config, state_dict=None, dtype="bf16", prefix="", action_dim=None, reward_prediction=False, decode_lds_kb=0):
+        self._decode_lds_kb = int(decode_lds_kb or 0)   # launch policy of THIS model's engine (set_decode_lds_kb)
         self._cfg = dict(W.LLAMA_SMALL)
         self._cfg.update({k: v for k, v in dict(config).items() if k in self._cfg})
         self.config = SimpleNamespace(**self._cfg)
@@ -108,13 +109,18 @@ class LlamaForCausalLM:
         if self.device.type != "cuda":
             raise RuntimeError("replica(): call .to('cuda') first")
         r = LlamaForCausalLM(self._cfg, self._sd, dtype=self.dtype, prefix=self._prefix, action_dim=self._action_dim,
-                             reward_prediction=self._reward)
+                             reward_prediction=self._reward, decode_lds_kb=self._decode_lds_kb)
         r.device = self.device
         r._sd_version = self._sd_version
         if hasattr(self, "_wrapper_heads"):
             r._wrapper_heads = self._wrapper_heads
         r._packed, r._packed_key = self._packed_weights(), self._pack_key()
         return r
+
+    # HF keyword arguments of from_config / from_pretrained that have no meaning for an inference engine (eval semantics, one
+    # attention implementation, local files only): accepted and ignored -- anything else raises TypeError
+    _IGNORED_HF_KWARGS = frozenset({"trust_remote_code", "attn_implementation", "torch_dtype", "attention_dropout", "use_cache", "revision",
+                                    "cache_dir", "local_files_only", "device_map", "use_safetensors", "token"})
 
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, subfolder="transformer", low_cpu_mem_usage=False, dtype="bf16",
@@ -124,10 +130,14 @@ class LlamaForCausalLM:
         return cls(cfg, sd, dtype=dtype)
 
     @classmethod
-    def from_config(cls, config, seed=None, dtype="bf16", **unused):
+    def from_config(cls, config, seed=None, dtype="bf16", **hf_kwargs):
         """``AutoModelForCausalLM.from_config(config)`` (mbrl/video_predictor.py:72, train_gpt.py:593): ``config`` = a dict, an object
         with the HF field names, or a path to a ``config.json`` / its directory (what ``AutoConfig.from_pretrained`` takes).
-        seed = None: no weights yet (load_state_dict follows); otherwise seeded random weights in the checkpoint schema."""
+        seed = None: no weights yet (load_state_dict follows); otherwise seeded random weights in the checkpoint schema.
+        Of HF's keyword arguments only the ones with no meaning here are accepted (and ignored): a misspelt name raises."""
+        unknown = set(hf_kwargs) - cls._IGNORED_HF_KWARGS
+        if unknown:
+            raise TypeError(f"from_config() got unexpected keyword argument(s) {sorted(unknown)}")
         if isinstance(config, (str, bytes)) or hasattr(config, "__fspath__"):
             config = W.load_llama_config(config)
         cfg = dict(W.LLAMA_SMALL)
@@ -189,8 +199,26 @@ class LlamaForCausalLM:
         cap_t = max(frames, e.max_frames if e else 0)
         self._drop_engine()
         self._engine = Engine(self.device, self._packed_weights(), llm_cfg=self._cfg, action_dim=self._action_dim or 0,
-                              reward_head=self._reward, llm_dtype=self.dtype, max_batch=cap_b, max_frames=cap_t)
+                              reward_head=self._reward, llm_dtype=self.dtype, max_batch=cap_b, max_frames=cap_t,
+                              decode_lds_kb=self._decode_lds_kb)
         return self._engine
+
+    # LDS budget (KiB) of a decode-step GEMM workgroup for a model whose batch shares the GPU with other batches in flight (bench.py
+    # --lanes, INTEGRATION.md "streams"): with a whole CU's LDS per workgroup (the default, fastest for one batch alone) the decode
+    # GEMMs of one batch lock the other batches' kernels out of the CU for their whole duration; at <= 52 KiB three or four
+    # workgroups of different engines fit, and four batches in flight reach 5,680 instead of 5,350 predicted frames/s
+    # (profiles/r04_lanes.txt).  A property of the ENGINE (ivg_config.decode_lds_kb), not of the process: a latency-bound model
+    # (MBRL step-wise rollout) and throughput lanes can live side by side.
+    BATCHES_IN_FLIGHT_LDS_KB = 40
+
+    def set_decode_lds_kb(self, kb):
+        """``kb`` = 0: the process default (``IVG_DECODE_LDS_KB``, 160); 16 .. 160 otherwise.  Applies to the live engine and to every
+        engine this model builds later; the budget picks the kernel generation, so tokens of two budgets are each deterministic
+        but not bit-comparable with one another."""
+        self._decode_lds_kb = int(kb or 0)
+        if self._engine is not None:
+            self._engine.set_decode_lds_kb(self._decode_lds_kb)
+        return self
 
     # ------------------------------------------------------------------ hot path
     def _uniforms(self, B, n, do_sample, generator):
@@ -327,6 +355,10 @@ class HeadModelWithAction:
     def get_input_embeddings(self, input_ids):
         """action_model.py:47-54."""
         return self.llm.get_input_embeddings()(input_ids)
+
+    def set_decode_lds_kb(self, kb):
+        self.llm.set_decode_lds_kb(kb)
+        return self
 
     def replica(self):
         """As LlamaForCausalLM.replica: a second wrapper (own engine) over the same weights in HBM."""

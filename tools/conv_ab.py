@@ -1,6 +1,6 @@
 """A/B of the 3x3 convolution kernels at the decoder's shapes through the C ABI (development aid): for every (H, Cin, Cout, ups, gn)
 the 256-pixel kernel of conv3x3.hip (IVG_CONV_WIDE=0) beside the persistent two-tile kernel of conv3x3w.hip (IVG_CONV_WIDE=1),
-optionally over several grid sizes.   python tools/conv_ab.py [N=896] [res=64|256] [grids=256,...]"""
+or over a preset of development variants.   python tools/conv_ab.py [N=896] [res=64|256] [preset=wide|pf|probe]"""
 import ctypes as C
 import os
 import sys
@@ -60,24 +60,34 @@ def time_conv(lib, H, Cin, Cout, ups, gn, N, iters=6):
 def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 896
     res = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-    grids = [int(g) for g in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0]
+    preset = sys.argv[3] if len(sys.argv) > 3 else "wide"
+    base = dict(IVG_CONV_WIDE=2, IVG_CONV_WIDE_GRID=None, IVG_CONV_WIDE_PF=None, IVG_CONV_WIDE_PROBE=None, IVG_CONV_WIDE_STAGGER=None)
+    variants = {"wide": [("wide", {})],
+                "pf": [("pf0", dict(IVG_CONV_WIDE_PF=0)), ("pf1", dict(IVG_CONV_WIDE_PF=1))],
+                "stagger": [("st0", dict(IVG_CONV_WIDE_STAGGER=0)), ("st1", dict(IVG_CONV_WIDE_STAGGER=1)), ("st2", dict(IVG_CONV_WIDE_STAGGER=2)),
+                            ("st4", dict(IVG_CONV_WIDE_STAGGER=4))],
+                "policy": [("default", dict(IVG_CONV_WIDE=1))],
+                # WRONG results, timing only: what the epilogue / the in-place input normalisation cost inside the persistent kernel
+                "probe": [("full", {}), ("no-epilogue", dict(IVG_CONV_WIDE_PROBE=1)), ("no-norm", dict(IVG_CONV_WIDE_PROBE=2)),
+                          ("neither", dict(IVG_CONV_WIDE_PROBE=3))]}[preset]
     lib = _lib.load()
     shapes = SHAPES64 if res == 64 else SHAPES256
     tot = {}
     print(f"# N={N} frames, bf16; ms per launch (TFLOP/s); gn=1 rows include the input's statistics + coefficient kernels in both columns")
     for (H, Cin, Cout, ups, gn, mult) in shapes:
         row = []
-        switches.set(IVG_CONV_WIDE=0, IVG_CONV_WIDE_GRID=None)
+        switches.set(**dict(base, IVG_CONV_WIDE=0))
         ms0, tf0 = time_conv(lib, H, Cin, Cout, ups, gn, N)
         row.append(f"narrow {ms0:7.3f} ({tf0:5.0f})")
         tot["narrow"] = tot.get("narrow", 0.0) + ms0 * mult
-        for g in grids:
-            switches.set(IVG_CONV_WIDE=1, IVG_CONV_WIDE_GRID=(g if g else None))
+        for label, env in variants:
+            switches.set(**dict(base, **env))
             n0 = lib.ivg_debug_counter(b"conv3x3_wide")
             ms1, tf1 = time_conv(lib, H, Cin, Cout, ups, gn, N)
             ran = lib.ivg_debug_counter(b"conv3x3_wide") > n0
-            row.append(f"wide[{g or 'cu'}] {ms1:7.3f} ({tf1:5.0f}){'' if ran else ' NOT-RUN'} x{ms0 / ms1:4.2f}")
-            tot[f"wide{g}"] = tot.get(f"wide{g}", 0.0) + ms1 * mult
+            row.append(f"{label} {ms1:7.3f} ({tf1:5.0f}){'' if ran else ' NOT-RUN'} x{ms0 / ms1:4.2f}")
+            tot[label] = tot.get(label, 0.0) + ms1 * mult
+        switches.set(**base)
         print(f"H={H:3d} {Cin:3d}->{Cout:3d} ups={ups} gn={gn} x{mult:2d}: " + " | ".join(row), flush=True)
     print("# weighted by launches per decoder pass (ms):", {k: round(v, 2) for k, v in tot.items()})
 
