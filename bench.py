@@ -8,10 +8,11 @@ A step = one pass of the hot path over one batch of synthetic clips already resi
     encode the context frames -> autoregressive rollout (17*F - 1 tokens) -> decode all T frames -> clamp(0, 1)
 (BASELINE.json configs[1]: ivideogpt-oxe-64-act-free shapes, synthetic 64x64 bf16 pixels, 64 trajectories per GPU,
 2 context + 14 predicted frames; seeded random weights of the real architecture -- no checkpoints exist offline).
-Two batches are kept in flight per GPU by default (``--lanes 2``: two engine instances over one copy of the weights, each with its own
-KV cache, workspace, HIP stream and host thread; the K timed steps are dealt round-robin to the lanes): the MFMA-bound convolutions of one batch's encode /
-decode run beside the latency- and HBM-bound rollout of the other.  ``value`` counts the frames of exactly K steps over the wall
-clock; ``single_lane`` in the line is the same pipeline with one batch in flight (``--lanes 1``; the latency of a batch).
+Four batches are kept in flight per GPU by default (``--lanes 4``: engine instances over one copy of the weights, each with its own KV
+cache, workspace, HIP stream and host thread, decode GEMMs planned under a 40 KiB LDS budget PER ENGINE -- ``ivg_config.decode_lds_kb``;
+the K timed steps are dealt round-robin to the lanes): the latency- and HBM-bound rollouts of the batches overlap one another.
+``value`` counts the frames of exactly K steps over the wall clock; ``single_lane`` in the line is the same pipeline with one batch in
+flight (the latency of a batch); ``roofline_in_flight`` the aggregate HBM rate of the rollout phase with all lanes running.
 Multi-GPU: independent trajectories shard by batch rows (weak scaling: 64 per GPU), no data-path collective; the
 per-sample metric rows are all-gathered over RCCL once per step (the reference's accelerator.gather, train_gpt.py:476-479).
 
@@ -46,7 +47,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from ivideogpt_amd import CompressiveVQModel, LlamaForCausalLM, weights as W  # noqa: E402
-from ivideogpt_amd import _lib, parallel, switches  # noqa: E402
+from ivideogpt_amd import _lib, parallel  # noqa: E402
 from ivideogpt_amd.pipeline import frame_metrics, predict_frames  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
@@ -134,8 +135,8 @@ KERNEL_NAMES = {
     "conv3x3": "ivg::conv3x3_kernel (LDS-halo 3x3 convolution, MFMA)",
     "igemm": "ivg::gemm256l_kernel + ivg::igemm_kernel<128,128,64> (dense GEMMs / implicit-GEMM convs other than 3x3, MFMA)",
 }
-PMC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json")
-TRACE_FILES = ("r04_kernel_trace_classes.json", "r03_kernel_trace_classes.json")
+PMC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json")
+TRACE_FILES = ("r05_kernel_trace_classes.json", "r04_kernel_trace_classes.json", "r03_kernel_trace_classes.json")
 
 
 def _pmc_traffic(name):
@@ -333,6 +334,96 @@ def measure_lanes(lanes, ctx, F, greedy, steps, warmup, gate=None, gatherer=None
     return el, [x[0] for x in last], [x[1] for x in last]
 
 
+def in_flight_pass(lanes, ctx, F, greedy, with_actions):
+    """The dominant kernel IN THE MODE `value` IS MEASURED IN: one more pass of all lanes (one step each, concurrently, as in the timed
+    loop -- after it, with the decode kernels' own launch stamps on in every lane's engine).  Reported:
+      * per lane the mean launch window of the decode attention / the decode GEMMs while the other lanes' kernels share the chip,
+      * over the ROLLOUT PHASE of the pass (the union of the lanes' rollout intervals, from events on the lane streams) the aggregate
+        rate at which the K / V rows and the weight matrices were read: all lanes' algorithmic bytes / that time.
+    -> the `roofline_in_flight` object of the line."""
+    import threading
+    L = len(lanes)
+    engines = [(ln["model"].llm if with_actions else ln["model"])._engine for ln in lanes]
+    for e in engines:
+        for k in (_lib.IVG_K_DECODE_ATTN, _lib.IVG_K_DECODE_GEMM):
+            e.profile_read(k)
+            e.profile_enable(k, True)
+    ref = torch.cuda.Event(enable_timing=True)
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(L)]
+    errors = []
+
+    def body(i, record):
+        try:
+            ln = lanes[i]
+            torch.cuda.set_device(ln["stream"].device)
+            with torch.cuda.stream(ln["stream"]):
+                kw = {"action": ln["actions"]} if ln["actions"] is not None else {}
+                if record:
+                    evs[i][0].record()
+                prompt = ln["tok"].encode_context(ln["pixels"], ctx)
+                if record:
+                    evs[i][1].record()
+                toks = ln["model"].generate(prompt, do_sample=not greedy, top_k=100, max_new_tokens=17 * F - 1, generator=ln["gen"], **kw)
+                if record:
+                    evs[i][2].record()
+                ln["tok"].detokenize(toks, ctx, clamp=True)
+                if record:
+                    evs[i][3].record()
+        except Exception as e:   # noqa: BLE001
+            errors.append(e)
+
+    def run(record):
+        ths = [threading.Thread(target=body, args=(i, record)) for i in range(L)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        torch.cuda.synchronize()
+        if errors:
+            raise errors[0]
+
+    run(False)                      # stamps on: the first pass re-captures / warms whatever the switch touches
+    for e in engines:
+        for k in (_lib.IVG_K_DECODE_ATTN, _lib.IVG_K_DECODE_GEMM):
+            e.profile_read(k)
+    torch.cuda.synchronize()
+    ref.record(torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    run(True)
+    per_lane, tot = [], {"attn": 0.0, "gemm": 0.0}
+    for i, e in enumerate(engines):
+        sa, sg = e.profile_read(_lib.IVG_K_DECODE_ATTN), e.profile_read(_lib.IVG_K_DECODE_GEMM)
+        for k in (_lib.IVG_K_DECODE_ATTN, _lib.IVG_K_DECODE_GEMM):
+            e.profile_enable(k, False)
+        t = [ref.elapsed_time(ev) for ev in evs[i]]
+        per_lane.append({"rollout_interval_ms": [t[1], t[2]], "decode_attn_mean_launch_us": 1e3 * sa["total_ms"] / max(1, sa["launches"]),
+                         "decode_gemm_mean_launch_us": 1e3 * sg["total_ms"] / max(1, sg["launches"]),
+                         "decode_attn_bytes": sa["total_bytes"], "decode_gemm_bytes": sg["total_bytes"]})
+        tot["attn"] += sa["total_bytes"]
+        tot["gemm"] += sg["total_bytes"]
+    iv = sorted(p["rollout_interval_ms"] for p in per_lane)
+    union, cur0, cur1 = 0.0, iv[0][0], iv[0][1]
+    for b0, b1 in iv[1:]:
+        if b0 > cur1:
+            union += cur1 - cur0
+            cur0, cur1 = b0, b1
+        else:
+            cur1 = max(cur1, b1)
+    union += cur1 - cur0
+    ach = (tot["attn"] + tot["gemm"]) / (union * 1e-3) / 1e9
+    mean_attn = sum(p["decode_attn_mean_launch_us"] for p in per_lane) / L
+    return {"bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS, "lanes": L,
+            "achieved": ach, "frac": ach / PEAK_HBM_GBS,
+            "what": "all lanes' decode-attention K / V rows + decode-GEMM weight bytes of one pass (one step per lane, concurrent, launch stamps on in "
+                    "every lane's engine, run after the timed loop) / the union of the lanes' rollout intervals (events on the lane streams)",
+            "rollout_phase_ms": union, "decode_attn_GB": tot["attn"] / 1e9, "decode_gemm_weight_GB": tot["gemm"] / 1e9,
+            "decode_attn_only": {"achieved": tot["attn"] / (union * 1e-3) / 1e9, "frac": tot["attn"] / (union * 1e-3) / 1e9 / PEAK_HBM_GBS},
+            "decode_attn_mean_launch_us_in_flight": mean_attn,
+            "per_lane": per_lane,
+            "note": "the launches of one lane are slower beside the other lanes' kernels than alone (roofline: one batch alone); the chip as a whole "
+                    "moves this many bytes per second while the rollouts overlap -- the figure the headline mode is bound by"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -357,8 +448,10 @@ def main():
     ap.add_argument("--greedy", action="store_true")
     ap.add_argument("--action-dim", type=int, default=0, help=">0: action-conditioned HeadModelWithAction (BASELINE config 3: 4)")
     ap.add_argument("--ctx", type=int, default=0, help="context frames (0: the tokenizer's pretrained context_length)")
-    ap.add_argument("--lane-switches", default="in-flight", choices=["in-flight", "none"],
-                    help="library switches while several batches are in flight: ivideogpt_amd.switches.BATCHES_IN_FLIGHT, or none (A/B)")
+    ap.add_argument("--lane-lds-kb", type=int, default=LlamaForCausalLM.BATCHES_IN_FLIGHT_LDS_KB,
+                    help="decode-GEMM LDS budget (KiB) of the engines of the lanes while several batches are in flight (per engine: "
+                         "ivg_config.decode_lds_kb / set_decode_lds_kb); 0: the process default, i.e. a whole CU per workgroup (A/B)")
+    ap.add_argument("--only-lanes", action="store_true", help="skip the per-stage and one-batch-in-flight passes (kernel traces of the lanes mode alone)")
     ap.add_argument("--lanes", type=int, default=4, help="batches in flight per GPU: engine instances on their own HIP streams and host threads "
                                                          "(1: one batch at a time, the per-batch latency case)")
     ap.add_argument("--conv-gate", type=int, default=0, help="1: at most one lane's convolution phase (encode / decode) on the device at a time "
@@ -435,12 +528,13 @@ def main():
 
     # ---- per-stage split: median of 3 passes, taken BEFORE anything else runs (one warm-up pass builds the engines)
     stage_pass()
-    sp = [stage_pass() for _ in range(3)]
+    n_sp = 1 if a.only_lanes else 3
+    sp = [stage_pass() for _ in range(n_sp)]
     stage = {"encode_ms": median([p[0] for p in sp]), "rollout_ms": median([p[1] for p in sp]), "decode_ms": median([p[2] for p in sp]),
-             "passes": 3, "note": "median of 3 passes on one batch alone, before the timed loops"}
+             "passes": n_sp, "note": f"median of {n_sp} passes on one batch alone, before the timed loops"}
 
     # ---- one batch in flight (the latency of a batch): >= 10 timed steps, mean and median
-    n1 = a.steps if a.lanes <= 1 else max(10, min(a.steps, 12))
+    n1 = a.steps if a.lanes <= 1 else (1 if a.only_lanes else max(10, min(a.steps, 12)))
     e1, frames, rows, step, t1 = measure(tok, model, pixels, actions, ctx, F, a.greedy, sample_gen, n1, a.warmup if a.lanes <= 1 else 1, per_step=True)
     assert torch.isfinite(frames).all() and rows.shape == (global_b, 3) and torch.isfinite(rows).all()
     my_elapsed = e1
@@ -448,6 +542,7 @@ def main():
               "ms_per_step_median": median(t1) * 1e3, "value_at_median": B * F * world / median(t1), "steps": n1,
               "note": "one batch in flight (lane 0 alone): the latency of a batch through encode -> rollout -> decode"}
     steps_timed = n1
+    in_flight = None
 
     # ---- the headline: `lanes` batches in flight per GPU, clean loop, no hooks
     if a.lanes > 1:
@@ -471,12 +566,17 @@ def main():
                 ln["stream"] = parallel.cu_masked_stream(dev, conv_bits)
                 ln["rollout_stream"] = parallel.cu_masked_stream(dev, roll_bits)
         # several batches in flight: decode GEMMs with a small LDS footprint, so that the kernels of the other batches fit beside them
-        with switches.override(**({} if a.lane_switches == "none" else switches.BATCHES_IN_FLIGHT)):
-            my_elapsed, lane_frames, lane_rows = measure_lanes(lanes, ctx, F, a.greedy, a.steps, a.warmup, gate,
-                                                               gatherer if a.gather_mode == "thread" else None)
+        # -- a property of the lanes' ENGINES (ivg_config.decode_lds_kb), not of the process; lane 0's engine gets its default back below
+        for ln in lanes:
+            ln["model"].set_decode_lds_kb(a.lane_lds_kb)
+        my_elapsed, lane_frames, lane_rows = measure_lanes(lanes, ctx, F, a.greedy, a.steps, a.warmup, gate,
+                                                           gatherer if a.gather_mode == "thread" else None)
         for fr, rw in zip(lane_frames, lane_rows):
             assert torch.isfinite(fr).all() and rw.shape == (global_b, 3) and torch.isfinite(rw).all()
         steps_timed = a.steps
+        if not a.no_profile:
+            in_flight = in_flight_pass(lanes, ctx, F, a.greedy, actions is not None)
+        model.set_decode_lds_kb(0)
         del lanes[1:]
     elapsed = parallel.max_over_ranks(my_elapsed, dev)
     per_rank = parallel.gather_metric_rows_even(torch.tensor([[B * F * steps_timed / my_elapsed]], device=dev, dtype=torch.float32)).flatten().tolist()
@@ -535,7 +635,7 @@ def main():
                                     ("compliant_mode", "x3", "x3", "split-bf16 arithmetic on fp32 tensors: pixels / logits within 1e-3 of the fp32 reference, "
                                                                    "token-identical greedy rollouts (tests/test_gpu_x3.py)")):
             _, _, _, _, tok_a, model_a = build_models(dev, a.res, a.medium, a.encode_dtype, dec, llm, a.action_dim, a.ctx or None, a.frames)
-            n_a = max(1, min(3, a.steps))
+            n_a = max(1, min(5, a.steps))
             e_a, fr_a, _, _, t_a = measure(tok_a, model_a, pixels, actions, ctx, F, a.greedy, sample_gen, n_a, 1, per_step=True)
             assert torch.isfinite(fr_a).all()
             alt[key] = {"value": B * F * n_a / e_a, "unit": "predicted frames/s", "ms_per_step": e_a / n_a * 1e3, "ms_per_step_median": median(t_a) * 1e3,
@@ -549,7 +649,9 @@ def main():
                                         pixels=torch.rand(B, T, 3, a.res, a.res, device=dev, generator=gi).to(torch.bfloat16),
                                         actions=torch.randn(B, T, a.action_dim, device=dev, generator=gi) if a.action_dim else None,
                                         gen=torch.Generator(device=dev).manual_seed(2000 + rank + 7919 * i), stream=lane_streams[i]))
-                n_l = 3 * n_x3
+                n_l = 4 * n_x3
+                for ln in lanes_a:
+                    ln["model"].set_decode_lds_kb(a.lane_lds_kb)
                 e_l, fl, _ = measure_lanes(lanes_a, ctx, F, a.greedy, n_l, 1, parallel.PhaseGate() if a.conv_gate else None)
                 assert all(torch.isfinite(x).all() for x in fl)
                 alt[key]["lanes_in_flight"] = {"lanes": n_x3, "value": B * F * n_l / e_l, "ms_per_step": e_l / n_l * 1e3, "steps": n_l}
@@ -557,7 +659,8 @@ def main():
             del model_a, tok_a
             torch.cuda.empty_cache()
 
-    # ---- the other per-GPU shapes of BASELINE.json (configs 3, 4, 5), short single-lane runs inside the same driver-observed line
+    # ---- the other per-GPU shapes of BASELINE.json (configs 3, 4, 5) inside the same driver-observed line: one batch in flight over
+    # >= 10 steps (mean and median), then `lanes` batches in flight over 2 * lanes steps -- the two figures config 2 is reported with
     other = {}
     if world == 1 and default_run and not a.no_other_configs:
         for k in (3, 4, 5):
@@ -567,15 +670,34 @@ def main():
                                                             c["ctx"] or None, c["frames"])
                 ctx_o, Fo = tok_o.context_length, c["frames"] - tok_o.context_length
                 go = torch.Generator(device=dev).manual_seed(3000 + k)
-                px_o = torch.rand(c["batch"], c["frames"], 3, c["res"], c["res"], device=dev, generator=go).to(torch.bfloat16)
-                act_o = torch.randn(c["batch"], c["frames"], c["action_dim"], device=dev, generator=go) if c["action_dim"] else None
-                e_o, fr_o, _, _, t_o = measure(tok_o, model_o, px_o, act_o, ctx_o, Fo, a.greedy, go, 3, 1, per_step=True)
+
+                def inputs(gen):
+                    return (torch.rand(c["batch"], c["frames"], 3, c["res"], c["res"], device=dev, generator=gen).to(torch.bfloat16),
+                            torch.randn(c["batch"], c["frames"], c["action_dim"], device=dev, generator=gen) if c["action_dim"] else None)
+                px_o, act_o = inputs(go)
+                n_o = 10
+                e_o, fr_o, _, _, t_o = measure(tok_o, model_o, px_o, act_o, ctx_o, Fo, a.greedy, go, n_o, 1, per_step=True)
                 assert torch.isfinite(fr_o).all()
-                other[f"config_{k}"] = {"value": c["batch"] * Fo * 3 / e_o, "unit": "predicted frames/s", "ms_per_step": e_o / 3 * 1e3,
-                                        "ms_per_step_median": median(t_o) * 1e3, "steps": 3, "lanes": 1,
+                other[f"config_{k}"] = {"value": c["batch"] * Fo * n_o / e_o, "unit": "predicted frames/s", "ms_per_step": e_o / n_o * 1e3,
+                                        "ms_per_step_median": median(t_o) * 1e3, "steps": n_o, "lanes": 1,
                                         "workload": f"{c['batch']} trajectories per GPU, {ctx_o} context + {Fo} predicted frames, {c['res']}x{c['res']}, "
                                                     f"{'medium (436 M)' if c['medium'] else 'small (138 M)'} transformer"
                                                     + (f", {c['action_dim']}-dim actions" if c["action_dim"] else "")}
+                if a.lanes > 1:
+                    lanes_o = [dict(tok=tok_o, model=model_o, pixels=px_o, actions=act_o, gen=go, stream=main_stream)]
+                    for i in range(1, a.lanes):
+                        gi = torch.Generator(device=dev).manual_seed(3000 + k + 7919 * i)
+                        px_i, act_i = inputs(gi)
+                        lanes_o.append(dict(tok=tok_o.replica(), model=model_o.replica(), pixels=px_i, actions=act_i,
+                                            gen=torch.Generator(device=dev).manual_seed(4000 + k + 7919 * i), stream=lane_streams[i]))
+                    for ln in lanes_o:
+                        ln["model"].set_decode_lds_kb(a.lane_lds_kb)
+                    n_l = 2 * a.lanes
+                    e_l, fl, _ = measure_lanes(lanes_o, ctx_o, Fo, a.greedy, n_l, 1)
+                    assert all(torch.isfinite(x).all() for x in fl)
+                    other[f"config_{k}"]["lanes_in_flight"] = {"lanes": a.lanes, "value": c["batch"] * Fo * n_l / e_l, "ms_per_step": e_l / n_l * 1e3,
+                                                               "steps": n_l}
+                    del lanes_o, fl
                 del tok_o, model_o, px_o, fr_o
             except Exception as ex:   # never lose the headline to a side measurement
                 other[f"config_{k}"] = {"value": None, "error": repr(ex)[:200]}
@@ -611,6 +733,8 @@ def main():
             "roofline": rl[0], "roofline_other": rl[1:],
             "stage_ms": stage,
         }
+        if in_flight:
+            out["roofline_in_flight"] = in_flight
         if single:
             out["single_lane"] = single
         out.update(alt)

@@ -298,7 +298,7 @@ int ivg_op_conv_in(const void* video, int video_dtype, const float* w, const flo
  * sample_from_logits */
 int ivg_op_sample(const float* logits, int B, int V, int top_k, float temperature, const float* uniforms, int64_t* out, ivg_stream stream);
 /* test hook: launches since the library was loaded of the kernel family `name` selects ("conv3x3_wide": the persistent two-tile 3x3
- * convolution of csrc/conv3x3w.hip) -- lets a test assert WHICH kernel produced the tensor it checked; -1 for an unknown name */
+ * convolution of csrc/conv3x3w.hip; "decode_gemm_gen3" / "decode_gemm_gen2": decode-step GEMMs the dispatcher sent to dgemm3.hip / dgemm.hip) -- lets a test assert WHICH kernel produced the tensor it checked; -1 for an unknown name */
 int64_t ivg_debug_counter(const char* name);
 
 #ifdef __cplusplus

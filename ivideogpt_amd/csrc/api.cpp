@@ -797,6 +797,8 @@ int ivg_op_conv_x3(const ivg_igemm_args* a, const void* w_x3, int groups, const 
 
 int64_t ivg_debug_counter(const char* name) {
   if (name && !strcmp(name, "conv3x3_wide")) return conv3x3_wide_launches();
+  if (name && !strcmp(name, "decode_gemm_gen3")) return decode_gemm_launches(3);
+  if (name && !strcmp(name, "decode_gemm_gen2")) return decode_gemm_launches(2);
   return -1;
 }
 

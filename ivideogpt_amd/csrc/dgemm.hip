@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <atomic>
 #include "igemm.h"
 #include "switches.h"
 
@@ -471,12 +472,15 @@ int launch_dgemm(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
 // reached it any more): third generation (dgemm3.hip) wherever it covers the shape, else the second (this file).  Coverage is a
 // function of (K, N, dtype, flags) only, so a GEMM of the model runs on the same kernel -- the same K-summation order -- whatever
 // the batch.  A shape neither covers (K bytes not a multiple of 128, M > 128, unaligned operands) fails loudly.
+static std::atomic<long long> g_gen3_launches{0}, g_gen2_launches{0};
+long long decode_gemm_launches(int generation) { return (generation == 3 ? g_gen3_launches : g_gen2_launches).load(std::memory_order_relaxed); }
+
 int launch_skinny(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
   if (a.M <= 0 || a.N <= 0) return 0;
   int rc = launch_dgemm3(a, dtype, stream);
-  if (rc != -1) return rc;
+  if (rc != -1) { g_gen3_launches.fetch_add(1, std::memory_order_relaxed); return rc; }
   rc = launch_dgemm(a, dtype, stream);
-  if (rc != -1) return rc;
+  if (rc != -1) { g_gen2_launches.fetch_add(1, std::memory_order_relaxed); return rc; }
   return (int)hipErrorInvalidValue;
 }
 

@@ -153,6 +153,58 @@ def _two_engines_in_flight(CompressiveVQModel, LlamaForCausalLM, W, predict_fram
         assert torch.equal(par[i][0], seq[i][0]), f"lane {i}: frames differ between concurrent and sequential runs"
 
 
+def test_decode_lds_budget_is_a_property_of_the_engine(switches):
+    """ivg_config.decode_lds_kb / set_decode_lds_kb: the LDS budget of the decode GEMMs belongs to ONE engine.  Two models in one
+    process, one under 40 KiB (what bench.py's lanes set), one with the default: the first produces exactly what a process-wide
+    IVG_DECODE_LDS_KB=40 produces and its q/k/v / gate-up / down GEMMs leave the third-generation kernel; the second is untouched."""
+    from ivideogpt_amd import LlamaForCausalLM, _lib, weights as W
+    l = _lib.load()
+    cfg = dict(W.LLAMA_SMALL, num_hidden_layers=2)
+    sd = W.random_llama_state_dict(cfg, 97)
+    g = torch.Generator().manual_seed(98)
+    prompt = torch.randint(0, cfg["vocab_size"], (8, 20), generator=g).to(DEV)
+
+    def roll(model):
+        n3, n2 = l.ivg_debug_counter(b"decode_gemm_gen3"), l.ivg_debug_counter(b"decode_gemm_gen2")
+        out = model.generate(prompt, do_sample=False, max_new_tokens=12)
+        torch.cuda.synchronize()
+        return out, l.ivg_debug_counter(b"decode_gemm_gen3") - n3, l.ivg_debug_counter(b"decode_gemm_gen2") - n2
+
+    switches(IVG_DECODE_LDS_KB=None)
+    base = LlamaForCausalLM(cfg, sd, dtype="bf16").to(DEV)
+    t_default, g3_default, _ = roll(base)
+    assert g3_default > 0, "with a whole CU's LDS the small transformer's decode GEMMs run on the third-generation kernel"
+    switches(IVG_DECODE_LDS_KB=40)
+    t_proc40, g3_proc40, g2_proc40 = roll(LlamaForCausalLM(cfg, sd, dtype="bf16").to(DEV))
+    assert g3_proc40 < g3_default and g2_proc40 > 0
+    switches(IVG_DECODE_LDS_KB=None)
+    small = base.replica().set_decode_lds_kb(LlamaForCausalLM.BATCHES_IN_FLIGHT_LDS_KB)      # policy set before the engine exists
+    t_eng40, g3_eng40, g2_eng40 = roll(small)
+    assert (g3_eng40, g2_eng40) == (g3_proc40, g2_proc40) and torch.equal(t_eng40, t_proc40)
+    t_again, g3_again, _ = roll(base)                                                            # the neighbour keeps its own policy
+    assert g3_again == g3_default and torch.equal(t_again, t_default)
+    small.set_decode_lds_kb(0)                                                                   # and a live engine can be switched back
+    t_back, g3_back, _ = roll(small)
+    assert g3_back == g3_default and torch.equal(t_back, t_default)
+    with pytest.raises(Exception):
+        small.set_decode_lds_kb(7)
+
+
+def test_bench_lanes_small_run_with_the_in_flight_roofline():
+    """the profiled passes of bench.py at a small shape: `roofline_in_flight` (all lanes' decode bytes over the union of their rollout
+    intervals) beside `roofline` (one batch alone)"""
+    import json
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--lanes", "2", "--batch", "4", "--frames", "6", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-fp32-mode"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    r = d["roofline_in_flight"]
+    assert r["lanes"] == 2 and r["achieved"] > 0 and 0 < r["frac"] < 1 and len(r["per_lane"]) == 2
+    assert all(pl["rollout_interval_ms"][1] > pl["rollout_interval_ms"][0] for pl in r["per_lane"]) and r["rollout_phase_ms"] > 0
+    assert d["roofline"]["frac"] > 0
+
+
 def test_bench_two_lanes_small_run():
     """``bench.py --lanes 2`` end to end at a small shape: one JSON line with both figures (two batches in flight / one)."""
     # (custom shapes: no other_configs block; the fp32 / x3 modes are skipped explicitly)
