@@ -51,6 +51,10 @@ from ivideogpt_amd import _lib, parallel  # noqa: E402
 from ivideogpt_amd.pipeline import frame_metrics, predict_frames  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+# What a PURE stream of v_mfma_f32_16x16x32_bf16 sustains on this part with random operands: the socket reaches its 1,400 W limit and
+# the shader clock falls to ~2.0 GHz (tools/ubench/mfma_power.hip, profiles/r05_mfma_power.txt: 1,946-1,999 TFLOP/s; 2,397-2,417 on
+# all-zero operands).  Printed beside `frac` as `frac_of_sustained`; `frac` keeps the nominal peak as its denominator.
+SUSTAINED_BF16_TFLOPS = 1950.0
 PEAK_F32_TFLOPS = 157.3     # f32-input MFMA peak (same guide)
 PEAK_HBM_GBS = 8000.0
 
@@ -202,6 +206,11 @@ def rooflines(kstats, a):
             ach = s["total_flops"] / sec / 1e12
             r = {"bound": "mfma", "achieved": ach, "peak": peak_f, "unit": "TFLOP/s", "frac": ach / peak_f,
                  "algorithmic_flops_per_launch": s["total_flops"] / s["launches"]}
+            if a.decode_dtype == "bf16":
+                r["peak_sustained"] = SUSTAINED_BF16_TFLOPS
+                r["frac_of_sustained"] = ach / SUSTAINED_BF16_TFLOPS
+                r["peak_sustained_source"] = ("profiles/r05_mfma_power.txt: a pure bf16 MFMA stream on random operands at the socket's 1,400 W limit "
+                                              "(committed micro-benchmark, not this run)")
         r["traffic"], src = _pmc_traffic(name)
         if src:
             r["traffic_source"] = src + " (committed rocprofv3 --pmc passes, not this run)"
