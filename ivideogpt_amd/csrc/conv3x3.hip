@@ -451,6 +451,10 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = silu_t<T>(v[r]);
       }
+      if (flags & IG_CLAMP01) {   // the decoders' last convolution when the caller wants displayable frames (predict.py:73)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r], 0.f), 1.f);
+      }
       if (gn) {   // statistics of the STORED values (rounded to the output type, as a separate pass over the tensor would see them)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

@@ -48,33 +48,35 @@ constexpr int G256_PITCH = 256 * 2 + 16;          // staged output row (bytes): 
 
 // epilogue shared by both kernels: lane holds 4 consecutive columns n of row (wm*64 + b*16 + lr); bias, residual, SiLU, SiLU(gate) * up
 // in registers, then staged through LDS (the ring is free) so that global stores are whole 16-byte runs of an output row
-__device__ __forceinline__ void g256_epilogue(const G256Dev& p, f32x4 (&acc)[4][4], unsigned char* smem, int m0, int n0, int wm, int wn, int lr, int lg,
+template <int BN>
+__device__ __forceinline__ void g256_epilogue(const G256Dev& p, f32x4 (&acc)[BN / 64][4], unsigned char* smem, int m0, int n0, int wm, int wn, int lr, int lg,
                                               int tid) {
+  constexpr int FN = BN / 64, WNC = BN / 4;           // N fragments per wave, columns per wave (4 waves along N)
   const int flags = p.flags;
   const bool glu = flags & IG_GLU;
-  const int out_cols = glu ? 128 : 256;               // columns this tile writes
+  const int out_cols = glu ? BN / 2 : BN;             // columns this tile writes
   const int out_n0 = glu ? (n0 >> 1) : n0;
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
     const int row = wm * 64 + b * 16 + lr;
     const int m = m0 + row;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
+    for (int a = 0; a < FN; ++a) {
       if (glu && (a & 1)) continue;
       float v4[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v4[r] = acc[a][b][r];
-      const int ncol = wn * 64 + a * 16 + lg * 4;     // column inside the 256-wide tile (of the PACKED weight rows for GLU)
+      const int ncol = wn * WNC + a * 16 + lg * 4;    // column inside the BN-wide tile (of the PACKED weight rows for GLU)
       if (flags & IG_BIAS_N) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v4[r] += p.bias[n0 + ncol + r];
       }
       int ocol = ncol;
       if (glu) {  // rows [16 gate | 16 up] per 32 packed weight rows: fragment a = gate, a + 1 = up of the same 16 outputs
-        const int a1 = a + 1 < 4 ? a + 1 : a;
+        const int a1 = a + 1 < FN ? a + 1 : a;
 #pragma unroll
         for (int r = 0; r < 4; ++r) v4[r] = silu_t<bf16_t>(v4[r]) * acc[a1][b][r];
-        ocol = (wn * 64 + a * 16) / 2 + lg * 4;
+        ocol = (wn * WNC + a * 16) / 2 + lg * 4;
       }
       if ((flags & IG_RESIDUAL) && m < p.M) {
         const bf16x4 rv = *(const bf16x4*)(p.R + (long)m * p.ldy + out_n0 + ocol);
@@ -114,7 +116,12 @@ constexpr int G256L_STAGE = 2 * G256L_HALF;
 __device__ __forceinline__ void g256l_dma16(const void* sbase, unsigned voff, unsigned lds_wave_base) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_wave_base), "v"(voff), "s"(sbase) : "memory");
 }
+// BN = 128 (round 5): the same 256 rows against 128 weight rows -- 16 waves = 4 (M) x 4 (N) of 64 x 32 sub-tiles, waves 0-7 fetch the
+// 16 KiB weight half of a stage.  For the dense 1x1 layers with 128 output channels over millions of pixels (the 64 x 64 / 256 x 256
+// level's resnet shortcuts, 256 -> 128): HBM-bound shapes (85 FLOP per byte) the 128 x 128 implicit GEMM ran at 8.7 % MFMA-busy.
+template <int BN>
 __global__ __launch_bounds__(1024) void gemm256l_kernel(const G256Dev p) {
+  constexpr int FN = BN / 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -128,7 +135,7 @@ __global__ __launch_bounds__(1024) void gemm256l_kernel(const G256Dev p) {
   }
   int tile_m, tile_n;
   g256_tile(p, v, tile_m, tile_n);
-  const int m0 = tile_m * 256, n0 = tile_n * 256;
+  const int m0 = tile_m * 256, n0 = tile_n * BN;
   const int steps = p.K >> 6;
   // wave w fills tile w (16 rows) of both operands: two requests of 8 rows x 128 bytes each
   const int r8 = lane >> 3, jj = lane & 7;
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(1024) void gemm256l_kernel(const G256Dev p) {
     const int r = h * 8 + r8;
     const unsigned sw = (unsigned)(jj ^ ((r >> 1) & 7)) * 16u;
     aoff[h] = (unsigned)min(m0 + wave * 16 + r, p.M - 1) * (unsigned)(p.ldx * 2) + sw;   // rows beyond M re-read row M - 1 (never stored)
-    woff[h] = (unsigned)(n0 + wave * 16 + r) * (unsigned)(p.ldw * 2) + sw;
+    woff[h] = (unsigned)(n0 + min(wave * 16 + r, BN - 1)) * (unsigned)(p.ldw * 2) + sw;
   }
   const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) const void*)smem;
   auto issue = [&](int step) {
@@ -147,12 +154,14 @@ __global__ __launch_bounds__(1024) void gemm256l_kernel(const G256Dev p) {
     const char* ws = (const char*)p.W + (size_t)step * 128;
 #pragma unroll
     for (int h = 0; h < 2; ++h) g256l_dma16(xs, aoff[h], base + h * 1024);
+    if (BN == 256 || wave < BN / 16) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) g256l_dma16(ws, woff[h], base + G256L_HALF + h * 1024);
+      for (int h = 0; h < 2; ++h) g256l_dma16(ws, woff[h], base + G256L_HALF + h * 1024);
+    }
   };
-  f32x4 acc[4][4];   // [a: N fragment][b: M fragment]
+  f32x4 acc[FN][4];   // [a: N fragment][b: M fragment]
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < FN; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int fslot0 = lr * 8, fkey = (lr >> 1) & 7;
@@ -166,13 +175,13 @@ __global__ __launch_bounds__(1024) void gemm256l_kernel(const G256Dev p) {
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
       const int slot = fslot0 + ((tt * 4 + lg) ^ fkey);
-      Chunk16 xa[4], wv[4];
+      Chunk16 xa[4], wv[FN];
 #pragma unroll
       for (int b = 0; b < 4; ++b) xa[b] = *(const Chunk16*)(sa + ((wm * 4 + b) * 128 + slot) * 16);
 #pragma unroll
-      for (int a = 0; a < 4; ++a) wv[a] = *(const Chunk16*)(sw_ + ((wn * 4 + a) * 128 + slot) * 16);
+      for (int a = 0; a < FN; ++a) wv[a] = *(const Chunk16*)(sw_ + ((wn * FN + a) * 128 + slot) * 16);
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < FN; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[a]), __builtin_bit_cast(bf16x8, xa[b]),
@@ -181,7 +190,7 @@ __global__ __launch_bounds__(1024) void gemm256l_kernel(const G256Dev p) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
-  g256_epilogue(p, acc, smem, m0, n0, wm, wn, lr, lg, tid);
+  g256_epilogue<BN>(p, acc, smem, m0, n0, wm, wn, lr, lg, tid);
 }
 
 // Returns -1 when the shape is not covered (caller uses launch_igemm).
@@ -195,26 +204,33 @@ int launch_gemm256(const IgemmArgs& a, DType dtype, hipStream_t stream) {
   if (a.c_ch != 1 || (a.c_grp > 1)) return -1;
   if (a.Nimg > 1 && a.c_img != (long)a.Hout * a.Wout * a.c_pix) return -1;
   const bool glu = a.flags & IG_GLU;
-  if (M < 4096 || M > 0x7fffffffL || a.N % 256 != 0 || a.Cin % 32 != 0 || a.Cin < 64 || a.ldw % 8 != 0 || a.c_pix % 8 != 0) return -1;
+  const int BN = a.N % 256 == 0 ? 256 : 128;
+  if (BN == 128 && (glu || M < (1L << 18))) return -1;   // the half-width tile: plain epilogues, HBM-bound 1x1 layers over >= 2^18 rows
+  if (M < 4096 || M > 0x7fffffffL || a.N % 128 != 0 || a.Cin % 32 != 0 || a.Cin < 64 || a.ldw % 8 != 0 || a.c_pix % 8 != 0) return -1;
   if (((uintptr_t)a.X & 15) || ((uintptr_t)a.W & 15) || ((uintptr_t)a.Y & 15) || ((a.flags & IG_RESIDUAL) && ((uintptr_t)a.R & 7))) return -1;
   if (glu && (a.flags & IG_BIAS_N)) return -1;
   G256Dev d;
   d.X = (const bf16_t*)a.X; d.W = (const bf16_t*)a.W; d.Y = (bf16_t*)a.Y; d.R = (const bf16_t*)a.R; d.bias = a.bias;
   d.M = (int)M; d.N = a.N; d.K = a.Cin; d.ldx = a.ldx; d.ldw = a.ldw; d.ldy = (int)a.c_pix;
-  d.tiles_n = a.N / 256;
+  d.tiles_n = a.N / BN;
   d.flags = a.flags;
   d.tiles_m = cdiv(M, 256);
   {  // N-tile groups whose weight slabs (gn x 256 rows x K bf16) stay within ~2.5 MB of the 4 MB L2 of an XCD
-    const long slab = 256L * d.K * 2;
+    const long slab = (long)BN * d.K * 2;
     d.gn = (int)std::max(1L, std::min<long>((5L << 19) / slab, d.tiles_n));
   }
   const long tiles = (long)cdiv(M, 256) * d.tiles_n;
   // whole-line requests: K steps of 64 elements; other K (no released shape) -> generic implicit GEMM
   if (d.K % 64 != 0 || (long)d.M * d.ldx * 2 >= (1L << 31) || (long)d.N * d.ldw * 2 >= (1L << 31)) return -1;
-  static DynLdsOnce once_l;
-  if (hipError_t e = ensure_dyn_lds(once_l, (const void*)gemm256l_kernel, 160 * 1024); e != hipSuccess) return (int)e;
+  static DynLdsOnce once_l, once_h;
   const int smem_l = 256 * G256_PITCH > 2 * G256L_STAGE ? 256 * G256_PITCH : 2 * G256L_STAGE;
-  hipLaunchKernelGGL(gemm256l_kernel, dim3((unsigned)tiles), dim3(1024), smem_l, stream, d);
+  if (BN == 256) {
+    if (hipError_t e = ensure_dyn_lds(once_l, (const void*)gemm256l_kernel<256>, 160 * 1024); e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(gemm256l_kernel<256>, dim3((unsigned)tiles), dim3(1024), smem_l, stream, d);
+  } else {
+    if (hipError_t e = ensure_dyn_lds(once_h, (const void*)gemm256l_kernel<128>, 160 * 1024); e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(gemm256l_kernel<128>, dim3((unsigned)tiles), dim3(1024), smem_l, stream, d);
+  }
   return (int)hipGetLastError();
 }
 

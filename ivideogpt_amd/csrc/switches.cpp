@@ -22,6 +22,8 @@ static Switches read_env() {
   s.gn_fuse = env_int("IVG_GN_FUSE", 1) != 0;
   s.gn_apply_fuse = env_int("IVG_GN_APPLY_FUSE", 1) != 0;
   s.x3 = env_int("IVG_X3", 1) != 0;
+  s.tail_fuse = env_int("IVG_TAIL_FUSE", 1) != 0;
+  s.shortcut_gemm256 = env_int("IVG_SHORTCUT_GEMM256", 1) != 0;
   s.conv_wide = env_int("IVG_CONV_WIDE", 0);
   if (s.conv_wide < 0 || s.conv_wide > 2) s.conv_wide = 0;
   s.conv_wide_grid = env_int("IVG_CONV_WIDE_GRID", 0);

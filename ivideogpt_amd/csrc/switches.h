@@ -18,6 +18,9 @@
 //                                        IVG_CONV_WIDE_GRID its grid size, IVG_CONV_WIDE_PF=0 no fragment prefetch across the step barrier,
 //                                        IVG_CONV_WIDE_STAGGER start phases (-1 = by items per workgroup), IVG_CONV_WIDE_PROBE timing probes with
 //                                        WRONG results (1: no epilogue, 2: no input normalisation)
+//   IVG_TAIL_FUSE            1        0: the decoders' tail as GroupNorm apply pass + implicit-GEMM conv_out (1: one conv3x3 launch with the
+//                                        normalisation inside its staging; bf16 decode path)
+//   IVG_SHORTCUT_GEMM256     1        0: 1x1 convolutions always on the implicit GEMM (1: on gemm256l where Cout % 256 == 0)
 //   IVG_X3                   1        0: the fp32 decode path of the tokenizer on f32-input MFMAs (1: split-bf16 "x3" convolutions)
 //   ---- launch policy
 //   IVG_GRAPH                0        1: decode steps replayed from hipGraphs (8 steps per launch) instead of eager launches
@@ -30,7 +33,7 @@
 namespace ivg {
 
 struct Switches {
-  int conv3x3 = 1, gemm256 = 1, dg3 = 1, flash_prefill = 1, flash_xatt = 1, gn_fuse = 1, gn_apply_fuse = 1, x3 = 1, conv_wide = 0, conv_wide_grid = 0, conv_wide_pf = 1, conv_wide_probe = 0, conv_wide_stagger = -1;
+  int conv3x3 = 1, gemm256 = 1, dg3 = 1, flash_prefill = 1, flash_xatt = 1, gn_fuse = 1, gn_apply_fuse = 1, x3 = 1, tail_fuse = 1, shortcut_gemm256 = 1, conv_wide = 0, conv_wide_grid = 0, conv_wide_pf = 1, conv_wide_probe = 0, conv_wide_stagger = -1;
   int graph = 0, dg3_warm = 1, conv_cap = 0, decode_lds_kb = 160;
 };
 

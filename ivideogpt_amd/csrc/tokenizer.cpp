@@ -62,7 +62,12 @@ int Run::conv(DType dt, const void* X, int N, int H, int W, const ConvW& c, void
   }
   if (in_coef) return -100;   // only the 3x3 kernel can normalise its input on the fly: the caller materialises the GroupNorm instead
   prof_begin(dt, flops, bytes);
-  CK(launch_igemm(a, dt, st));
+  int rc = -1;
+  // 1x1 shortcuts with Cout a multiple of 256 (32 x 32 level: 512 -> 256 over 917,504 pixels): a plain GEMM -- 256 x 256 tiles with
+  // whole-line LDS-DMA instead of the implicit GEMM's 128 x 128 gather (7-16 % MFMA-busy there, round-4 review)
+  if (k == 1 && stride == 1 && !ups && sw().shortcut_gemm256) rc = launch_gemm256(a, dt, st);
+  if (rc == -1) rc = launch_igemm(a, dt, st);
+  CK(rc);
   prof_end(dt);
   return 0;
 }
@@ -527,18 +532,38 @@ int Run::decoder_trunk(const TrunkW& w, const void* z, int B, int per, int T_tot
       CK((int)hipMemcpyAsync((*keep)[i + 2].p, a, (size_t)N * side * side * C * esz(dt), hipMemcpyDeviceToDevice, st));
   }
   const int C0 = c.block_out_channels[0];
-  IVG_TRY(gnorm(dt, a, b, N, side * side, C0, w.norm_out, 1e-6f, 1, nullptr, &sa));
-  {  // conv_out straight into the planar (B, T, 3, H, W) clip: float32, or the decode path's own bfloat16 (ivg_detokenize_to)
+  {  // conv_norm_out -> SiLU -> conv_out straight into the planar (B, T, 3, H, W) clip: float32, or the decode path's own bfloat16
     const bool out32 = out_dt == F32;
     IgemmArgs g;
-    g.X = b; g.W = w.conv_out.w; g.Y = (char*)out_pixels + (size_t)t0 * 3 * res * res * (out32 ? 4 : 2); g.bias = w.conv_out.b;
+    g.W = w.conv_out.w; g.Y = (char*)out_pixels + (size_t)t0 * 3 * res * res * (out32 ? 4 : 2); g.bias = w.conv_out.b;
     g.Nimg = N; g.Hin = side; g.Win = side; g.Cin = C0; g.ldx = C0; g.Hout = side; g.Wout = side;
     g.KH = 3; g.KW = 3; g.stride = 1; g.pad = 1;
     g.N = 3; g.ldw = 9 * C0;
     g.c_img = 3L * res * res; g.c_pix = 1; g.c_ch = (long)res * res;
     g.c_grp = per; g.c_grp_stride = (long)T_total * 3 * res * res;
     g.flags = IG_BIAS_N | (out32 ? IG_OUT_F32 : 0) | (e->clamp_out ? IG_CLAMP01 : 0);   // clamp(0, 1) of predict.py:73 in the epilogue
-    IVG_TRY(gemm(dt, g, 2.0 * N * side * side * 27.0 * C0, (double)esz(dt) * N * side * side * C0 + (out32 ? 4.0 : 2.0) * N * 3 * side * side));
+    const double flops = 2.0 * N * side * side * 27.0 * C0;
+    const double bytes = (double)esz(dt) * N * side * side * C0 + (out32 ? 4.0 : 2.0) * N * 3 * side * side;
+    // Round 5: the tail as ONE launch -- the normalisation inside the 3x3 kernel's halo staging (its 64-channel instance computes 61
+    // output channels nobody stores: still cheaper than a GroupNorm pass that writes the normalised tensor plus an implicit GEMM that
+    // re-gathers it nine times; bf16 decode path with the producer's statistics at hand, IVG_TAIL_FUSE=0 restores the two launches)
+    int rc = -1;
+    if (dt == BF16 && !x3 && gn_apply_fuse_enabled() && sw().tail_fuse && sa.part && sa.chunks > 0 && !planning) {
+      void* coef = e->ws.alloc((size_t)N * C0 * sizeof(float) * 2);
+      CK(launch_gn_coef(sa.part, sa.chunks, w.norm_out.g, w.norm_out.b, N, side * side, C0, c.norm_num_groups, 1e-6f, coef, st));
+      g.X = a; g.gn_in_coef = coef;
+      prof_begin(dt, flops, bytes, 2);
+      rc = launch_conv3x3(g, dt, st);
+      if (rc == 0) prof_end(dt, 2); else prof_cancel(dt, 2);
+      if (rc > 0) CK(rc);
+    } else if (planning) {
+      (void)e->ws.alloc((size_t)N * C0 * sizeof(float) * 2);
+    }
+    if (rc != 0) {
+      IVG_TRY(gnorm(dt, a, b, N, side * side, C0, w.norm_out, 1e-6f, 1, nullptr, &sa));
+      g.X = b; g.gn_in_coef = nullptr;
+      IVG_TRY(gemm(dt, g, flops, bytes));
+    }
   }
   e->ws.reset(m);
   return 0;

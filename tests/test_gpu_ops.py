@@ -466,6 +466,28 @@ def test_decode_gemm_model_shapes(K, N, mode, dt, gen, switches):
         assert rel_err(Y.float(), ref) < tol, (M, K, N, mode, dt, gen)
 
 
+def test_gemm256_half_width_tile_for_128_output_channels(switches):
+    """gemm256l_kernel<128> (round 5): 256 rows x 128 weight rows per workgroup, for the dense 1x1 layers with 128 output channels over
+    >= 2^18 pixels (the resnet shortcuts of the top decoder level, 256 -> 128).  Ragged last M tile, bias, in-place residual; and the
+    same bits as the implicit GEMM would NOT be expected (other K order) -- compared against fp64."""
+    M, N, K = (1 << 18) + 77, 128, 256
+    g = torch.Generator().manual_seed(5)
+    X = q(torch.randn(M, K, generator=g), "bf16")
+    W_ = q(torch.randn(N, K, generator=g) / K ** 0.5, "bf16")
+    b = torch.randn(N, generator=g)
+    R = q(torch.randn(M, N, generator=g), "bf16")
+    ref = X.double() @ W_.double().T + b.double() + R.double()
+    Xd, Wd, bd = X.to(DEV, torch.bfloat16), W_.to(DEV, torch.bfloat16), b.to(DEV)
+    outs = []
+    for g256 in ("1", "0"):
+        switches(IVG_GEMM256=g256)
+        Y = R.to(DEV, torch.bfloat16).clone()
+        igemm("bf16", Xd, Wd, Y, Y, bd, Win=M, Wout=M, Cin=K, ldx=K, N=N, ldw=K, c_pix=N, flags=1 | 4)
+        assert rel_err(Y.float(), ref) < TOL["bf16"]
+        outs.append(Y)
+    assert (outs[0].float() - outs[1].float()).abs().max().item() < 0.1      # two kernels, one result up to bf16 rounding
+
+
 @pytest.mark.parametrize("mode", ["plain", "bias_residual_inplace", "glu", "silu", "k_short", "k_odd_steps", "nimg"])
 def test_gemm256_large_dense(mode, switches):
     """256 x 256-tile GEMM of the prompt pass (bf16, rows not a multiple of 256): every epilogue against fp64, and bit-for-bit
