@@ -359,7 +359,7 @@ def in_flight_pass(lanes, ctx, F, greedy, with_actions):
             e.profile_enable(k, True)
     ref = torch.cuda.Event(enable_timing=True)
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(L)]
-    errors = []
+    errors, host_ms = [], [0.0] * L
 
     def body(i, record):
         try:
@@ -372,7 +372,9 @@ def in_flight_pass(lanes, ctx, F, greedy, with_actions):
                 prompt = ln["tok"].encode_context(ln["pixels"], ctx)
                 if record:
                     evs[i][1].record()
+                th0 = time.perf_counter()
                 toks = ln["model"].generate(prompt, do_sample=not greedy, top_k=100, max_new_tokens=17 * F - 1, generator=ln["gen"], **kw)
+                host_ms[i] = (time.perf_counter() - th0) * 1e3   # the host thread's time to ENQUEUE the rollout (no sync inside)
                 if record:
                     evs[i][2].record()
                 ln["tok"].detokenize(toks, ctx, clamp=True)
@@ -405,7 +407,7 @@ def in_flight_pass(lanes, ctx, F, greedy, with_actions):
         for k in (_lib.IVG_K_DECODE_ATTN, _lib.IVG_K_DECODE_GEMM):
             e.profile_enable(k, False)
         t = [ref.elapsed_time(ev) for ev in evs[i]]
-        per_lane.append({"rollout_interval_ms": [t[1], t[2]], "decode_attn_mean_launch_us": 1e3 * sa["total_ms"] / max(1, sa["launches"]),
+        per_lane.append({"rollout_interval_ms": [t[1], t[2]], "rollout_host_enqueue_ms": host_ms[i], "decode_attn_mean_launch_us": 1e3 * sa["total_ms"] / max(1, sa["launches"]),
                          "decode_gemm_mean_launch_us": 1e3 * sg["total_ms"] / max(1, sg["launches"]),
                          "decode_attn_bytes": sa["total_bytes"], "decode_gemm_bytes": sg["total_bytes"]})
         tot["attn"] += sa["total_bytes"]

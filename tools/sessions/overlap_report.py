@@ -18,9 +18,13 @@ for s, e, n in ev:
     pts.append((s, 1)); pts.append((e, -1))
 pts.sort()
 busy1 = busy2 = 0
+level = defaultdict(int)
 cur = 0; last = pts[0][0]
 for t, d in pts:
+    level[min(cur, 5)] += t - last
     if cur == 1: busy1 += t - last
     elif cur >= 2: busy2 += t - last
     cur += d; last = t
-print(f"time with exactly one kernel running {busy1/1e6:.2f} ms, with two or more {busy2/1e6:.2f} ms, span {(pts[-1][0]-pts[0][0])/1e6:.2f} ms")
+span = pts[-1][0] - pts[0][0]
+print(f"time with exactly one kernel running {busy1/1e6:.2f} ms, with two or more {busy2/1e6:.2f} ms, span {span/1e6:.2f} ms")
+print("kernels on the device at once (share of the span): " + "  ".join(f"{k}{'+' if k == 5 else ''}: {100 * v / span:.1f} %" for k, v in sorted(level.items())))
