@@ -552,9 +552,9 @@ int Run::decoder_trunk(const TrunkW& w, const void* z, int B, int per, int T_tot
       void* coef = e->ws.alloc((size_t)N * C0 * sizeof(float) * 2);
       CK(launch_gn_coef(sa.part, sa.chunks, w.norm_out.g, w.norm_out.b, N, side * side, C0, c.norm_num_groups, 1e-6f, coef, st));
       g.X = a; g.gn_in_coef = coef;
-      prof_begin(dt, flops, bytes, 2);
-      rc = launch_conv3x3(g, dt, st);
-      if (rc == 0) prof_end(dt, 2); else prof_cancel(dt, 2);
+      prof_begin(dt, flops, bytes);   // (accounted with the class conv_out has always been in -- "GEMMs / convs other than the trunks' 3x3": 3 output
+      rc = launch_conv3x3(g, dt, st); //  channels are memory-bound work, and the conv3x3 class stays the set of launches earlier rounds measured)
+      if (rc == 0) prof_end(dt); else prof_cancel(dt);
       if (rc > 0) CK(rc);
     } else if (planning) {
       (void)e->ws.alloc((size_t)N * C0 * sizeof(float) * 2);
