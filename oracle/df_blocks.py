@@ -15,7 +15,9 @@ checkpoint loads unchanged.  **Parity unpinned** for this file: no DF source or 
 available offline.  What narrows that: parameter counts (114.16 M / 310.47 M = the reference README's), and -- round 5 --
 ``oracle/pin/crosscheck_vqgan_blocks.py`` (in the CPU suite): ResnetBlock2D, Downsample2D, Attention, VectorQuantizer and the whole
 encoder trunk agree (<= 1.5e-6 relative, VQ ids identical) with an INDEPENDENT implementation of the same taming-VQGAN blocks that
-the image does hold, ``transformers.models.chameleon.modeling_chameleon``.  ``oracle/pin/pin_df_blocks.py`` pins this file against
+the image does hold, ``transformers.models.chameleon.modeling_chameleon``; Upsample2D and the whole decoder trunk (mid block with
+attention, layers_per_block + 1 resnets per up level, where the upsamplers sit, tail) agree (<= 2.7e-6) with a second one,
+``transformers.models.janus.modeling_janus``.  ``oracle/pin/pin_df_blocks.py`` pins this file against
 real ``diffusers`` (and oracle/metrics.py against real ``piqa``) wherever those wheels import; here it prints SKIPPED.
 """
 import torch

@@ -13,11 +13,19 @@ VQGAN blocks; HF's Chameleon module is written by other people from the same lin
     oracle.df_blocks.VectorQuantizer (argmin of cdist)                                                   <->  ChameleonVQVAEVectorQuantizer (argmin of z^2+e^2-2ze)
     oracle.vq_tokenizer.EncoderRef (conv_in, DownEncoderBlock2D x L, UNetMidBlock2D, GN-SiLU-conv_out)   <->  ChameleonVQVAEEncoder (whole trunk)
 
+and, for the DECODER side (Chameleon ships no decoder), a second independent implementation of the same lineage,
+``transformers.models.janus.modeling_janus`` (HF's port of Janus' VQGAN):
+
+    oracle.df_blocks.Upsample2D    (nearest x2, conv3x3 pad 1)                                            <->  JanusVQVAEConvUpsample
+    oracle.vq_tokenizer.DecoderRef (conv_in, UNetMidBlock2D, UpDecoderBlock2D x L with layers_per_block+1
+                                    resnets and the upsamplers on all but the last level, GN-SiLU-conv_out) <->  JanusVQVAEDecoder
+    (Janus puts an attention block behind every resnet of its lowest-resolution level, which diffusers' UpDecoderBlock2D does not
+    have: those blocks get a zero output projection, i.e. become the identity -- everything else of the trunk is compared.)
+
 The same tensors go into both; outputs must agree to 1e-5 relative (fp32 summation orders differ: Linear vs 1x1 conv, SDPA vs bmm) and
 the VQ assignment must be identical.  This is NOT a pin against diffusers (oracle/pin/pin_df_blocks.py does that wherever the wheel
-exists); it shrinks the unpinned surface to "both restatements share a misunderstanding", and it covers the encoder-side blocks only
-(Chameleon has no decoder: Upsample2D / UpDecoderBlock2D stay checked by reading).  Runs on CPU in seconds; part of the CPU suite
-(tests/test_oracle_crosscheck.py).
+exists); it shrinks the unpinned surface to "three restatements by different people share a misunderstanding".  Runs on CPU in
+seconds; part of the CPU suite (tests/test_oracle_crosscheck.py).
 """
 import os
 import sys
@@ -170,11 +178,71 @@ def check_encoder_trunk(g):
     return out
 
 
+def _janus():
+    from transformers.models.janus import modeling_janus as MJ
+    return MJ
+
+
+@torch.no_grad()
+def check_upsample(g):
+    MJ = _janus()
+    a = DF.Upsample2D(64).eval()
+    _randomise(a, g)
+    b = MJ.JanusVQVAEConvUpsample(64).eval()
+    b.conv.load_state_dict(a.conv.state_dict())
+    out = {}
+    for hw in ((8, 8), (5, 7)):
+        x = torch.randn(2, 64, *hw, generator=g)
+        ya, yb = a(x), b(x)
+        assert ya.shape == yb.shape == (2, 64, 2 * hw[0], 2 * hw[1])
+        out[f"upsample_{hw[0]}x{hw[1]}"] = _rel(ya, yb)
+    return out
+
+
+@torch.no_grad()
+def check_decoder_trunk(g):
+    """the whole decoder as vae.py:198-371 composes it: conv_in, mid block (with attention: the cond_decoder's; Janus always has it),
+    up levels of layers_per_block + 1 resnets, where the upsamplers sit, tail"""
+    MJ = _janus()
+    out = {}
+    for chans, lpb in (((64, 128, 256), 2), ((64, 64), 1)):
+        a = OT.DecoderRef(64, 3, chans, lpb, 32, True).eval()
+        _randomise(a, g)
+        mult = tuple(c // chans[0] for c in chans)
+        b = MJ.JanusVQVAEDecoder(_cfg(base_channels=chans[0], channel_multiplier=mult, num_res_blocks=lpb, out_channels=3)).eval()
+        _randomise(b, g)                                             # (so that nothing left un-copied could agree by accident)
+        b.conv_in.load_state_dict(a.conv_in.state_dict())
+        _copy_resnet(b.mid.block_1, a.mid_block.resnets[0])
+        _copy_attn(b.mid.attn_1, a.mid_block.attentions[0])
+        _copy_resnet(b.mid.block_2, a.mid_block.resnets[1])
+        assert len(b.up) == len(a.up_blocks)
+        for lvl, blk in enumerate(a.up_blocks):
+            assert len(b.up[lvl].block) == len(blk.resnets) == lpb + 1
+            for j, r in enumerate(blk.resnets):
+                _copy_resnet(b.up[lvl].block[j], r)
+            for att in b.up[lvl].attn:                                # Janus-only blocks -> identity
+                att.proj_out.weight.data.zero_()
+                att.proj_out.bias.data.zero_()
+            if blk.upsamplers is not None:
+                b.up[lvl].upsample.conv.load_state_dict(blk.upsamplers[0].conv.state_dict())
+            else:
+                assert not hasattr(b.up[lvl], "upsample"), "both put no upsampler on the last level"
+        b.norm_out.load_state_dict(a.conv_norm_out.state_dict())
+        b.conv_out.load_state_dict(a.conv_out.state_dict())
+        z = torch.randn(2, 64, 4, 4, generator=g)
+        ya, _ = a(z)
+        yb = b(z)
+        side = 4 * 2 ** (len(chans) - 1)
+        assert ya.shape == yb.shape == (2, 3, side, side)
+        out[f"decoder_trunk_{len(chans)}_levels"] = _rel(ya, yb)
+    return out
+
+
 def run(verbose=True):
     torch.manual_seed(0)
     g = torch.Generator().manual_seed(1234)
     res = {}
-    for fn in (check_resnet, check_downsample, check_attention, check_vq, check_encoder_trunk):
+    for fn in (check_resnet, check_downsample, check_attention, check_vq, check_encoder_trunk, check_upsample, check_decoder_trunk):
         res.update(fn(g))
     if verbose:
         for k, v in res.items():
@@ -185,5 +253,5 @@ def run(verbose=True):
 
 if __name__ == "__main__":
     res, bad = run()
-    print("CROSS-CHECK", "FAILED: " + str(bad) if bad else "ok: oracle/df_blocks.py agrees with transformers' Chameleon VQGAN blocks")
+    print("CROSS-CHECK", "FAILED: " + str(bad) if bad else "ok: oracle/df_blocks.py agrees with transformers' Chameleon (encoder side) and Janus (decoder side) VQGAN blocks")
     sys.exit(1 if bad else 0)

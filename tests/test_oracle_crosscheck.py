@@ -1,6 +1,6 @@
 """CPU: oracle/df_blocks.py (the restated diffusers blocks, "parity unpinned": diffusers is absent from the image) agrees with an
-independent third-party implementation of the same taming-VQGAN blocks that IS installed -- transformers' Chameleon VQGAN encoder --
-block by block and over the whole encoder trunk; and the real-diffusers / real-piqa pin script runs (SKIPPED sections where the
+independent third-party implementation of the same taming-VQGAN blocks that IS installed -- transformers' Chameleon VQGAN encoder and
+Janus VQGAN decoder -- block by block and over the whole encoder / decoder trunks; and the real-diffusers / real-piqa pin script runs (SKIPPED sections where the
 wheels are missing, never a silent pass of a failed comparison).  oracle/pin/crosscheck_vqgan_blocks.py, oracle/pin/pin_df_blocks.py."""
 import importlib.util
 import os
@@ -21,11 +21,13 @@ def _load(rel):
 
 def test_df_blocks_agree_with_chameleon_vqgan_blocks():
     pytest.importorskip("transformers.models.chameleon.modeling_chameleon")
+    pytest.importorskip("transformers.models.janus.modeling_janus")
     cc = _load("oracle/pin/crosscheck_vqgan_blocks.py")
     res, bad = cc.run(verbose=False)
     assert not bad, bad
     # every block family was exercised
-    for key in ("resnet_64_128", "downsample_9x11", "attention_128", "vq_8192_ids_differ", "encoder_trunk_mid_attention=0", "encoder_trunk_mid_attention=1"):
+    for key in ("resnet_64_128", "downsample_9x11", "attention_128", "vq_8192_ids_differ", "encoder_trunk_mid_attention=0", "encoder_trunk_mid_attention=1",
+                "upsample_5x7", "decoder_trunk_3_levels", "decoder_trunk_2_levels"):
         assert key in res
     assert res["vq_8192_ids_differ"] == 0 and res["vq_512_ids_differ"] == 0
 
