@@ -90,7 +90,9 @@ typedef struct {
    * live in one process, e.g. mbrl/video_predictor.py's step-wise rollout beside a batch evaluator) */
   int32_t decode_lds_kb;   /* LDS budget of a decode-step GEMM workgroup in KiB (16 .. 160); 0: the process default (IVG_DECODE_LDS_KB,
                             * 160 = a whole CU: fastest for one batch alone; <= 52: three or four workgroups of DIFFERENT engines share a CU --
-                            * what several batches in flight on one GPU want).  Best effort: shapes whose smallest plan is larger keep it.
+                            * what several batches in flight on one GPU want; a budget > 0 is the engine's BATCHES-IN-FLIGHT PROFILE: its decode
+                            * GEMMs also request weights with the default cache policy -- the other engines over the same copy ask for the same
+                            * lines -- and do not warm the next launch's weights).  Best effort: shapes whose smallest plan is larger keep it.
                             * The budget picks the kernel generation and therefore the fp32 summation order: tokens of two budgets are
                             * each deterministic and batch-invariant but not bit-comparable with one another. */
 } ivg_config;

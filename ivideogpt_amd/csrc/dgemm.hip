@@ -36,6 +36,7 @@ struct DgDev {
   long long* dbg;   // development (tools/ubench/dgemm_phase.hip): per (workgroup, wave) phase stamps, null in production
   // cache warm-up of the next launch's weights (same scheme as dgemm3.hip): tile t of pf_tile_bytes is read by XCD t % 8
   const char* pf_base; unsigned pf_tile_bytes; int pf_tiles; int pf_per_wave;
+  int w_nt;     // weights by non-temporal requests (one batch: every byte is read once per token) or default-policy ones (SkinnyArgs.w_shared)
 };
 
 // LDS-DMA with the address split the way the hardware takes it: wave-uniform 64-bit base (scalar registers, advanced per burst /
@@ -143,7 +144,8 @@ __global__ __launch_bounds__(WMAX * 64) void dgemm_kernel(const DgDev p) {
       for (int a = 0; a < FN; ++a)
 #pragma unroll
         for (int h = 0; h < 2; ++h)
-          dg_dma16_nt(W + (c0 + g * 8) * 16, woff[a][h], stage_w_lds + ((g * FN + a) * 2 + h) * 1024);
+          if (p.w_nt) dg_dma16_nt(W + (c0 + g * 8) * 16, woff[a][h], stage_w_lds + ((g * FN + a) * 2 + h) * 1024);
+          else dg_dma16(W + (c0 + g * 8) * 16, woff[a][h], stage_w_lds + ((g * FN + a) * 2 + h) * 1024);
     }
     if (burst == 0) stamp(1);
 #pragma unroll
@@ -451,7 +453,7 @@ int launch_dgemm(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
   }
   while (MF > 1 && waves * lgv * (MF + FN) * 2048 > budget) MF >>= 1;
   DgDev d{a.X, a.W, a.Y, a.M, a.N, a.K, a.ldx, a.ldw, a.ldy, a.flags, a.eps, a.bump, nburst, a.pos ? a.prof : nullptr, a.pos, a.prof_ld, a.dbg,
-          nullptr, 0u, 0, 0};
+          nullptr, 0u, 0, 0, a.w_shared ? 0 : 1};
   if (a.next_W && a.next_tile_bytes >= 1024 && a.next_tiles > 0 && sw().dg3_warm) {
     const long grid = (long)cdiv(a.N, 16 * FN) * cdiv(a.M, 16 * MF);
     const long waves_per_xcd = std::max(1L, grid / 8) * waves;

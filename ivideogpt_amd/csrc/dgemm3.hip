@@ -503,7 +503,7 @@ int launch_dgemm3(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
   d.ldxb = (unsigned)a.ldx * es; d.ldwb = (unsigned)a.ldw * es; d.ldy = a.ldy;
   d.wr = pl.wr; d.klw = pl.klw; d.ring = pl.ring; d.wave_bytes = pl.wave_bytes; d.flags = a.flags;
   d.inv_k = 1.0f / (float)a.K; d.eps = a.eps; d.bump = a.bump;
-  d.w_nt = 1;
+  d.w_nt = a.w_shared ? 0 : 1;
   d.x3 = (a.x3 && dtype == F32) ? 1 : 0;
   d.prof = a.pos ? a.prof : nullptr; d.pos = a.pos; d.prof_ld = a.prof_ld;
   d.dbg = a.dbg;

@@ -82,6 +82,8 @@ struct SkinnyArgs {
   const int* pos = nullptr;
   int prof_ld = 0;
   bool x3 = false;            // fp32 tensors: split-bf16 arithmetic (dgemm3.hip only; the other generations ignore it)
+  bool w_shared = false;      // the weight matrix is read by OTHER engines' launches too within the same few microseconds (replicas over one
+                              // copy of the weights, batches in flight): default cache policy instead of non-temporal requests
   int lds_kb = 0;             // LDS budget of a workgroup in KiB (the calling engine's policy); 0: the process default (IVG_DECODE_LDS_KB)
   long long* dbg = nullptr;   // development: phase stamps of the second / third-generation kernel (tools/ubench/dgemm_phase.hip)
   // cache warm-up (dgemm3.hip): the weight matrix the NEXT launch of the chain streams, as next_tiles contiguous tiles of

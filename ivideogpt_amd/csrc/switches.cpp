@@ -35,6 +35,8 @@ static Switches read_env() {
   s.dg3_warm = env_int("IVG_DG3_WARM", 1) != 0;
   s.conv_cap = env_int("IVG_CONV_CAP", 0) == 1;
   s.decode_lds_kb = env_int("IVG_DECODE_LDS_KB", 160);
+  s.decode_w_shared = env_int("IVG_DECODE_W_SHARED", 1) != 0;
+  s.inflight_warm = env_int("IVG_INFLIGHT_WARM", 0) != 0;
   if (s.decode_lds_kb < 16 || s.decode_lds_kb > 160) s.decode_lds_kb = 160;
   return s;
 }

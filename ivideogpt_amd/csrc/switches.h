@@ -27,6 +27,8 @@
 //   IVG_DG3_WARM             1        0: decode GEMMs do not pull the next launch's weights toward the chip
 //   IVG_CONV_CAP             0        1: conv3x3 grids at ONE workgroup per CU (LDS padded past half a CU's 160 KiB): leaves half of
 //                                        every CU's LDS, wave slots and registers to the kernels of another batch in flight
+//   IVG_DECODE_W_SHARED      1        engines with a batches-in-flight budget (decode_lds_kb > 0): 0 = non-temporal weight requests as for one batch alone
+//   IVG_INFLIGHT_WARM        0        the same engines: 1 = keep warming the next launch's weights
 //   IVG_DECODE_LDS_KB        160      LDS budget of a decode-GEMM workgroup in KiB (<= 78: it fits beside a capped conv3x3 workgroup)
 #pragma once
 
@@ -34,7 +36,7 @@ namespace ivg {
 
 struct Switches {
   int conv3x3 = 1, gemm256 = 1, dg3 = 1, flash_prefill = 1, flash_xatt = 1, gn_fuse = 1, gn_apply_fuse = 1, x3 = 1, tail_fuse = 1, shortcut_gemm256 = 1, conv_wide = 0, conv_wide_grid = 0, conv_wide_pf = 1, conv_wide_probe = 0, conv_wide_stagger = -1;
-  int graph = 0, dg3_warm = 1, conv_cap = 0, decode_lds_kb = 160;
+  int graph = 0, dg3_warm = 1, conv_cap = 0, decode_lds_kb = 160, decode_w_shared = 1, inflight_warm = 0;
 };
 
 const Switches& sw();             // the published table: immutable, never freed or rewritten (every reload publishes a NEW one)

@@ -222,9 +222,19 @@ static int step_body(ivg_engine* e, hipStream_t st, const GenBuf& g, int B, cons
     if (!e->gemm_prof_on || !e->gemm_prof) return;
     a.prof = e->gemm_prof + (size_t)idx * gp_ld; a.pos = (const int*)state; a.prof_ld = e->Lmax;
   };
+  // The batches-in-flight profile of an engine (ivg_config.decode_lds_kb > 0: it shares the GPU -- and ONE copy of the weights -- with
+  // other engines, bench.py --lanes): beside the LDS budget, (1) the weight requests of the decode GEMMs use the default cache policy
+  // instead of non-temporal ones -- the other engines ask for the same lines within microseconds (+1.7 %, IVG_DECODE_W_SHARED=0 for
+  // A/B) -- and (2) no launch warms the next launch's weights: with (1) the other lanes' launches already do, and the extra requests
+  // only compete with three attention streams (+2.0 % on top, IVG_INFLIGHT_WARM=1 for A/B; profiles/r05_lanes_policy.txt).  One batch
+  // alone keeps non-temporal weights + warm-up (rounds 2 / 3: each byte is read once per token, the warm-up hides its first touch).
+  const bool in_flight = e->decode_lds_kb > 0;
+  const bool w_shared = in_flight && sw().decode_w_shared;
+  const bool warm = !in_flight || sw().inflight_warm;
   // every launch also pulls the weight tiles of the NEXT launch of the chain toward the CUs that will consume them (dgemm3.hip): the
   // dependent GEMM then starts on (Infinity-)cache hits instead of a cold HBM stream
   auto link_next = [&](SkinnyArgs& cur, const SkinnyArgs& nxt) {
+    if (!warm) return;
     int rows = dgemm3_w_rows_per_block(nxt, dt);
     if (rows <= 0) rows = dgemm_w_rows_per_block(nxt, dt);   // the next launch runs on the second-generation kernel
     if (rows <= 0 || nxt.ldw != nxt.K) return;
@@ -232,7 +242,7 @@ static int step_body(ivg_engine* e, hipStream_t st, const GenBuf& g, int B, cons
   };
   auto layer_args = [&](int l, SkinnyArgs* g) {
     const LayerW& w = e->layers[l];
-    for (int k = 0; k < 4; ++k) { g[k].x3 = e->llm_x3 && sw().x3; g[k].lds_kb = e->decode_lds_kb; }
+    for (int k = 0; k < 4; ++k) { g[k].x3 = e->llm_x3 && sw().x3; g[k].lds_kb = e->decode_lds_kb; g[k].w_shared = w_shared; }
     SkinnyArgs& s = g[0];
     s.X = x; s.W = w.wqkv; s.Y = qkv; s.M = B; s.N = 3 * H; s.K = H; s.ldx = H; s.ldw = H; s.ldy = 3 * H;
     s.flags = SK_NORM; s.eps = c.rms_norm_eps;
@@ -246,7 +256,7 @@ static int step_body(ivg_engine* e, hipStream_t st, const GenBuf& g, int B, cons
   };
   SkinnyArgs lm;
   lm.X = x; lm.W = e->lm_head; lm.Y = logits; lm.M = B; lm.N = V; lm.K = H; lm.ldx = H; lm.ldw = H; lm.ldy = V;
-  lm.flags = IG_OUT_F32 | SK_NORM; lm.eps = c.rms_norm_eps; lm.lds_kb = e->decode_lds_kb;
+  lm.flags = IG_OUT_F32 | SK_NORM; lm.eps = c.rms_norm_eps; lm.lds_kb = e->decode_lds_kb; lm.w_shared = w_shared;
   lm.bump = (int*)state;  // pos += 1, j += 1 once the last reader of this chain's state (its last attention) is done
   SkinnyArgs cur[4], nxt[4];
   layer_args(0, cur);
