@@ -215,6 +215,34 @@ def test_committed_bench_line_keeps_the_contract():
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
 
 
+def test_committed_round5_bench_line_has_the_in_flight_roofline_and_all_configs():
+    """profiles/r05_bench_n1.json (the driver's command at the end of round 5): the contract keys, the dominant kernel's roofline on
+    the profiler's clock, `roofline_in_flight` measured in the mode `value` is measured in (all lanes' decode bytes over the union of
+    their rollout intervals), the MFMA classes priced against the nominal AND the measured sustained peak, the 1e-3-compliant
+    modes, and BASELINE configs 3 / 4 / 5 with one batch in flight over >= 10 steps and with the lanes."""
+    import json
+    d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_n1.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "single_lane", "roofline_in_flight", "fp32_mode", "compliant_mode", "other_configs"):
+        assert k in d, k
+    assert d["steps"] == 20 and d["warmup"] == 5 and d["config"]["lanes"] == 4 and d["vs_baseline"] is None
+    assert abs(d["value"] - d["config"]["global_batch"] * 14 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and "decode_attn" in r["kernel"] and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["traffic"] > 0
+    assert 0.95 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.05                       # PMC traffic ~ algorithmic bytes
+    f = d["roofline_in_flight"]
+    assert f["lanes"] == 4 and len(f["per_lane"]) == 4 and 0 < f["frac"] < 1 and abs(f["frac"] - f["achieved"] / f["peak"]) < 1e-9
+    assert all(p["rollout_interval_ms"][1] > p["rollout_interval_ms"][0] and p["decode_attn_mean_launch_us"] > 0 for p in f["per_lane"])
+    assert f["rollout_phase_ms"] >= max(p["rollout_interval_ms"][1] - p["rollout_interval_ms"][0] for p in f["per_lane"]) - 1e-6
+    mf = [o for o in d["roofline_other"] if o["bound"] == "mfma"]
+    assert mf and all(o["peak_sustained"] < o["peak"] and o["frac_of_sustained"] > o["frac"] for o in mf)
+    assert d["single_lane"]["steps"] >= 10 and d["single_lane"]["value"] < d["value"]
+    assert d["fp32_mode"]["value"] < d["compliant_mode"]["value"] < d["single_lane"]["value"]
+    for k in ("config_3", "config_4", "config_5"):
+        c = d["other_configs"][k]
+        assert c["steps"] >= 10 and c["value"] > 0 and c["lanes_in_flight"]["lanes"] == 4 and c["lanes_in_flight"]["value"] > c["value"]
+
+
 def test_bench_launch_line_and_config_presets():
     """bench.py --gpus N without a torchrun environment re-executes itself under torch.distributed.run on 127.0.0.1, one rank per
     GPU; --config presets carry the per-GPU shapes of BASELINE.json's configs."""
@@ -432,3 +460,33 @@ def test_pack_x3_slot_layout_and_split_accuracy():
     assert (y.double() - ref).abs().max() <= 1e-5 * (w.double().abs() * a.double()).sum(1).max()
     with pytest.raises(AssertionError):
         pack_x3(torch.zeros(4, 6))
+
+
+def test_round5_host_fixes_policy_kwargs_gate_and_scratch_cache():
+    """Host-side pieces of round 5 (no GPU): the per-engine launch policy travels with the model object and its replicas' constructor
+    arguments; ``from_config`` rejects misspelt keyword arguments but ignores HF's inference-irrelevant ones; a PhaseGate whose
+    ``wait_event`` raises releases its lock (the other lanes do not deadlock); the metric scratch cache is bounded."""
+    import threading
+    from ivideogpt_amd import LlamaForCausalLM, metrics, parallel, weights as W
+    m = LlamaForCausalLM(W.LLAMA_SMALL, None, dtype="bf16", decode_lds_kb=40)
+    assert m._decode_lds_kb == 40 and m.set_decode_lds_kb(0) is m and m._decode_lds_kb == 0        # no engine yet: stored for the next one
+    assert LlamaForCausalLM.BATCHES_IN_FLIGHT_LDS_KB == 40
+    cfg = dict(W.LLAMA_SMALL, num_hidden_layers=1)
+    LlamaForCausalLM.from_config(cfg, trust_remote_code=True, attn_implementation="sdpa", attention_dropout=0.1)   # accepted, ignored
+    with pytest.raises(TypeError, match="dtpye"):
+        LlamaForCausalLM.from_config(cfg, dtpye="bf16")
+
+    class Boom:
+        def wait_event(self, ev):
+            raise RuntimeError("stream died")
+    gate = parallel.PhaseGate()
+    gate._last = object()
+    with pytest.raises(RuntimeError):
+        with gate.phase(Boom()):
+            pass
+    got = threading.Event()
+    t = threading.Thread(target=lambda: (gate._lock.acquire(), got.set(), gate._lock.release()))
+    t.start()
+    t.join(5)
+    assert got.is_set(), "the gate's lock must be free again after a failed __enter__"
+    assert metrics._WS_MAX == 16 and isinstance(metrics._WS, dict)
