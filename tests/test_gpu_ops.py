@@ -152,6 +152,49 @@ def test_conv_out_planar_video(dt):
     assert (clip[:, :t0] == -7.0).all()
 
 
+@pytest.mark.parametrize("out32", [1, 0])
+@pytest.mark.parametrize("clamp", [1, 0])
+def test_fused_decoder_tail_norm_silu_conv_out_clamp_planar(clamp, out32):
+    """The decoders' tail as ONE launch (round 5; vae.py:292-294,364-369 + predict.py:73): conv_norm_out -> SiLU -> conv_out (C -> 3)
+    [-> clamp(0, 1)] with the normalisation inside the 3x3 kernel's halo staging (its 64-channel instance), written straight into the
+    planar (B, T, 3, H, W) clip at a frame offset, float32 or bfloat16 pixels."""
+    L, l = lib()
+    dt = "bf16"
+    g = torch.Generator().manual_seed(21 + clamp)
+    B, per, T, t0, H, Cin, groups = 2, 3, 5, 2, 32, 128, 32
+    x = q(torch.randn(B * per, Cin, H, H, generator=g) * 1.3 + 0.2, dt)
+    w = q(torch.randn(3, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5 * 3.0, dt)
+    b = torch.randn(3, generator=g) * 0.3 + 0.4
+    gamma, beta = 1 + 0.2 * torch.randn(Cin, generator=g), 0.2 * torch.randn(Cin, generator=g)
+    hn = F.silu(F.group_norm(x.double(), groups, gamma.double(), beta.double(), eps=1e-6))
+    hn = q(hn.float(), dt).double()
+    ref = F.conv2d(hn, w.double(), b.double(), padding=1)
+    if clamp:
+        ref = ref.clamp(0, 1)
+        assert (ref == 0).any() and (ref == 1).any() and ((ref > 0) & (ref < 1)).any()      # the clamp has something to do on both sides
+    ref = ref.reshape(B, per, 3, H, H)
+    X = x.permute(0, 2, 3, 1).contiguous().to(DEV, tdt(dt))
+    Wp = w.permute(0, 2, 3, 1).reshape(3, -1).contiguous().to(DEV, tdt(dt))
+    clip = torch.full((B, T, 3, H, H), -7.0, device=DEV, dtype=torch.float32 if out32 else torch.bfloat16)
+    Yv = clip.view(-1)[t0 * 3 * H * H:]
+    bd, gd, btd = b.to(DEV), gamma.to(DEV), beta.to(DEV)
+    a = L.IvgIgemmArgs()
+    a.X, a.W, a.Y, a.R, a.bias = X.data_ptr(), Wp.data_ptr(), Yv.data_ptr(), None, bd.data_ptr()
+    for k, v in dict(Nimg=B * per, Hin=H, Win=H, Cin=Cin, ldx=Cin, Hout=H, Wout=H, KH=3, KW=3, stride=1, pad=1, ups=0, N=3, ldw=9 * Cin,
+                     c_img=3 * H * H, c_pix=1, c_ch=H * H, c_grp=per, c_grp_stride=T * 3 * H * H, flags=1 | (32 if out32 else 0) | (128 if clamp else 0),
+                     alpha=1.0, nb0=1, nb1=1, nb2=1).items():
+        setattr(a, k, v)
+    ws = torch.empty(B * per * (((H * H + 1023) // 1024) * groups * 16 + Cin * 8) + 256, dtype=torch.uint8, device=DEV)
+    assert l.ivg_op_gn_conv(C.byref(a), code(dt), groups, P(gd), P(btd), 1e-6, P(ws), stream()) == 0
+    torch.cuda.synchronize()
+    got = clip[:, t0:t0 + per].float()
+    assert torch.isfinite(got).all()
+    assert rel_err(got, ref) < TOL[dt]
+    if clamp:
+        assert got.min().item() >= 0.0 and got.max().item() <= 1.0
+    assert (clip[:, :t0].float() == -7.0).all()
+
+
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 def test_batched_attention_gemms(dt):
     """strided batch (b, f, head) with a shared (stride 0) operand, alpha, fp32 scores, K tail (hd = 48), bias along M."""
