@@ -53,17 +53,50 @@ __global__ __launch_bounds__(512, 2) void mfma_kernel(const u32x4* __restrict__ 
   if (tid == 0) clk[blockIdx.x] = t1 - t0;
 }
 
+// the same stream with v_mfma_f32_32x32x16_bf16: twice the MACs per operand element read from the register file (16 per element
+// against 8) -- does the bigger tile sustain more under the power cap?  8 independent 32x32 accumulators (128 registers) per wave.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int LDS_PER_16>
+__global__ __launch_bounds__(512, 2) void mfma32_kernel(const u32x4* __restrict__ ops, int iters, float* __restrict__ out, long long* __restrict__ clk) {
+  __shared__ u32x4 lds[512 * 4];
+  const int tid = threadIdx.x;
+  for (int i = 0; i < 4; ++i) lds[i * 512 + tid] = ops[(i * 512 + tid) & 4095];
+  __syncthreads();
+  u32x4 a[4], b[4], nb[4];
+  for (int i = 0; i < 4; ++i) { a[i] = ops[(tid * 4 + i) & 4095]; b[i] = ops[(tid * 4 + i + 2048) & 4095]; nb[i] = b[i]; }
+  f32x16 acc[8];
+  for (int i = 0; i < 8; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {   // 8 MFMAs of 32x32x16 = the FLOPs of 16 MFMAs of 16x16x32
+      const bool rd = LDS_PER_16 == 8 || (LDS_PER_16 == 6 && i != 2 && i != 6);
+      if (rd) nb[i & 3] = lds[((it * 8 + i) * 64 + tid) & 2047];
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a[i & 3]), "v"(b[(i + 1) & 3]));
+    }
+    if (LDS_PER_16) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) b[i] = nb[i];
+    }
+  }
+  float s = 0.f;
+  for (int i = 0; i < 8; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+  out[blockIdx.x * 512 + tid] = s;
+  if (tid == 0) clk[blockIdx.x] = 0;
+}
+
 static double now_s() { timespec ts; clock_gettime(CLOCK_REALTIME, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
-template <int L>
+template <int L, bool BIG = false>
 static void run(const char* name, const u32x4* ops, int iters, float* out, long long* clk, int grid, double target_ms) {
   const double t_begin = now_s();
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  hipLaunchKernelGGL(mfma_kernel<L>, dim3(grid), dim3(512), 0, 0, ops, 1000, out, clk);   // warm-up
+  if (BIG) hipLaunchKernelGGL(mfma32_kernel<L>, dim3(grid), dim3(512), 0, 0, ops, 1000, out, clk);
+  else hipLaunchKernelGGL(mfma_kernel<L>, dim3(grid), dim3(512), 0, 0, ops, 1000, out, clk);   // warm-up
   CK(hipDeviceSynchronize());
   // size the launch for ~target_ms
   CK(hipEventRecord(e0));
-  hipLaunchKernelGGL(mfma_kernel<L>, dim3(grid), dim3(512), 0, 0, ops, iters, out, clk);
+  if (BIG) hipLaunchKernelGGL(mfma32_kernel<L>, dim3(grid), dim3(512), 0, 0, ops, iters, out, clk);
+  else hipLaunchKernelGGL(mfma_kernel<L>, dim3(grid), dim3(512), 0, 0, ops, iters, out, clk);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -71,7 +104,8 @@ static void run(const char* name, const u32x4* ops, int iters, float* out, long 
   double best = 0, best_ms = 0; long long cyc = 0;
   for (int rep = 0; rep < 3; ++rep) {
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(mfma_kernel<L>, dim3(grid), dim3(512), 0, 0, ops, it2, out, clk);
+    if (BIG) hipLaunchKernelGGL(mfma32_kernel<L>, dim3(grid), dim3(512), 0, 0, ops, it2, out, clk);
+    else hipLaunchKernelGGL(mfma_kernel<L>, dim3(grid), dim3(512), 0, 0, ops, it2, out, clk);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     CK(hipEventElapsedTime(&ms, e0, e1));
@@ -110,6 +144,10 @@ int main(int argc, char** argv) {
   run<8>("random + 8 ds_read_b128 per 16 MFMAs (conv3x3)", rnd, 20000, out, clk, grid, target_ms);
   run<16>("random + 16 ds_read_b128 per 16 MFMAs", rnd, 20000, out, clk, grid, target_ms);
   run<8>("ZERO operands + 8 ds_read_b128 per 16 MFMAs", zeros, 20000, out, clk, grid, target_ms);
+  run<0, true>("32x32x16: MFMA only, zero operands", zeros, 20000, out, clk, grid, target_ms);
+  run<0, true>("32x32x16: MFMA only, random operands", rnd, 20000, out, clk, grid, target_ms);
+  run<6, true>("32x32x16: random + 6 ds_read_b128 per 16-MFMA equiv", rnd, 20000, out, clk, grid, target_ms);
+  run<8, true>("32x32x16: random + 8 ds_read_b128 per 16-MFMA equiv", rnd, 20000, out, clk, grid, target_ms);
   run<0>("MFMA only, zero operands (again, warm chip)", zeros, 20000, out, clk, grid, target_ms);
   return 0;
 }
