@@ -304,15 +304,22 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
             Chunk16 wd = Chunk16{wv[a][2 * h], wv[a][2 * h + 1], wv[a][2 * h], wv[a][2 * h + 1]};
             asm volatile("" : "+v"(wd));   // (keeps the duplicate from being hoisted out of its four MFMAs)
 #pragma unroll
-            for (int b = 0; b < FM; ++b)
+            for (int b0 = 0; b0 < FM; ++b0) {
+              const int b = ((a * 2 + h) & 1) ? FM - 1 - b0 : b0;   // snake order: the halo fragment stays when the weight half changes
               acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wd), __builtin_bit_cast(bf16x8, xa[b]), acc[a][b], 0, 0, 0);
+            }
           }
         }
       } else {
+      // SNAKE order over the (b, a) fragment tile: exactly ONE operand changes between consecutive MFMAs (row-major changes both at
+      // every row end).  Same products into the same accumulators in the same K order -- bit-identical -- but the matrix pipe's input
+      // toggling is what the socket's power limit prices: a pure random-operand stream sustains 2,061 TFLOP/s walked this way against
+      // 2,023 row-major and 1,973 with both operands changing every time (tools/ubench/mfma_power.hip, profiles/r05_mfma_power.txt)
 #pragma unroll
       for (int b = 0; b < FM; ++b) {
 #pragma unroll
-        for (int a = 0; a < FN; ++a) {
+        for (int a0 = 0; a0 < FN; ++a0) {
+          const int a = (b & 1) ? FN - 1 - a0 : a0;
           if constexpr (sizeof(T) == 2) {
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[a]), __builtin_bit_cast(bf16x8, xa[b]),
                                                                 acc[a][b], 0, 0, 0);
@@ -376,7 +383,8 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
 #pragma unroll
           for (int b = 0; b < FM; ++b)
 #pragma unroll
-            for (int a = 0; a < FN; ++a) {
+            for (int a0 = 0; a0 < FN; ++a0) {
+              const int a = (b & 1) ? FN - 1 - a0 : a0;   // snake order (see the one-step loop)
               if constexpr (sizeof(T) == 2) {
                 acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[a]), __builtin_bit_cast(bf16x8, xa[b]),
                                                                     acc[a][b], 0, 0, 0);

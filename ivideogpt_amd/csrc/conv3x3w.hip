@@ -315,7 +315,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3w_kernel(const Conv3Dev p) {
 #pragma unroll
         for (int b = 0; b < FM; ++b)
 #pragma unroll
-          for (int a = 0; a < FN; ++a) mfma_bf16_acc(acc[t][a][b], wv[a], xa[t][b]);
+          for (int a0 = 0; a0 < FN; ++a0) {
+            const int a = (b & 1) ? FN - 1 - a0 : a0;   // snake order: one operand changes per MFMA (conv3x3.hip has the measurement)
+            mfma_bf16_acc(acc[t][a][b], wv[a], xa[t][b]);
+          }
         if constexpr (PF) {
           __builtin_amdgcn_sched_barrier(0);   // the reads below reuse xa[t]: not before its last MFMA has been issued
           if (tap < 8) load_xa(PAR, t, tap + 1);

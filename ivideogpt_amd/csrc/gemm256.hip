@@ -183,9 +183,11 @@ __global__ __launch_bounds__(1024) void gemm256l_kernel(const G256Dev p) {
 #pragma unroll
       for (int a = 0; a < FN; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b0 = 0; b0 < 4; ++b0) {
+          const int b = (a & 1) ? 3 - b0 : b0;   // snake order: one operand changes per MFMA (conv3x3.hip has the measurement)
           acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[a]), __builtin_bit_cast(bf16x8, xa[b]),
                                                               acc[a][b], 0, 0, 0);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();

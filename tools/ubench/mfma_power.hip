@@ -84,18 +84,47 @@ __global__ __launch_bounds__(512, 2) void mfma32_kernel(const u32x4* __restrict_
   if (tid == 0) clk[blockIdx.x] = 0;
 }
 
+// operand reuse between CONSECUTIVE MFMAs (random operands, no LDS): does the order in which a 4 x 4 fragment tile is walked change
+// what the pipe sustains?  PAT 0: both operands change at every MFMA; 1: row-major over (b, a) -- the B operand stays for four MFMAs,
+// both change at a row end (conv3x3's order); 2: snake -- exactly one operand changes at every MFMA; 3: the same two fragments always.
+template <int PAT>
+__global__ __launch_bounds__(512, 2) void mfma_order_kernel(const u32x4* __restrict__ ops, int iters, float* __restrict__ out, long long* __restrict__ clk) {
+  const int tid = threadIdx.x;
+  u32x4 a[4], b[4];
+  for (int i = 0; i < 4; ++i) { a[i] = ops[(tid * 4 + i) & 4095]; b[i] = ops[(tid * 4 + i + 2048) & 4095]; }
+  f32x4 acc[16];
+  for (int i = 0; i < 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      int ia, ib;
+      if (PAT == 0) { ia = i & 3; ib = (i + 1 + (i >> 2)) & 3; }
+      else if (PAT == 1) { ib = i >> 2; ia = i & 3; }
+      else if (PAT == 2) { ib = i >> 2; ia = (ib & 1) ? 3 - (i & 3) : (i & 3); }
+      else { ia = 0; ib = 0; }
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[ib * 4 + ia]) : "v"(a[ia]), "v"(b[ib]));
+    }
+  }
+  float s = 0.f;
+  for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[blockIdx.x * 512 + tid] = s;
+  if (tid == 0) clk[blockIdx.x] = 0;
+}
+
 static double now_s() { timespec ts; clock_gettime(CLOCK_REALTIME, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
-template <int L, bool BIG = false>
+template <int L, bool BIG = false, int ORDER = -1>
 static void run(const char* name, const u32x4* ops, int iters, float* out, long long* clk, int grid, double target_ms) {
   const double t_begin = now_s();
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  if (BIG) hipLaunchKernelGGL(mfma32_kernel<L>, dim3(grid), dim3(512), 0, 0, ops, 1000, out, clk);
+  if (ORDER >= 0) hipLaunchKernelGGL(mfma_order_kernel<(ORDER < 0 ? 0 : ORDER)>, dim3(grid), dim3(512), 0, 0, ops, 1000, out, clk);
+  else if (BIG) hipLaunchKernelGGL(mfma32_kernel<L>, dim3(grid), dim3(512), 0, 0, ops, 1000, out, clk);
   else hipLaunchKernelGGL(mfma_kernel<L>, dim3(grid), dim3(512), 0, 0, ops, 1000, out, clk);   // warm-up
   CK(hipDeviceSynchronize());
   // size the launch for ~target_ms
   CK(hipEventRecord(e0));
-  if (BIG) hipLaunchKernelGGL(mfma32_kernel<L>, dim3(grid), dim3(512), 0, 0, ops, iters, out, clk);
+  if (ORDER >= 0) hipLaunchKernelGGL(mfma_order_kernel<(ORDER < 0 ? 0 : ORDER)>, dim3(grid), dim3(512), 0, 0, ops, iters, out, clk);
+  else if (BIG) hipLaunchKernelGGL(mfma32_kernel<L>, dim3(grid), dim3(512), 0, 0, ops, iters, out, clk);
   else hipLaunchKernelGGL(mfma_kernel<L>, dim3(grid), dim3(512), 0, 0, ops, iters, out, clk);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
@@ -104,7 +133,8 @@ static void run(const char* name, const u32x4* ops, int iters, float* out, long 
   double best = 0, best_ms = 0; long long cyc = 0;
   for (int rep = 0; rep < 3; ++rep) {
     CK(hipEventRecord(e0));
-    if (BIG) hipLaunchKernelGGL(mfma32_kernel<L>, dim3(grid), dim3(512), 0, 0, ops, it2, out, clk);
+    if (ORDER >= 0) hipLaunchKernelGGL(mfma_order_kernel<(ORDER < 0 ? 0 : ORDER)>, dim3(grid), dim3(512), 0, 0, ops, it2, out, clk);
+    else if (BIG) hipLaunchKernelGGL(mfma32_kernel<L>, dim3(grid), dim3(512), 0, 0, ops, it2, out, clk);
     else hipLaunchKernelGGL(mfma_kernel<L>, dim3(grid), dim3(512), 0, 0, ops, it2, out, clk);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
@@ -148,6 +178,10 @@ int main(int argc, char** argv) {
   run<0, true>("32x32x16: MFMA only, random operands", rnd, 20000, out, clk, grid, target_ms);
   run<6, true>("32x32x16: random + 6 ds_read_b128 per 16-MFMA equiv", rnd, 20000, out, clk, grid, target_ms);
   run<8, true>("32x32x16: random + 8 ds_read_b128 per 16-MFMA equiv", rnd, 20000, out, clk, grid, target_ms);
+  run<0, false, 0>("order: both operands change at every MFMA", rnd, 20000, out, clk, grid, target_ms);
+  run<0, false, 1>("order: row-major (b outer, a inner; conv3x3)", rnd, 20000, out, clk, grid, target_ms);
+  run<0, false, 2>("order: snake (one operand changes per MFMA)", rnd, 20000, out, clk, grid, target_ms);
+  run<0, false, 3>("order: the same two fragments always", rnd, 20000, out, clk, grid, target_ms);
   run<0>("MFMA only, zero operands (again, warm chip)", zeros, 20000, out, clk, grid, target_ms);
   return 0;
 }
