@@ -90,9 +90,11 @@ typedef struct {
    * live in one process, e.g. mbrl/video_predictor.py's step-wise rollout beside a batch evaluator) */
   int32_t decode_lds_kb;   /* LDS budget of a decode-step GEMM workgroup in KiB (16 .. 160); 0: the process default (IVG_DECODE_LDS_KB,
                             * 160 = a whole CU: fastest for one batch alone; <= 52: three or four workgroups of DIFFERENT engines share a CU --
-                            * what several batches in flight on one GPU want; a budget > 0 is the engine's BATCHES-IN-FLIGHT PROFILE: its decode
-                            * GEMMs also request weights with the default cache policy -- the other engines over the same copy ask for the same
-                            * lines -- and do not warm the next launch's weights).  Best effort: shapes whose smallest plan is larger keep it.
+                            * what several batches in flight on one GPU want.  A budget in force BELOW 160 -- set here or through the process
+                            * default -- is the engine's BATCHES-IN-FLIGHT PROFILE: its decode GEMMs also request weights with the default
+                            * cache policy -- the other engines over the same copy ask for the same lines -- and do not warm the next launch's
+                            * weights; an explicit 160 is the one-batch profile, like 0 with the default untouched.  Best effort: shapes whose
+                            * smallest plan is larger keep it.
                             * The budget picks the kernel generation and therefore the fp32 summation order: tokens of two budgets are
                             * each deterministic and batch-invariant but not bit-comparable with one another. */
 } ivg_config;
@@ -286,6 +288,10 @@ int ivg_op_xattn(const void* q, const void* Kp, const void* VpT, void* out, int 
 /* decode-step GEMM (M <= 128 rows; K bytes a multiple of 128): Y = epi(X W^T), flags = IG_* | SK_NORM of csrc/igemm.h */
 int ivg_op_skinny(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy, int flags, int dtype,
                   ivg_stream stream);
+/* the same under an engine's launch policy: lds_kb = ivg_config.decode_lds_kb (0: process default), w_shared != 0: default-policy weight
+ * requests -- together the batches-in-flight profile, i.e. the kernel plans bench.py's lanes run (tests compare THOSE with fp64) */
+int ivg_op_skinny_policy(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy, int flags, int dtype, int lds_kb,
+                         int w_shared, ivg_stream stream);
 int ivg_op_groupnorm(const void* X, void* Y, void* ws /* >= N*chunks*groups*16 B */, const float* gamma, const float* beta,
                      const float* pos, int N, int P, int C, int groups, float eps, int silu, int dtype, ivg_stream stream);
 int ivg_op_softmax(const float* S, void* P, int64_t rows, int Lq, int Lk, int lds, int ldp, int causal, int dtype,
@@ -299,8 +305,9 @@ int ivg_op_conv_in(const void* video, int video_dtype, const float* w, const flo
  * TemperatureLogitsWarper (logits / temperature, > 0) + TopKLogitsWarper + softmax + draw as restated by oracle/llama.py
  * sample_from_logits */
 int ivg_op_sample(const float* logits, int B, int V, int top_k, float temperature, const float* uniforms, int64_t* out, ivg_stream stream);
-/* test hook: launches since the library was loaded of the kernel family `name` selects ("conv3x3_wide": the persistent two-tile 3x3
- * convolution of csrc/conv3x3w.hip; "decode_gemm_gen3" / "decode_gemm_gen2": decode-step GEMMs the dispatcher sent to dgemm3.hip / dgemm.hip) -- lets a test assert WHICH kernel produced the tensor it checked; -1 for an unknown name */
+/* test hook: launches since the library was loaded of the kernel family `name` selects ("decode_gemm_gen3" / "decode_gemm_gen2":
+ * decode-step GEMMs the dispatcher sent to dgemm3.hip / dgemm.hip; "conv3x3_subpixel": upsampling convolutions run as four 2x2 phase
+ * convolutions) -- lets a test assert WHICH kernel produced the tensor it checked; -1 for an unknown name */
 int64_t ivg_debug_counter(const char* name);
 
 #ifdef __cplusplus

@@ -384,6 +384,8 @@ int ivg_set_temperature(ivg_engine* e, float temperature) {
   return IVG_OK;
 }
 
+int ivg_engine::effective_lds_kb() const { return decode_lds_kb > 0 ? decode_lds_kb : ivg::sw().decode_lds_kb; }
+
 int ivg_set_decode_lds_kb(ivg_engine* e, int kb) {
   if (!e) return IVG_ERR_INVALID;
   if (kb != 0 && (kb < 16 || kb > 160)) return e->fail(IVG_ERR_INVALID, "decode_lds_kb must be 0 (process default) or 16 .. 160");
@@ -796,14 +798,20 @@ int ivg_op_conv_x3(const ivg_igemm_args* a, const void* w_x3, int groups, const 
 }
 
 int64_t ivg_debug_counter(const char* name) {
-  if (name && !strcmp(name, "conv3x3_wide")) return conv3x3_wide_launches();
   if (name && !strcmp(name, "decode_gemm_gen3")) return decode_gemm_launches(3);
   if (name && !strcmp(name, "decode_gemm_gen2")) return decode_gemm_launches(2);
   return -1;
 }
 
 int ivg_op_skinny(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy, int flags, int dtype, ivg_stream stream) {
+  return ivg_op_skinny_policy(X, W, Y, M, N, K, ldx, ldw, ldy, flags, dtype, 0, 0, stream);
+}
+
+int ivg_op_skinny_policy(const void* X, const void* W, void* Y, int M, int N, int K, int ldx, int ldw, int ldy, int flags, int dtype, int lds_kb,
+                         int w_shared, ivg_stream stream) {
+  if (lds_kb != 0 && (lds_kb < 16 || lds_kb > 160)) return IVG_ERR_INVALID;
   SkinnyArgs s; s.X = X; s.W = W; s.Y = Y; s.M = M; s.N = N; s.K = K; s.ldx = ldx; s.ldw = ldw; s.ldy = ldy; s.flags = flags;
+  s.lds_kb = lds_kb; s.w_shared = w_shared != 0;
   return launch_skinny(s, (DType)dtype, (hipStream_t)stream) ? IVG_ERR_HIP : IVG_OK;
 }
 

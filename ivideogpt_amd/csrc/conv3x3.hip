@@ -595,11 +595,6 @@ int launch_conv3x3(const IgemmArgs& a, DType dtype, hipStream_t stream) {
     d.gn_part = (double2*)a.gn_part; d.gn_groups = a.gn_groups;
     a.gn_chunks = d.tiles_per_img * d.tiles_n;
   }
-  d.sp_total = 0; d.sp_pairs = 0; d.probe = 0; d.stagger = 0;
-  if (dtype == BF16 && bn == 128 && !a.W_x3) {   // persistent two-tile kernel (conv3x3w.hip) where it covers the shape
-    const int rc = launch_conv3x3_wide(d, a.Nimg, a.ups != 0, TW, gna, stream);
-    if (rc != -1) return rc;
-  }
 #define IVG_C3_TW(T, BNv, U, G, PR) (TW == 16 ? launch_c3<T, BNv, U, 16, G, PR>(d, a.Nimg, stream) : launch_c3<T, BNv, U, 32, G, PR>(d, a.Nimg, stream))
 #define IVG_C3_BN(T, U, G, PR) (bn == 128 ? IVG_C3_TW(T, 128, U, G, PR) : IVG_C3_TW(T, 64, U, G, PR))
   if (a.W_x3) {   // split-bf16 arithmetic on fp32 tensors (the launcher swaps in the pre-split weights: same bytes per row)

@@ -1,5 +1,6 @@
-// Shared pieces of the LDS-halo 3x3 convolution kernels (conv3x3.hip: 256-pixel tiles, two workgroups per CU;
-// conv3x3w.hip: persistent workgroups owning two spatial tiles against one weight ring).  gfx950 only.
+// Shared pieces of the LDS-halo 3x3 convolution kernel (conv3x3.hip: 256-pixel tiles, two workgroups per CU).  gfx950 only.
+// (Round 5's persistent two-tile variant -- bit-identical, 1 % behind inside the decode stage, the evidence behind DESIGN.md 6.1 --
+// left the product library in round 6: tools/ubench/conv3x3w.hip keeps the source as a record.)
 #pragma once
 #include "igemm.h"
 
@@ -17,9 +18,6 @@ struct Conv3Dev {
   int coef_off;                      // byte offset of the two per-chunk coefficient rows in LDS
   double2* gn_part;                  // GroupNorm statistics of the output (null: off): [img][chunk = spatial tile x N tile][group]
   int gn_groups, gn_off;             // gn_off: byte offset of the per-channel partial sums in LDS (behind everything else)
-  int sp_total, sp_pairs;            // conv3x3w.hip: spatial tiles of the launch (images x tiles per image) and pairs of them
-  int stagger;                       // conv3x3w.hip: start phases of the persistent workgroups (see the kernel)
-  int probe;                         // conv3x3w.hip, measurement only (IVG_CONV_WIDE_PROBE): 1 = no epilogue, 2 = no input normalisation
 };
 
 
@@ -62,9 +60,5 @@ template <int N> __device__ __forceinline__ void wait_dma_keep() {   // all DMA 
   else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
 }
-
-
-// conv3x3w.hip: the persistent two-tile kernel; -1 when the shape is not covered (conv3x3.hip's launcher then runs its own kernel)
-int launch_conv3x3_wide(const Conv3Dev& d, int nimg, bool ups, int TW, bool gna, hipStream_t stream);
 
 }  // namespace ivg

@@ -91,7 +91,13 @@ struct ivg_engine {
   size_t gen_bytes = 0;
   std::unordered_map<std::string, hipGraphExec_t> graphs;
   bool use_graph = false;     // IVG_GRAPH=1 at ivg_create (switches.h)
+  unsigned graphs_gen = 0;    // switches_generation() the captured graphs belong to (a changed table drops them all)
   int decode_lds_kb = 0;      // LDS budget of this engine's decode GEMMs (ivg_config.decode_lds_kb / ivg_set_decode_lds_kb; 0: process default)
+  // the budget in force (this engine's, else the process default IVG_DECODE_LDS_KB) and what it implies: below a whole CU's 160 KiB the
+  // engine runs the BATCHES-IN-FLIGHT profile (shared-weight cache policy, no warm-up of the next launch) -- the same whichever of
+  // the two routes set the budget, and an explicit 160 is the one-batch profile like 0 (advice, round 5)
+  int effective_lds_kb() const;
+  bool in_flight() const { return effective_lds_kb() < 160; }
   float temperature = 1.0f;   // sampling temperature of the rollout (ivg_set_temperature; HF TemperatureLogitsWarper semantics)
   ivg::ProfClass prof[IVG_K_COUNT];
   unsigned long long* attn_prof = nullptr;  // [layers][IVG_ATTN_PROF_SLOTS][2][Lmax] wall-clock stamps of the decode attention

@@ -62,7 +62,6 @@ int launch_gemm256(const IgemmArgs& a, DType dtype, hipStream_t stream);
 // LDS-halo 3x3 stride-1 kernel (conv3x3.hip); returns -1 when the shape is not covered (use launch_igemm then)
 int launch_conv3x3(const IgemmArgs& a, DType dtype, hipStream_t stream);
 long long decode_gemm_launches(int generation);   // dgemm.hip: decode GEMMs the dispatcher sent to generation 3 / 2 since load (test hook)
-long long conv3x3_wide_launches();   // conv3x3w.hip: launches of the persistent two-tile kernel since load (test hook)
 // upper bound of the GroupNorm statistics chunks a conv3x3 launch with this output geometry writes per image
 int conv3x3_gn_chunks_bound(int Hout, int Wout, int N);
 

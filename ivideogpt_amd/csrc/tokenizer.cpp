@@ -65,7 +65,7 @@ int Run::conv(DType dt, const void* X, int N, int H, int W, const ConvW& c, void
   int rc = -1;
   // 1x1 shortcuts with Cout a multiple of 256 (32 x 32 level: 512 -> 256 over 917,504 pixels): a plain GEMM -- 256 x 256 tiles with
   // whole-line LDS-DMA instead of the implicit GEMM's 128 x 128 gather (7-16 % MFMA-busy there, round-4 review)
-  if (k == 1 && stride == 1 && !ups && sw().shortcut_gemm256) rc = launch_gemm256(a, dt, st);
+  if (k == 1 && stride == 1 && !ups) rc = launch_gemm256(a, dt, st);
   if (rc == -1) rc = launch_igemm(a, dt, st);
   CK(rc);
   prof_end(dt);
@@ -546,9 +546,9 @@ int Run::decoder_trunk(const TrunkW& w, const void* z, int B, int per, int T_tot
     const double bytes = (double)esz(dt) * N * side * side * C0 + (out32 ? 4.0 : 2.0) * N * 3 * side * side;
     // Round 5: the tail as ONE launch -- the normalisation inside the 3x3 kernel's halo staging (its 64-channel instance computes 61
     // output channels nobody stores: still cheaper than a GroupNorm pass that writes the normalised tensor plus an implicit GEMM that
-    // re-gathers it nine times; bf16 decode path with the producer's statistics at hand, IVG_TAIL_FUSE=0 restores the two launches)
+    // re-gathers it nine times; bf16 decode path with the producer's statistics at hand -- other modes keep the two launches)
     int rc = -1;
-    if (dt == BF16 && !x3 && gn_apply_fuse_enabled() && sw().tail_fuse && sa.part && sa.chunks > 0 && !planning) {
+    if (dt == BF16 && !x3 && gn_apply_fuse_enabled() && sa.part && sa.chunks > 0 && !planning) {
       void* coef = e->ws.alloc((size_t)N * C0 * sizeof(float) * 2);
       CK(launch_gn_coef(sa.part, sa.chunks, w.norm_out.g, w.norm_out.b, N, side * side, C0, c.norm_num_groups, 1e-6f, coef, st));
       g.X = a; g.gn_in_coef = coef;

@@ -182,6 +182,7 @@ int Run::prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const voi
     SkinnyArgs s;
     s.X = hidden_last; s.W = e->lm_head; s.Y = logits_last; s.M = B; s.N = V; s.K = H; s.ldx = H; s.ldw = H; s.ldy = V;
     s.flags = IG_OUT_F32 | SK_NORM; s.eps = c.rms_norm_eps; s.lds_kb = e->decode_lds_kb;
+    s.w_shared = e->in_flight() && sw().decode_w_shared;   // (the same policy as the steps' lm_head: one copy of the weights under several engines)
     CK(launch_skinny(s, dt, st));
   }
   e->ws.reset(m);
@@ -222,13 +223,13 @@ static int step_body(ivg_engine* e, hipStream_t st, const GenBuf& g, int B, cons
     if (!e->gemm_prof_on || !e->gemm_prof) return;
     a.prof = e->gemm_prof + (size_t)idx * gp_ld; a.pos = (const int*)state; a.prof_ld = e->Lmax;
   };
-  // The batches-in-flight profile of an engine (ivg_config.decode_lds_kb > 0: it shares the GPU -- and ONE copy of the weights -- with
-  // other engines, bench.py --lanes): beside the LDS budget, (1) the weight requests of the decode GEMMs use the default cache policy
+  // The batches-in-flight profile of an engine (an LDS budget below a whole CU, set per engine -- ivg_config.decode_lds_kb -- or process-wide
+  // -- IVG_DECODE_LDS_KB: it shares the GPU -- and ONE copy of the weights -- with other engines, bench.py --lanes): beside the LDS budget, (1) the weight requests of the decode GEMMs use the default cache policy
   // instead of non-temporal ones -- the other engines ask for the same lines within microseconds (+1.7 %, IVG_DECODE_W_SHARED=0 for
   // A/B) -- and (2) no launch warms the next launch's weights: with (1) the other lanes' launches already do, and the extra requests
   // only compete with three attention streams (+2.0 % on top, IVG_INFLIGHT_WARM=1 for A/B; profiles/r05_lanes_policy.txt).  One batch
   // alone keeps non-temporal weights + warm-up (rounds 2 / 3: each byte is read once per token, the warm-up hides its first touch).
-  const bool in_flight = e->decode_lds_kb > 0;
+  const bool in_flight = e->in_flight();
   const bool w_shared = in_flight && sw().decode_w_shared;
   const bool warm = !in_flight || sw().inflight_warm;
   // every launch also pulls the weight tiles of the NEXT launch of the chain toward the CUs that will consume them (dgemm3.hip): the
@@ -380,6 +381,14 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
     auto get_graph = [&](int n_steps, hipGraphExec_t* out) -> int {
       *out = nullptr;
       if (!(e->use_graph && st != nullptr)) return 0;
+      if (e->graphs_gen != switches_generation()) {   // the switch table changed: no captured step of the old table can be replayed again
+        if (!e->graphs.empty()) {
+          CK((int)hipStreamSynchronize(st));
+          for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
+          e->graphs.clear();
+        }
+        e->graphs_gen = switches_generation();
+      }
       const std::string k = key + (n_steps > 1 ? ":x" + std::to_string(n_steps) : "");
       auto it = e->graphs.find(k);
       if (it != e->graphs.end()) { *out = it->second; return 0; }

@@ -2,6 +2,7 @@
 (/root/reference/ivideogpt/utils/video_metric.py:63-100) without LPIPS / FVD (external network weights): per-frame MSE,
 PSNR and SSIM (piqa semantics), mean over a trajectory's frames, best of the ``t`` samples drawn per trajectory."""
 import ctypes as C
+import threading
 
 import torch
 
@@ -12,6 +13,7 @@ from .packing import dtype_code
 _WS = {}   # (device, stream) -> scratch tensor of ivg_frame_metrics (partial sums of the metric tiles), least recently used first
 _WS_MAX = 16   # a raw stream handle can be reused by a NEW stream after the old one died: a bounded cache also bounds how long such a
                # stale association lives (the buffer is private to one call's kernels either way -- ordered by the stream it runs on)
+_WS_LOCK = threading.Lock()   # the lanes' host threads (bench.py --lanes) all come through here: pop / insert / evict as one step
 
 
 @torch.no_grad()
@@ -35,12 +37,13 @@ def frame_metric_rows(video_gt, video_pred, gt_t0=0, pred_t0=0, frames=None):
     # the same current stream, so the caching allocator hands the old block only to later work of that stream.
     stream = torch.cuda.current_stream(gt.device)
     key = (gt.device, stream.cuda_stream)
-    ws = _WS.pop(key, None)           # (re-inserted below: the dict is in least-recently-used order)
-    if ws is None or ws.numel() * 4 < nbytes:
-        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=gt.device)
-    _WS[key] = ws
-    while len(_WS) > _WS_MAX:         # callers that keep creating streams (CU-masked ExternalStreams, short-lived lanes) do not leak
-        _WS.pop(next(iter(_WS)))      # one buffer per dead handle; an evicted buffer's block returns to the caching allocator
+    with _WS_LOCK:
+        ws = _WS.pop(key, None)           # (re-inserted below: the dict is in least-recently-used order)
+        if ws is None or ws.numel() * 4 < nbytes:
+            ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=gt.device)
+        _WS[key] = ws
+        while len(_WS) > _WS_MAX:         # callers that keep creating streams (CU-masked ExternalStreams, short-lived lanes) do not leak
+            _WS.pop(next(iter(_WS)))      # one buffer per dead handle; an evicted buffer's block returns to the caching allocator
     st = C.c_void_p(stream.cuda_stream)
     _lib.check(lib.ivg_frame_metrics(C.c_void_p(gt.data_ptr()), dtype_code(gt.dtype), B, Tg, gt_t0, C.c_void_p(pred.data_ptr()), n, Tp, pred_t0,
                                      T, H, W, C.c_void_p(rows.data_ptr()), C.c_void_p(ws.data_ptr()), nbytes, st), None, "frame_metrics")

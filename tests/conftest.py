@@ -22,10 +22,12 @@ def golden_dir():
 def switches(monkeypatch):
     """``switches(IVG_X="0", IVG_Y=None)``: set / delete IVG_* variables and publish them to the loaded library (the switch table
     of csrc/switches.h is read at load, at ivg_create and on ivg_reload_switches -- an op-level test that flips a switch between two
-    launches has to say so).  The environment and the library's table are restored after the test."""
+    launches has to say so).  The environment and the library's table are restored after the test.  The A/B switches are development
+    tools the library honours only under IVG_DEV=1 (csrc/switches.h): the fixture sets it."""
     from ivideogpt_amd import _lib
 
     def apply(**kv):
+        monkeypatch.setenv("IVG_DEV", "1")
         for k, v in kv.items():
             if v is None:
                 monkeypatch.delenv(k, raising=False)

@@ -463,15 +463,20 @@ DECODE_SHAPES = [  # (K, N, flags): every decode-step GEMM of the small (768 / 3
 ]
 
 
-@pytest.mark.parametrize("gen", ["gen3", "gen2"])
+@pytest.mark.parametrize("gen", ["gen3", "gen2", "inflight40"])
 @pytest.mark.parametrize("dt", ["bf16", "fp32"])
 @pytest.mark.parametrize("K,N,mode", DECODE_SHAPES)
 def test_decode_gemm_model_shapes(K, N, mode, dt, gen, switches):
     """The decode-step GEMMs at the shapes the rollouts run (BASELINE configs 2 and 5), with their fused epilogues -- RMSNorm row
     scale, in-place residual, SiLU(gate) * up, fp32 logits -- against fp64, for the third-generation kernel (dgemm3.hip: K over up
-    to 16 waves, one barrier; the default) and the second (IVG_DG3=0, dgemm.hip: activations as whole lines through LDS)."""
+    to 16 waves, one barrier; the default), the second (IVG_DG3=0, dgemm.hip: activations as whole lines through LDS) and
+    ``inflight40``: the BATCHES-IN-FLIGHT profile exactly as bench.py's lanes launch it -- the engine policy of a 40 KiB LDS budget with
+    shared-weight (default cache policy) requests through ivg_op_skinny_policy, whatever generation / plan the dispatcher picks for it:
+    the kernel configurations the headline number is produced with."""
     L, l = lib()
     switches(IVG_DG3="0" if gen == "gen2" else None, IVG_DECODE_LDS_KB=None)
+    policy = (40, 1) if gen == "inflight40" else (0, 0)
+    g2_0 = l.ivg_debug_counter(b"decode_gemm_gen2")
     g = torch.Generator().manual_seed(K + N)
     for M in (64, 37, 128):
         x = q(torch.randn(M, K, generator=g) * 1.7, dt)
@@ -502,11 +507,14 @@ def test_decode_gemm_model_shapes(K, N, mode, dt, gen, switches):
             flags |= 4
         else:
             Y = torch.full((M, ldy), float("nan"), device=DEV, dtype=out_dt)
-        assert l.ivg_op_skinny(P(xd), P(wd), P(Y), M, N, K, K, K, ldy, flags, code(dt), stream()) == 0
+        assert l.ivg_op_skinny_policy(P(xd), P(wd), P(Y), M, N, K, K, K, ldy, flags, code(dt), policy[0], policy[1], stream()) == 0
         torch.cuda.synchronize()
         assert torch.isfinite(Y.float()).all()
         tol = 2e-5 if (dt == "fp32" or mode == "norm_f32") else TOL[dt]
         assert rel_err(Y.float(), ref) < tol, (M, K, N, mode, dt, gen)
+    if gen == "inflight40" and K * (2 if dt == "bf16" else 4) in (1536, 6144) and N in (2304, 6144, 768):
+        # the small transformer's q/k/v, gate/up, o and down under the lanes' budget: the small-footprint second-generation plans
+        assert l.ivg_debug_counter(b"decode_gemm_gen2") - g2_0 == 3, "the 40 KiB budget did not select the second-generation plans"
 
 
 def test_gemm256_half_width_tile_for_128_output_channels(switches):

@@ -21,9 +21,9 @@ def make_tok(cfg, sd, ctx, dec):
     return m
 
 
-def make_llm(cfg, sd, dtype):
+def make_llm(cfg, sd, dtype, lds_kb=0):
     from ivideogpt_amd import LlamaForCausalLM
-    return LlamaForCausalLM(cfg, sd, dtype=dtype).to(DEV)
+    return LlamaForCausalLM(cfg, sd, dtype=dtype, decode_lds_kb=lds_kb).to(DEV)
 
 
 @pytest.mark.parametrize("name", ["tok_mini64_ctx2.npz", "tok_mini64_ctx1.npz", "tok_mini256_ctx2.npz"])
@@ -96,9 +96,12 @@ def test_x3_full_width_llama_logits_vs_oracle():
     assert e3.max().item() > 0.0
 
 
+@pytest.mark.parametrize("lds_kb", [0, 40], ids=["one_batch", "batches_in_flight"])
 @pytest.mark.parametrize("width", ["small", "medium"])
-def test_x3_decode_path_at_released_widths_vs_oracle(width):
-    """The x3 DECODE path (dgemm3.hip X3: both fragments split in registers) at the released transformer widths: greedy rollouts from
+def test_x3_decode_path_at_released_widths_vs_oracle(width, lds_kb):
+    """(Both launch profiles of an engine -- include/ivg.h ivg_config.decode_lds_kb: under the batches-in-flight budget the q/k/v,
+    gate/up and down GEMMs run the second-generation plans, which multiply fp32 tensors on f32-input MFMAs.)
+    The x3 DECODE path (dgemm3.hip X3: both fragments split in registers) at the released transformer widths: greedy rollouts from
     a 514-token prompt through ``generate`` equal the oracle's token for token; sampled ones with the same uniforms equal it up to
     near-ties of the inverse CDF (a draw within what the 1e-3 logits bar allows of a boundary may fall to the neighbouring kept
     token: tests/helpers.py assert_sampled_rollout_matches, the rule the fp32 mode's long rollouts are held to); rows do not depend
@@ -114,14 +117,14 @@ def test_x3_decode_path_at_released_widths_vs_oracle(width):
     n_new = 40
     u = torch.rand(2, n_new, generator=g)
     ora = oracle_llama(cfg, sd)
-    m = make_llm(cfg, sd, "x3")
+    m = make_llm(cfg, sd, "x3", lds_kb)
     out_g = m.generate(prompt.to(DEV), do_sample=False, max_new_tokens=n_new).cpu()
     ref_g = generate_cached(ora, prompt, n_new)
     assert torch.equal(out_g, ref_g), f"greedy: {(out_g != ref_g).sum().item()} of {2 * n_new} tokens differ from the oracle"
     out_s = m.generate(prompt.to(DEV), do_sample=True, top_k=100, max_new_tokens=n_new, uniforms=u.to(DEV)).cpu()
     ref_s = generate_cached(ora, prompt, n_new, top_k=100, uniforms=u)
     diverged = assert_sampled_rollout_matches(out_s, ref_s, ora, u, 100, prompt.shape[1], what=f"x3 {width} sampled rollout")
-    RECORD[f"sampled_{width}"] = f"{diverged} of 2 rows left the oracle's rollout at a near-tie of the inverse CDF (margin < 3e-3)"
+    RECORD[f"sampled_{width}_lds{lds_kb}"] = f"{diverged} of 2 rows left the oracle's rollout at a near-tie of the inverse CDF (margin < 3e-3)"
     p64 = torch.randint(0, 16384, (64, 40), generator=g)
     u64 = torch.rand(64, 12, generator=g)
     full = m.generate(p64.to(DEV), do_sample=True, top_k=100, max_new_tokens=12, uniforms=u64.to(DEV)).cpu()

@@ -82,17 +82,13 @@ def main():
     secs = float(sys.argv[1]) if len(sys.argv) > 1 else 2.5
     lib = _lib.load()
     N = 896
-    narrow, wide = dict(IVG_CONV_WIDE=0), dict(IVG_CONV_WIDE=2)
+    narrow = {}
     print(f"# {N} frames, bf16, plain 3x3 convolution (no bias), ~{secs} s per arm; rocm-smi sampled every 0.25 s")
+    print("# (the persistent two-tile arms of round 5 -- profiles/r05_conv_power.txt -- ran against tools/ubench/conv3x3w.hip, no longer in libivg)")
     arm(lib, "16x16 512->512  256-pixel kernel, random data", 16, 512, 512, 0, 0, N, secs, narrow)
     arm(lib, "16x16 512->512  256-pixel kernel, ZERO data", 16, 512, 512, 0, 0, N, secs, narrow, data="zeros")
-    arm(lib, "16x16 512->512  persistent two-tile kernel, random data", 16, 512, 512, 0, 0, N, secs, wide)
     arm(lib, "64x64 128->128  256-pixel kernel, random data", 64, 128, 128, 0, 0, N, secs, narrow)
-    arm(lib, "64x64 128->128  persistent two-tile kernel, random data", 64, 128, 128, 0, 0, N, secs, wide)
-    arm(lib, "64x64 128->128  persistent two-tile kernel, ZERO data", 64, 128, 128, 0, 0, N, secs, wide, data="zeros")
-    arm(lib, "32->64 256->256 upsampling, 256-pixel kernel, random data", 32, 256, 256, 1, 0, N, secs, narrow)
-    arm(lib, "32->64 256->256 upsampling, persistent kernel, random data", 32, 256, 256, 1, 0, N, secs, wide)
-    switches.set(IVG_CONV_WIDE=None)
+    arm(lib, "32->64 256->256 upsampling, random data", 32, 256, 256, 1, 0, N, secs, narrow)
 
 
 if __name__ == "__main__":

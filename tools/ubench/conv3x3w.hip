@@ -1,3 +1,8 @@
+// RECORD, not a build target (round 6): this file was ivideogpt_amd/csrc/conv3x3w.hip in round 5 -- built into libivg behind IVG_CONV_WIDE
+// (default off), bit-identical to conv3x3.hip, +13 % in isolation on the 64x64 layers and 1 % behind inside the decode stage.  It is the
+// evidence behind DESIGN.md 6.1 (the convolutions sit at the socket's power limit: profiles/r05_conv_ab_*.txt, r05_conv_power.txt).  The
+// round-5 review asked for measurement scaffolding (the IVG_CONV_WIDE_PROBE wrong-result probes) to leave the product library; the
+// kernel left with it.  To rebuild: check out 683c1c8 (tests/test_gpu_conv_wide.py and tools/conv_ab.py live there).
 // Persistent two-tile 3x3 convolution for gfx950 (bf16, 128 output channels per workgroup) -- an ALTERNATIVE to conv3x3.hip's kernel for
 // the decoder trunks (vae.py:298-371, conditional_vae.py:186-212), selected by IVG_CONV_WIDE (default OFF).
 //
