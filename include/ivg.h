@@ -160,6 +160,22 @@ void ivg_cache_destroy(ivg_engine* e, ivg_cache* c);
 int ivg_generate(ivg_engine* e, const int64_t* prompt, int64_t prompt_stride, int B, int L0, int n_new, const float* actions,
                  int act_T, int ctx, const float* uniforms, int top_k, int64_t* ids_out, float* reward_out, ivg_stream stream);
 
+/* Shared-context rollouts.  Three of the reference's four callers hand generate() rows whose prompt is ONE clip's context repeated:
+ * inference/predict.py:65 (gen_input.repeat(repeat_times, 1)), train_gpt.py:165-184 (generate_multiple_times: t samples per clip),
+ * vp/ivideogpt_interface.py:155-202 (VP2: every candidate action sequence starts from the same two frames).  Here the prompt is given
+ * ONCE per group of `group_size` consecutive trajectories: it is prefilled once, its K / V rows are stored once, and every decode step
+ * of the group's trajectories reads those rows from the one copy (L2 / Infinity Cache hits instead of group_size HBM streams); only
+ * positions >= L0 - 1 -- the prompt's last token, which carries the trajectory's own action, and the new tokens -- are per trajectory.
+ *   prompts  int64 (n_groups, L0) row stride prompt_stride; trajectory b = g * group_size + k uses prompts[g]
+ *   actions  float32 (n_groups * group_size, act_T, action_dim) or NULL (with actions: L0 must be 257*ctx, the context alone)
+ *   uniforms float32 (n_groups * group_size, n_new) or NULL (greedy);  force_sdf != 0: ivg_generate_forced_sdf's schedule
+ *   ids_out  int64 (n_groups * group_size, L0 + n_new);  reward_out float32 (n_groups * group_size) or NULL
+ * Same tokens as ivg_generate on the repeated prompt up to the rounding of the prompt's LAST position (fed through the decode-step
+ * kernels here, through the prompt pass there): identical except at near-ties of the sampler. */
+int ivg_generate_shared(ivg_engine* e, const int64_t* prompts, int64_t prompt_stride, int n_groups, int group_size, int L0, int n_new,
+                        const float* actions, int act_T, int ctx, const float* uniforms, int top_k, int force_sdf, int64_t* ids_out, float* reward_out,
+                        ivg_stream stream);
+
 /* HeadModelWithAction.generate_without_action (action_model.py:123-152; no caller in the reference): 16 sampled tokens per future
  * frame, then the forced sdf separator -- ivg_generate's action-conditioned schedule without any action embedding.  Same
  * arguments as ivg_generate minus actions / reward. */
@@ -281,6 +297,14 @@ int ivg_op_gn_conv(const ivg_igemm_args* a, int dtype, int groups, const float* 
  * (ws as ivg_op_gn_conv).  IVG_ERR_INVALID when the 3x3 kernel does not cover the shape. */
 int ivg_op_conv_x3(const ivg_igemm_args* a, const void* w_x3, int groups, const float* gamma, const float* beta, float eps, void* ws,
                    ivg_stream stream);
+/* Nearest-x2 upsampling followed by a 3x3 convolution (diffusers Upsample2D: vae.py:271-284) in SUB-PIXEL form: four 2x2 convolutions over
+ * the low-resolution input, one per output-pixel parity, with the weights pre-summed per parity (ivideogpt_amd/packing.py pack_subpixel:
+ * w_sub [4][N][4 * Cin] in the element type of X) -- 2.25 x fewer multiplies, same result.  a->ups must be 1 and a->Hout = 2 a->Hin.
+ * w_x3 / w_sub_x3 (both or neither): the split-bf16 arithmetic on fp32 tensors.  gn_part / groups as in ivg_op_conv_gn (NULL: no
+ * statistics).  Returns the statistics chunks per image (0 without gn_part), IVG_ERR_INVALID when the sub-pixel kernel does not cover
+ * the shape. */
+int ivg_op_conv_subpixel(const ivg_igemm_args* a, int dtype, const void* w_sub, const void* w_x3, const void* w_sub_x3, void* gn_part, int groups,
+                         ivg_stream stream);
 /* Tokenizer cross-attention in one pass (bf16 only; IVG_ERR_INVALID when the shape is not covered): q [M][P][C], Kp [M/F][kv][C],
  * VpT [M/F][C][kv] -> out [M][P][C], heads of C / nh channels, softmax(q k^T / sqrt(C / nh)) v per head
  * (ivideogpt/vq_model/conditional_vae.py:38-55). */

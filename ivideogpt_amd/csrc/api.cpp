@@ -43,6 +43,9 @@ struct Lookup {
     c.b = f32(n + ".bias", cout);
     // optional: the same matrix pre-split into bf16 (hi, lo) pairs for the split-bf16 3x3 kernel (packing.py: pack_x3)
     if (dt == F32 && k == 3 && e->wmap.count(n + ".weight.x3")) c.w3 = data(n + ".weight.x3", IVG_BF16, (int64_t)2 * cout * k * k * cin);
+    // optional (upsampler convs): the sub-pixel phase weights [4][cout][4 * cin] (packing.py: pack_subpixel), and their x3 split
+    if (k == 3 && e->wmap.count(n + ".weight.subpix")) c.wsub = data(n + ".weight.subpix", (int)dt, (int64_t)16 * cout * cin);
+    if (dt == F32 && k == 3 && e->wmap.count(n + ".weight.subpix.x3")) c.wsub3 = data(n + ".weight.subpix.x3", IVG_BF16, (int64_t)32 * cout * cin);
     return c;
   }
   NormW norm(const std::string& n, int C) { NormW r; r.g = f32(n + ".weight", C); r.b = f32(n + ".bias", C); return r; }
@@ -465,6 +468,32 @@ int ivg_generate(ivg_engine* e, const int64_t* prompt, int64_t prompt_stride, in
     return r.generate(prompt, prompt_stride, B, L0, n_new, actions, act_T, ctx, uniforms, top_k, ids_out, reward_out); });
 }
 
+int ivg_generate_shared(ivg_engine* e, const int64_t* prompts, int64_t prompt_stride, int n_groups, int group_size, int L0, int n_new,
+                        const float* actions, int act_T, int ctx, const float* uniforms, int top_k, int force_sdf, int64_t* ids_out, float* reward_out,
+                        ivg_stream stream) {
+  if (!e) return IVG_ERR_INVALID;
+  if (e->cfg.num_layers <= 0) return e->fail(IVG_ERR_INVALID, "generate: engine was created without a transformer");
+  if (n_groups <= 0 || group_size <= 0) return e->fail(IVG_ERR_INVALID, "generate_shared: n_groups and group_size must be positive");
+  if (n_new < 1 || L0 < 2 || L0 + n_new > e->Lmax)
+    return e->fail(IVG_ERR_CAPACITY, "generate: sequence of " + std::to_string(L0 + n_new) + " tokens exceeds the KV cache (" + std::to_string(e->Lmax) + ")");
+  if (actions && (e->cfg.action_dim <= 0 || !e->act_w)) return e->fail(IVG_ERR_INVALID, "generate: actions given but the model is action-free");
+  if (actions) {
+    // the shared prefix is [0, L0 - 1): it may not contain an action slot (those carry per-trajectory actions), so the prompt is the
+    // context alone -- its last token, the first sdf slot, is fed per trajectory
+    if (L0 != 257 * ctx) return e->fail(IVG_ERR_INVALID, "generate_shared: an action-conditioned shared prompt must hold exactly 257*ctx tokens");
+    const int last = n_new / 17 + ctx - 1;
+    if (last >= act_T || act_T > e->cfg.max_frames) return e->fail(IVG_ERR_INVALID, "generate: action tensor too short (or longer than max_frames)");
+  }
+  const int B = n_groups * group_size;
+  if (group_size == 1)   // nothing to share: the plain entry (one prefill over all rows)
+    return plan_then_run(e, (hipStream_t)stream, [&](Run& r) {
+      return r.generate(prompts, prompt_stride, B, L0, n_new, actions, act_T, ctx, uniforms, top_k, ids_out, reward_out, false, nullptr, nullptr, nullptr,
+                        force_sdf != 0); });
+  return plan_then_run(e, (hipStream_t)stream, [&](Run& r) {
+    return r.generate(prompts, prompt_stride, B, L0, n_new, actions, act_T, ctx, uniforms, top_k, ids_out, reward_out, false, nullptr, nullptr, nullptr,
+                      force_sdf != 0, group_size); });
+}
+
 int ivg_generate_forced_sdf(ivg_engine* e, const int64_t* prompt, int64_t prompt_stride, int B, int L0, int n_new, int ctx, const float* uniforms,
                             int top_k, int64_t* ids_out, ivg_stream stream) {
   if (!e) return IVG_ERR_INVALID;
@@ -749,6 +778,27 @@ int ivg_op_conv_gn(const ivg_igemm_args* a, int dtype, void* gn_part, int groups
   return g.gn_chunks;
 }
 
+int ivg_op_conv_subpixel(const ivg_igemm_args* a, int dtype, const void* w_sub, const void* w_x3, const void* w_sub_x3, void* gn_part, int groups,
+                         ivg_stream stream) {
+  // unit-test hook: the nearest-x2 upsampling convolution in sub-pixel form (a->ups must be 1; a->W = the plain [N][9 Cin] matrix,
+  // unused unless the shape falls back).  w_x3 / w_sub_x3 != NULL: split-bf16 arithmetic on fp32 tensors.  gn_part != NULL: output
+  // statistics from the epilogue; returns the chunks per image then (0 without), IVG_ERR_INVALID when the sub-pixel kernel did not run.
+  if (!a->ups || !w_sub) return IVG_ERR_INVALID;
+  IgemmArgs g;
+  g.X = a->X; g.W = a->W; g.Y = a->Y; g.R = a->R; g.bias = a->bias;
+  g.Nimg = a->Nimg; g.Hin = a->Hin; g.Win = a->Win; g.Cin = a->Cin; g.ldx = a->ldx; g.Hout = a->Hout; g.Wout = a->Wout;
+  g.KH = a->KH; g.KW = a->KW; g.stride = a->stride; g.pad = a->pad; g.ups = a->ups; g.N = a->N; g.ldw = a->ldw;
+  g.c_img = a->c_img; g.c_pix = a->c_pix; g.c_ch = a->c_ch; g.c_grp = a->c_grp; g.c_grp_stride = a->c_grp_stride;
+  g.flags = a->flags; g.alpha = a->alpha;
+  g.W_sub = w_sub; g.W_x3 = w_x3; g.W_sub_x3 = w_sub_x3;
+  g.gn_part = gn_part; g.gn_groups = groups;
+  const long long before = conv3x3_subpixel_launches();
+  const int rc = launch_conv3x3(g, (DType)dtype, (hipStream_t)stream);
+  if (rc != 0) return rc > 0 ? IVG_ERR_HIP : IVG_ERR_INVALID;
+  if (conv3x3_subpixel_launches() == before) return IVG_ERR_INVALID;
+  return gn_part ? g.gn_chunks : 0;
+}
+
 int ivg_op_xattn(const void* q, const void* Kp, const void* VpT, void* out, int M, int F, int P, int kv, int C, int nh, int dtype, ivg_stream stream) {
   const int rc = launch_xattn(q, Kp, VpT, out, M, F, P, kv, C, nh, (DType)dtype, (hipStream_t)stream);
   return rc == 0 ? IVG_OK : (rc > 0 ? IVG_ERR_HIP : IVG_ERR_INVALID);
@@ -798,6 +848,7 @@ int ivg_op_conv_x3(const ivg_igemm_args* a, const void* w_x3, int groups, const 
 }
 
 int64_t ivg_debug_counter(const char* name) {
+  if (name && !strcmp(name, "conv3x3_subpixel")) return conv3x3_subpixel_launches();
   if (name && !strcmp(name, "decode_gemm_gen3")) return decode_gemm_launches(3);
   if (name && !strcmp(name, "decode_gemm_gen2")) return decode_gemm_launches(2);
   return -1;

@@ -30,6 +30,7 @@
 //     queue and drains it.
 // Bytes per (tap, chunk) step: 8 KiB of weights + 1/9 of a ~24 KiB halo for 2.1 MFLOP -> ~195 FLOP/B (igemm: 64).
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -57,9 +58,21 @@ namespace ivg {
 // a slot's [a_hi | a_lo] by [w_hi | w_hi], a second one by [w_lo | w_lo]: all four partial products, fp32 accumulate, for 2 x 16
 // MFMA clocks per 16 channels where the f32-input MFMA path needs 4 x 32 -- 2^-17 relative per operand instead of 2^-24 (far inside
 // the 1e-3 bar on pixels; NOT used by tokenize, whose bit-exact ids need the exact fp32 chain).  Same LDS geometry as the fp32 instances.
-template <typename T, int BN, bool UPS, int TW, bool GNA, bool TPB2, bool X3 = false>
+// SUBPIX (round 6): the nearest-x2 upsampling convolution in SUB-PIXEL form.  A 3x3 convolution over a nearest-x2 upsampled image is
+// exactly four 2x2 convolutions over the low-resolution image, one per output-pixel parity (py, px), with pre-summed weights: output
+// row 2 iy + py reads upsampled rows 2 iy + py - 1 .. 2 iy + py + 1 = input rows {iy - 1, iy, iy} (py = 0) or {iy, iy, iy + 1}
+// (py = 1), so the row taps collapse to {W0, W1 + W2} resp. {W0 + W1, W2}; columns alike; the zero padding of the upsampled image
+// maps onto the zero padding of the input.  16 instead of 36 tap-GEMMs per input pixel: 2.25 x fewer multiplies for the same
+// result (the weights are pre-summed in fp32 at pack time, packing.py pack_subpixel: [phase][N][tap (kh2, kw2)][Cin]).  A workgroup
+// owns a TH x TW tile of INPUT pixels, ONE phase and BN channels: the plain kernel's halo tile and fragment addressing with the tap
+// set {(py + kh2, px + kw2)} -- four steps per channel chunk on a ring of four weight slots -- and an epilogue that stores to the
+// pixels (2 y + py, 2 x + px).  The four phases of a spatial tile are adjacent in the XCD-aware block order (one halo in L2).
+template <typename T, int BN, bool UPS, int TW, bool GNA, bool TPB2, bool X3 = false, bool SUBPIX = false>
 __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
   static_assert(!X3 || sizeof(T) == 4, "split-bf16 arithmetic reads fp32 tensors");
+  static_assert(!SUBPIX || (!UPS && !GNA && !TPB2), "the sub-pixel instances are plain-geometry, one step per barrier, un-normalised input");
+  constexpr int NT = SUBPIX ? 4 : 9;       // taps (steps) per channel chunk
+  constexpr int RING = SUBPIX ? 4 : 3;     // weight ring slots of the one-step loop (slot of step s = s % RING must be a function of the tap)
   constexpr int VEC = Traits<T>::VEC;
   constexpr int CK = 4 * VEC;              // channels per chunk: one 64-byte LDS row per halo pixel (one MFMA K-step)
   constexpr int WN = BN / 2;               // 8 waves = 4 (pixels) x 2 (channels)
@@ -76,7 +89,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
   auto PXO = [](int b) constexpr { return TW == 16 ? 0 : (b & 1) * 16; };
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* hbuf0 = smem;
-  unsigned char* wbuf0 = smem + 2 * HB;   // three weight buffers
+  unsigned char* wbuf0 = smem + 2 * HB;   // three weight buffers (four: sub-pixel instances and the two-step loop)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform values stay in scalar registers
@@ -93,7 +106,8 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
     v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
   const int tile_n = v % p.tiles_n;
-  const int sp = v / p.tiles_n;
+  const int phase = SUBPIX ? (v / p.tiles_n) & 3 : 0;   // (py, px) = (phase >> 1, phase & 1): parity of the output pixels this workgroup writes
+  const int sp = SUBPIX ? (v / p.tiles_n) >> 2 : v / p.tiles_n;
   const int img = sp / p.tiles_per_img;
   const int t_in = sp - img * p.tiles_per_img;
   const int ty = t_in / p.tiles_x, tx = t_in - ty * p.tiles_x;
@@ -139,7 +153,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
     const int n = q >> 2, slot = q & 3;
     const int c = slot ^ swz_key(n);
     const int nrow = min(n_base + n, p.N - 1);
-    woff = (unsigned)(nrow * p.ldw) * (unsigned)sizeof(T) + (unsigned)(c * VEC * (int)sizeof(T));
+    woff = (unsigned)((SUBPIX ? phase * p.N + nrow : nrow) * p.ldw) * (unsigned)sizeof(T) + (unsigned)(c * VEC * (int)sizeof(T));
   }
   const int w_dst = (BN == 128 ? wave : (wave & 3)) * 1024;
   auto issue_w = [&](int tap, int chunk, int ring) {
@@ -217,6 +231,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
   for (int kw = 0; kw < 3; ++kw) {
     int hx, rowbase;
     if constexpr (UPS) { hx = ((lr + kw - 1) >> 1) + 1; rowbase = (pyw >> 1) * HTW; }
+    else if constexpr (SUBPIX) { hx = lr + kw + (phase & 1); rowbase = (pyw + (phase >> 1)) * HTW; }   // taps (py + kh2, px + kw2), kw < 2 used
     else { hx = lr + kw; rowbase = pyw * HTW; }
     a_base[kw] = (rowbase + hx) * 64 + ((lg ^ halo_key<UPS>(hx)) << 4);
   }
@@ -225,7 +240,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
     else return ((BR(b) + kh) * HTW + PXO(b)) * 64;
   };
   auto read_a = [&](int buf, int tap, int b) -> Chunk16 {
-    const int kh = tap / 3, kw = tap - kh * 3;
+    const int kh = SUBPIX ? tap >> 1 : tap / 3, kw = SUBPIX ? tap & 1 : tap - kh * 3;
     int base = a_base[kw];
     if constexpr (XHALF) {
       if (b & 1) { asm volatile("" : "+v"(base)); base = (base + 8 * 64) ^ 16; }   // (opaque: or the compiler hoists the three results back into registers)
@@ -267,23 +282,36 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
     const bool more = chunk + 1 < nchunks;                       // another chunk follows: its halo is staged under this one
     unsigned char* hb_next = hbuf0 + (1 - PAR) * HB;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int tap2 = (tap + 2) % 9, chunk2 = chunk + (tap + 2) / 9;   // the step whose weights are requested now
-      const bool w_more = tap < 7 || more;
-      const bool h_more = tap < HI && more;
+    for (int tap = 0; tap < NT; ++tap) {
+      const int tap2 = (tap + 2) % NT, chunk2 = chunk + (tap + 2) / NT;   // the step whose weights are requested now
+      const bool w_more = tap < NT - 2 || more;
       int issued = 0;
       auto issue_dma = [&]() {
-        if (w_more) { issue_w(tap2, chunk2, (tap + 2) % 3); issued += 1; }
-        if (tap < HI) { if (more) { issue_halo_piece(tap, chunk + 1, hb_next); issued += h_any[tap < HI ? tap : 0]; } }
+        if (w_more) { issue_w(tap2, chunk2, (tap + 2) % RING); issued += 1; }
+        if constexpr (SUBPIX) {
+          // four steps per chunk: pieces 0 and 1 of the next chunk's halo at tap 0, piece 2 at tap 1 -- each has landed by the end of
+          // the following step, so the split-bf16 instances can rewrite them at taps 2 and 3, before the chunk's last barrier
+          static_assert(!SUBPIX || HI == 3, "halo pieces of the plain geometry");
+          if (more) {
+            if (tap == 0) { issue_halo_piece(0, chunk + 1, hb_next); issue_halo_piece(1, chunk + 1, hb_next); issued += h_any[0] + h_any[1]; }
+            if (tap == 1) { issue_halo_piece(2, chunk + 1, hb_next); issued += h_any[2]; }
+          }
+        } else {
+          if (tap < HI) { if (more) { issue_halo_piece(tap, chunk + 1, hb_next); issued += h_any[tap < HI ? tap : 0]; } }
+        }
       };
-      (void)h_more;
       if (GNA || X3 || early) issue_dma();   // (the instances that transform the staged halo issue at the top in every wave: one code path less, no spills)
       if constexpr (GNA || X3) {
         if (more) {
           if (tap == 0) issued += load_coef(chunk + 1);
           // piece `it` of the next chunk was requested at tap `it` and has landed by the end of tap `it + 1`: normalise it at
           // tap 4 + it (visible to everyone after that step's barrier, long before the chunk's first tap)
-          if (tap >= 4 && tap - 4 < HI) transform_piece(chunk + 1, tap - 4, hb_next);
+          if constexpr (SUBPIX) {
+            if (tap == 2) { transform_piece(chunk + 1, 0, hb_next); transform_piece(chunk + 1, 1, hb_next); }
+            if (tap == 3) transform_piece(chunk + 1, 2, hb_next);
+          } else {
+            if (tap >= 4 && tap - 4 < HI) transform_piece(chunk + 1, tap - 4, hb_next);
+          }
         }
       }
       if (!GNA && !X3 && !early) issue_dma();
@@ -292,7 +320,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
 #pragma unroll
       for (int b = 0; b < FM; ++b) xa[b] = read_a(PAR, tap, b);
 #pragma unroll
-      for (int a = 0; a < FN; ++a) wv[a] = *(const Chunk16*)(wbuf0 + w_base + ((tap % 3) * W_BYTES + a * 1024));
+      for (int a = 0; a < FN; ++a) wv[a] = *(const Chunk16*)(wbuf0 + w_base + ((tap % RING) * W_BYTES + a * 1024));
       if constexpr (X3) {
         // W fragment outermost: one duplicated half ([w_hi | w_hi], then [w_lo | w_lo]) is live at a time -- built for all FN fragments
         // up front (the order the compiler prefers) it costs 32 registers the 128-channel instances do not have (13-31 spilled, and
@@ -423,7 +451,8 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
     for (int r = 0; r < 4; ++r) { gs[a][r] = 0.f; gq[a][r] = 0.f; }
 #pragma unroll
   for (int b = 0; b < FM; ++b) {
-    const int pix = (y0 + pyw + BR(b)) * p.Wo + (x0 + PXO(b) + lr);
+    const int pix = SUBPIX ? (2 * (y0 + pyw + BR(b)) + (phase >> 1)) * p.Wo + 2 * (x0 + PXO(b) + lr) + (phase & 1)
+                           : (y0 + pyw + BR(b)) * p.Wo + (x0 + PXO(b) + lr);
     const long obase = (long)(img / p.c_grp) * p.c_grp_stride + (long)(img % p.c_grp) * p.c_img + (long)pix * p.c_pix;
 #pragma unroll
     for (int a = 0; a < FN; ++a) {
@@ -513,8 +542,8 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
     double a1 = 0.0, a2 = 0.0;
     for (int c = c0; c < c1; ++c)
       for (int w = 0; w < 4; ++w) { a1 += (double)ch_s[w * BN + c - n_base]; a2 += (double)ch_q[w * BN + c - n_base]; }
-    const long chunk = (long)t_in * p.tiles_n + tile_n;
-    p.gn_part[((long)img * p.tiles_per_img * p.tiles_n + chunk) * p.gn_groups + tid] = double2{a1, a2};
+    const long chunk = (long)(SUBPIX ? t_in * 4 + phase : t_in) * p.tiles_n + tile_n;
+    p.gn_part[((long)img * p.tiles_per_img * (SUBPIX ? 4 : 1) * p.tiles_n + chunk) * p.gn_groups + tid] = double2{a1, a2};
   }
   if (staged) {
     constexpr int CPR = BN * (int)sizeof(T) / 16;   // 16-byte chunks per staged pixel row
@@ -522,19 +551,20 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
     const long ibase = (long)(img / p.c_grp) * p.c_grp_stride + (long)(img % p.c_grp) * p.c_img;
     for (int q = tid; q < 256 * CPR; q += 512) {
       const int pl = q / CPR, ch = q - pl * CPR;
-      const int oy = y0 + (pl >> TWS), ox = x0 + (pl & (TW - 1));
+      const int oy = SUBPIX ? 2 * (y0 + (pl >> TWS)) + (phase >> 1) : y0 + (pl >> TWS);
+      const int ox = SUBPIX ? 2 * (x0 + (pl & (TW - 1))) + (phase & 1) : x0 + (pl & (TW - 1));
       const Chunk16 val = *(const Chunk16*)(smem + pl * PITCH + ch * 16);
       *(Chunk16*)(Y + ibase + (long)(oy * p.Wo + ox) * p.c_pix + n_base + ch * (16 / (int)sizeof(T))) = val;
     }
   }
 }
 
-template <typename T, int BN, bool UPS, int TW, bool GNA, bool TPB2, bool X3 = false>
+template <typename T, int BN, bool UPS, int TW, bool GNA, bool TPB2, bool X3 = false, bool SUBPIX = false>
 static int launch_c3(const Conv3Dev& d, int nimg, hipStream_t stream) {
   constexpr int TH = 256 / TW;
   constexpr int HROWS = (UPS ? TH / 2 + 2 : TH + 2) * (UPS ? TW / 2 + 2 : TW + 2);
   constexpr int HB = (HROWS * 4 + 511) / 512 * 8192;
-  constexpr int MAIN = 2 * HB + (TPB2 ? 4 : 3) * BN * 64;   // halo double buffer + weight ring
+  constexpr int MAIN = 2 * HB + (TPB2 || SUBPIX ? 4 : 3) * BN * 64;   // halo double buffer + weight ring
   static_assert(MAIN <= 80 * 1024, "two workgroups per CU");
   int smem = MAIN;
   const int stage = 256 * (BN * (int)sizeof(T) + 16);   // LDS-staged epilogue tile
@@ -550,9 +580,9 @@ static int launch_c3(const Conv3Dev& d, int nimg, hipStream_t stream) {
   // beside HBM- / latency-bound ones instead of a grid that holds every CU until it drains.
   if (sw().conv_cap) smem = std::max(smem, 82 * 1024);
   static DynLdsOnce once;
-  auto kfn = conv3x3_kernel<T, BN, UPS, TW, GNA, TPB2, X3>;
+  auto kfn = conv3x3_kernel<T, BN, UPS, TW, GNA, TPB2, X3, SUBPIX>;
   if (hipError_t e = ensure_dyn_lds(once, (const void*)kfn, 160 * 1024); e != hipSuccess) return (int)e;
-  const long blocks = (long)nimg * d.tiles_per_img * d.tiles_n;
+  const long blocks = (long)nimg * d.tiles_per_img * d.tiles_n * (SUBPIX ? 4 : 1);
   hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(512), smem, stream, dd);
   return (int)hipGetLastError();
 }
@@ -560,6 +590,9 @@ static int launch_c3(const Conv3Dev& d, int nimg, hipStream_t stream) {
 int conv3x3_gn_chunks_bound(int Hout, int Wout, int N) { return cdiv((long)Hout * Wout, 256) * cdiv(N, 64); }
 
 bool conv3x3_enabled() { return sw().conv3x3 != 0; }
+
+static std::atomic<long long> g_subpix_launches{0};
+long long conv3x3_subpixel_launches() { return g_subpix_launches.load(std::memory_order_relaxed); }
 
 // Returns -1 when the shape is not covered (caller falls back to the generic implicit GEMM).
 int launch_conv3x3(const IgemmArgs& a, DType dtype, hipStream_t stream) {
@@ -571,16 +604,24 @@ int launch_conv3x3(const IgemmArgs& a, DType dtype, hipStream_t stream) {
   if (a.Cin % ck != 0 || a.ldx != a.Cin || a.N < 1) return -1;
   const int Ho = a.Hout, Wo = a.Wout;
   if (a.ups ? (Ho != 2 * a.Hin || Wo != 2 * a.Win) : (Ho != a.Hin || Wo != a.Win)) return -1;
-  const int TW = Wo >= 32 ? 32 : Wo;   // 16x16 or 8x32 output tiles: halo <= 10 x 34 pixels = 24 KiB per buffer
+  // sub-pixel form of an upsampling convolution (pre-summed phase weights at hand, input tileable): tiles are laid over the INPUT
+  const void* w_sub = a.W_x3 ? a.W_sub_x3 : a.W_sub;
+  bool subpix = a.ups && w_sub && sw().subpixel && !a.gn_in_coef;
+  if (subpix) {
+    const int tw = a.Win >= 32 ? 32 : a.Win;
+    if ((tw != 16 && tw != 32) || a.Win % tw != 0 || a.Hin % (256 / tw) != 0 || ((uintptr_t)w_sub & 15)) subpix = false;
+  }
+  const int Ht = subpix ? a.Hin : Ho, Wt = subpix ? a.Win : Wo;   // the grid the 256-pixel tiles cover
+  const int TW = Wt >= 32 ? 32 : Wt;   // 16x16 or 8x32 tiles: halo <= 10 x 34 pixels = 24 KiB per buffer
   if (TW != 16 && TW != 32) return -1;
   const int bn = a.N > 64 ? 128 : 64;
   const int TH = 256 / TW;
-  if (Wo % TW != 0 || Ho % TH != 0) return -1;
+  if (Wt % TW != 0 || Ht % TH != 0) return -1;
   if (((uintptr_t)a.X & 15) || ((uintptr_t)a.W & 15)) return -1;
   Conv3Dev d;
   d.X = a.X; d.W = a.W; d.Y = a.Y; d.R = a.R; d.bias = a.bias;
   d.H = a.Hin; d.Wd = a.Win; d.Cin = a.Cin; d.Ho = Ho; d.Wo = Wo;
-  d.tiles_x = Wo / TW; d.tiles_per_img = d.tiles_x * (Ho / TH);
+  d.tiles_x = Wt / TW; d.tiles_per_img = d.tiles_x * (Ht / TH);
   d.N = a.N; d.ldw = a.ldw;
   d.tiles_n = cdiv(a.N, bn);
   d.c_img = a.c_img; d.c_pix = a.c_pix; d.c_ch = a.c_ch; d.c_grp = a.c_grp > 0 ? a.c_grp : 1; d.c_grp_stride = a.c_grp_stride;
@@ -593,7 +634,17 @@ int launch_conv3x3(const IgemmArgs& a, DType dtype, hipStream_t stream) {
   d.in_coef = (const f32x2*)a.gn_in_coef;
   if (a.gn_part && a.gn_groups > 0 && a.gn_groups <= 64 && a.N % a.gn_groups == 0 && (a.c_grp <= 1)) {
     d.gn_part = (double2*)a.gn_part; d.gn_groups = a.gn_groups;
-    a.gn_chunks = d.tiles_per_img * d.tiles_n;
+    a.gn_chunks = d.tiles_per_img * d.tiles_n * (subpix ? 4 : 1);
+  }
+  if (subpix) {   // [phase][N][4 taps x Cin]: four 2x2 convolutions over the input (see the kernel's SUBPIX note)
+    d.W = w_sub; d.ldw = 4 * a.Cin;
+    g_subpix_launches.fetch_add(1, std::memory_order_relaxed);
+#define IVG_C3S_TW(T, BNv, X) (TW == 16 ? launch_c3<T, BNv, false, 16, false, false, X, true>(d, a.Nimg, stream) : launch_c3<T, BNv, false, 32, false, false, X, true>(d, a.Nimg, stream))
+#define IVG_C3S_BN(T, X) (bn == 128 ? IVG_C3S_TW(T, 128, X) : IVG_C3S_TW(T, 64, X))
+    if (a.W_x3) { if (dtype != F32) return (int)hipErrorInvalidValue; return IVG_C3S_BN(float, true); }
+    return dtype == BF16 ? IVG_C3S_BN(bf16_t, false) : IVG_C3S_BN(float, false);
+#undef IVG_C3S_BN
+#undef IVG_C3S_TW
   }
 #define IVG_C3_TW(T, BNv, U, G, PR) (TW == 16 ? launch_c3<T, BNv, U, 16, G, PR>(d, a.Nimg, stream) : launch_c3<T, BNv, U, 32, G, PR>(d, a.Nimg, stream))
 #define IVG_C3_BN(T, U, G, PR) (bn == 128 ? IVG_C3_TW(T, 128, U, G, PR) : IVG_C3_TW(T, 64, U, G, PR))

@@ -27,7 +27,8 @@ struct Arena {
 };
 
 struct ConvW { const void* w = nullptr; const float* b = nullptr; int cin = 0, cout = 0, k = 1;
-               const void* w3 = nullptr; /* fp32 3x3 convs of the "x3" decode mode: weights pre-split into bf16 (hi, lo) pairs */ };
+               const void* w3 = nullptr; /* fp32 3x3 convs of the "x3" decode mode: weights pre-split into bf16 (hi, lo) pairs */
+               const void* wsub = nullptr; const void* wsub3 = nullptr; /* upsampler convs: pre-summed sub-pixel phase weights (+ x3 split) */ };
 struct NormW { const float* g = nullptr; const float* b = nullptr; };
 struct ResnetW { NormW n1, n2; ConvW c1, c2, sc; bool has_sc = false; int cin = 0, cout = 0; };
 struct AttnW { NormW gn; ConvW q, k, v, o; };

@@ -56,7 +56,8 @@ struct Run {
   int generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, int n_new, const float* actions, int act_T, int ctx,
                const float* uniforms, int top_k, int64_t* ids_out, float* reward_out, bool reuse_kv = false,
                const void* embeds = nullptr, int64_t* new_ids_out = nullptr, void* hidden_out = nullptr,
-               bool force_sdf = false /* every 17th new token is the forced sdf even without actions (generate_without_action) */);
+               bool force_sdf = false /* every 17th new token is the forced sdf even without actions (generate_without_action) */,
+               int group = 1 /* > 1: shared-context rollout, `prompt` holds one row per group of `group` consecutive trajectories */);
 
   // ---- measurement
   void prof_begin(DType dt, double flops, double bytes, int base = 0);   // base 0: igemm classes, 2: conv3x3 classes

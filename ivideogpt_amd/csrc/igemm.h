@@ -48,6 +48,11 @@ struct IgemmArgs {
   // conv3x3.hip, fp32 tensors only: the weights pre-split into bf16 (hi, lo) pairs in the kernel's slot layout (packing.py pack_x3;
   // same bytes per row as W) -- selects the split-bf16 ("x3") arithmetic of the 1e-3-compliant decode mode.  null: off
   const void* W_x3 = nullptr;
+  // conv3x3.hip, ups = 1 only: the upsampling convolution's weights pre-summed per output-pixel parity for the SUB-PIXEL form
+  // (packing.py pack_subpixel: [4 phases][N][4 taps x Cin], element type of X; W_sub_x3: the same pre-split for the x3 arithmetic).
+  // null: nine taps over the upsampled grid
+  const void* W_sub = nullptr;
+  const void* W_sub_x3 = nullptr;
   // igemm.hip, fp32 tensors only: split-bf16 arithmetic with both operands split in registers (no pre-split weights needed)
   bool x3 = false;
   // batch z = (z0 * nb1 + z1) * nb2 + z2 ; element strides per operand
@@ -61,6 +66,7 @@ int launch_igemm(const IgemmArgs& a, DType dtype, hipStream_t stream);
 int launch_gemm256(const IgemmArgs& a, DType dtype, hipStream_t stream);
 // LDS-halo 3x3 stride-1 kernel (conv3x3.hip); returns -1 when the shape is not covered (use launch_igemm then)
 int launch_conv3x3(const IgemmArgs& a, DType dtype, hipStream_t stream);
+long long conv3x3_subpixel_launches();   // conv3x3.hip: upsampling convolutions launched in sub-pixel form since load (test hook)
 long long decode_gemm_launches(int generation);   // dgemm.hip: decode GEMMs the dispatcher sent to generation 3 / 2 since load (test hook)
 // upper bound of the GroupNorm statistics chunks a conv3x3 launch with this output geometry writes per image
 int conv3x3_gn_chunks_bound(int Hout, int Wout, int N);

@@ -573,11 +573,20 @@ __device__ __forceinline__ float group_sum(float d, int lpk) {
 // the lane-group reductions, the group counts and the row strides are constants instead of chains of scalar branches per chunk
 // (Two value blocks in flight across the softmax statistics were built and measured slower in round 3 -- 64.3 vs 61.2 ms of
 // attention per step, profiles/r03_attn_pre2_ab.txt: one block per workgroup already keeps 25 MB in flight chip-wide -- removed.)
-template <typename T, bool NT, int HD>
+// SHARED (round 6, shared-context rollouts: ivg_generate_shared): the G rows of a group were given ONE prompt -- predict.py's
+// repeat_times samples of a clip, train_gpt.generate_multiple_times, VP2's candidate action sequences over the same two frames.  The
+// prompt was prefilled once per group and its K / V rows [0, P) live ONCE, in cache row `slot = (b - row0) / G` of the chunk (the rows
+// a prefill of the group's prompt wrote); a trajectory's own rows -- positions >= P: the prompt's last token, which carries the row's
+// action, and everything generated -- live in its own cache row b.  The two position ranges never overlap, so no second buffer
+// exists: a key row t is read from the group's cache row when t < P and from the trajectory's otherwise.  The same arithmetic in the
+// same order as the un-shared kernel on the same bytes; the prefix rows use default-policy loads (the other rows of the group ask for
+// the same lines: they are served from L2 / Infinity Cache instead of HBM).
+template <typename T, bool NT, int HD, bool SHARED = false>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ qkv, T* __restrict__ kc, T* __restrict__ vc,
                                                           T* __restrict__ out, const float* __restrict__ cosT,
                                                           const float* __restrict__ sinT, int heads, int hd_arg, int Lmax,
-                                                          const StepState* __restrict__ state, unsigned long long* prof) {
+                                                          const StepState* __restrict__ state, unsigned long long* prof,
+                                                          int sh_P = 0, int sh_G = 1, int sh_row0 = 0) {
   constexpr int VEC = Traits<T>::VEC;
   const int hd = HD > 0 ? HD : hd_arg;
   constexpr int UNR = 8;   // 16-byte loads in flight per lane: 3 workgroups x 256 lanes x 8 x 16 B = 96 KiB per CU
@@ -602,6 +611,9 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   const float scale = rsqrtf((float)hd);
   T* kb = kc + ((long)b * heads + h) * Lmax * hd;
   T* vb = vc + ((long)b * heads + h) * Lmax * hd;
+  // SHARED: byte distance from this trajectory's head base to its group's (the prefix rows t < sh_P are read there); 0 otherwise
+  long sh_delta = 0;
+  if constexpr (SHARED) sh_delta = ((long)((b - sh_row0) / sh_G) - b) * heads * Lmax * hd * (long)sizeof(T);
   const int step = gpb * UNR;
   // rows beyond the cached keys are not requested (on average half of the last block of 256: re-reading a clamped row instead
   // measured +1 us per launch); 32-bit byte offsets from the (wave-uniform) head base
@@ -611,8 +623,10 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int t = t0 + u * gpb + grp;
-      const Chunk16* src = (const Chunk16*)(bb + ((unsigned)(t * hd) * (unsigned)sizeof(T) + lane_off));
-      dst[u] = t < pos ? (NT ? __builtin_nontemporal_load(src) : *src) : Chunk16{0u, 0u, 0u, 0u};
+      const char* rb = bb;
+      if constexpr (SHARED) rb = t < sh_P ? bb + sh_delta : bb;
+      const Chunk16* src = (const Chunk16*)(rb + ((unsigned)(t * hd) * (unsigned)sizeof(T) + lane_off));
+      dst[u] = t < pos ? ((NT && !SHARED) ? __builtin_nontemporal_load(src) : *src) : Chunk16{0u, 0u, 0u, 0u};
     }
   };
   Chunk16 cur[UNR], nxt[UNR];
@@ -736,7 +750,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
 }
 
 int launch_decode_attn(const void* qkv, void* kc, void* vc, void* out, const float* cosT, const float* sinT, int B, int heads, int hd,
-                       int Lmax, const StepState* state, unsigned long long* prof, DType dt, hipStream_t st) {
+                       int Lmax, const StepState* state, unsigned long long* prof, DType dt, hipStream_t st, int sh_P, int sh_G, int sh_row0) {
   const int vec = dt == BF16 ? 8 : 4;
   if (hd % vec != 0 || hd > 256 || 256 % (hd / vec) != 0 || (hd & 1)) return (int)hipErrorInvalidValue;
   const int gpb = 256 / (hd / vec);
@@ -744,7 +758,16 @@ int launch_decode_attn(const void* qkv, void* kc, void* vc, void* out, const flo
   dim3 g(B * heads);
   // non-temporal cache-row loads (bf16): 5.57 -> 6.28 TB/s on a pure stream, 203 -> 191 ms per rollout
 #define IVG_DA(T, NTv, HDv) \
-  hipLaunchKernelGGL((decode_attn_kernel<T, NTv, HDv>), g, dim3(256), smem, st, (const T*)qkv, (T*)kc, (T*)vc, (T*)out, cosT, sinT, heads, hd, Lmax, state, prof)
+  hipLaunchKernelGGL((decode_attn_kernel<T, NTv, HDv>), g, dim3(256), smem, st, (const T*)qkv, (T*)kc, (T*)vc, (T*)out, cosT, sinT, heads, hd, Lmax, state, prof, 0, 1, 0)
+  if (sh_G > 1) {   // shared-context rollout: prefix rows from the group's cache row
+    if (sh_P < 0 || sh_row0 > 0) return (int)hipErrorInvalidValue;
+#define IVG_DAS(T, NTv, HDv) \
+  hipLaunchKernelGGL((decode_attn_kernel<T, NTv, HDv, true>), g, dim3(256), smem, st, (const T*)qkv, (T*)kc, (T*)vc, (T*)out, cosT, sinT, heads, hd, Lmax, state, prof, sh_P, sh_G, sh_row0)
+    if (dt == BF16) { if (hd == 64) IVG_DAS(bf16_t, true, 64); else IVG_DAS(bf16_t, true, 0); }
+    else { if (hd == 64) IVG_DAS(float, false, 64); else IVG_DAS(float, false, 0); }
+#undef IVG_DAS
+    return (int)hipGetLastError();
+  }
   if (dt == BF16) { if (hd == 64) IVG_DA(bf16_t, true, 64); else IVG_DA(bf16_t, true, 0); }
   else { if (hd == 64) IVG_DA(float, false, 64); else IVG_DA(float, false, 0); }
 #undef IVG_DA
@@ -801,6 +824,10 @@ __global__ __launch_bounds__(256) void sample_embed_kernel(SampleArgs a) {
   long tok = 0;
   if (forced) {
     tok = a.forced_token;
+  } else if (j == 0) {
+    // step 0 only ever FEEDS the prompt's last token (kept-cache and shared-context rollouts: the cache holds positions [0, L0 - 1)):
+    // nothing is decided, the token is read back from the id row (the store below rewrites it with itself)
+    tok = a.ids_out[(long)b * a.ids_stride + a.L0 - 1];
   } else {
     const float* src = a.logits + (long)b * V;
     if ((V & 1) == 0 && (((uintptr_t)src) & 7) == 0) {
@@ -1102,6 +1129,20 @@ __global__ void state_set_kernel(StepState* s, int pos, int j) { s->pos = pos; s
 
 int launch_state_set(StepState* state, int pos, int j, hipStream_t st) {
   hipLaunchKernelGGL(state_set_kernel, dim3(1), dim3(1), 0, st, state, pos, j);
+  return (int)hipGetLastError();
+}
+
+// ids[r][0 .. L) = prompts[(b0 + r) / G][0 .. L): every trajectory of a group starts from a copy of its group's prompt
+__global__ void expand_prompt_rows_kernel(const int64_t* __restrict__ prompts, long pstride, int64_t* __restrict__ ids, long ids_ld, int L,
+                                          int G, int b0) {
+  const int r = blockIdx.y;
+  const int64_t* src = prompts + (long)((b0 + r) / G) * pstride;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < L; c += gridDim.x * blockDim.x) ids[(long)r * ids_ld + c] = src[c];
+}
+
+int launch_expand_prompt_rows(const int64_t* prompts, long pstride, int64_t* ids, long ids_ld, int rows, int L, int G, int b0, hipStream_t st) {
+  if (rows <= 0 || L <= 0) return 0;
+  hipLaunchKernelGGL(expand_prompt_rows_kernel, dim3((unsigned)((L + 255) / 256), (unsigned)rows), dim3(256), 0, st, prompts, pstride, ids, ids_ld, L, G, b0);
   return (int)hipGetLastError();
 }
 

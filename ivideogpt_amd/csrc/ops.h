@@ -73,8 +73,12 @@ bool xattn_covers(int P, int kv, int C, int nh, DType dt);   // pure predicate (
 // prof (nullable): [IVG_ATTN_PROF_SLOTS][Lmax starts | Lmax ends] wall-clock stamps (100 MHz) of the launch at each cache
 // position; workgroups spread over the slots so the atomics do not serialise on one address
 #define IVG_ATTN_PROF_SLOTS 32
+// sh_G > 1 (shared-context rollout): chunk row b belongs to group slot (b - sh_row0) / sh_G (sh_row0 <= 0); key rows t < sh_P are read
+// from cache row `slot` (where the prefill of the group's prompt wrote them), rows t >= sh_P from the trajectory's own cache row b
 int launch_decode_attn(const void* qkv, void* kc, void* vc, void* out, const float* cosT, const float* sinT, int B, int heads, int hd,
-                       int Lmax, const StepState* state, unsigned long long* prof, DType dt, hipStream_t st);
+                       int Lmax, const StepState* state, unsigned long long* prof, DType dt, hipStream_t st, int sh_P = 0, int sh_G = 1,
+                       int sh_row0 = 0);
+int launch_expand_prompt_rows(const int64_t* prompts, long pstride, int64_t* ids, long ids_ld, int rows, int L, int G, int b0, hipStream_t st);
 // token decision + embedding of the decided token (+ action embedding on forced sdf slots) + state advance
 struct SampleArgs {
   const float* logits; int V;            // [B][V] fp32 (row stride V)

@@ -51,6 +51,7 @@ int Run::conv(DType dt, const void* X, int N, int H, int W, const ConvW& c, void
   if (out_stats && out_stats->part && gn_fuse_enabled()) { a.gn_part = out_stats->part; a.gn_groups = e->cfg.norm_num_groups; }
   a.gn_in_coef = in_coef;
   if (dt == F32 && x3 && sw().x3) { a.x3 = true; a.W_x3 = c.w3; }   // split-bf16 arithmetic (IVG_F32X3 decode; IVG_X3=0: f32-input MFMAs)
+  if (ups) { a.W_sub = c.wsub; a.W_sub_x3 = a.W_x3 ? c.wsub3 : nullptr; }   // upsampling convolutions in sub-pixel form (conv3x3.hip SUBPIX)
   const double flops = 2.0 * N * Ho * Wo * (double)c.cout * k * k * c.cin;
   const double bytes = (double)esz(dt) * ((double)N * H * W * c.cin + (double)c.cout * k * k * c.cin) + (double)(out_f32 ? 4 : esz(dt)) * N * Ho * Wo * c.cout;
   if (k == 3 && stride == 1) {  // FLOP majority: LDS-halo kernel; shapes it does not cover fall through to the implicit GEMM

@@ -31,6 +31,9 @@ struct GenBuf {  // persistent decode-step buffers (fixed addresses so the captu
   int64_t* ids; float* uni; char* act_emb; int Bc, ids_ld;
   float* last_act;   // [Bc][max_frames][action_dim]: the action table of the call that built the kept KV cache
   int* flag;         // mismatch counter of the prefix verification
+  // shared-context rollout (ivg_generate_shared; set per chunk by Run::generate): rows of the chunk in groups of sh_G sharing the cache
+  // rows of their prompt -- see decode_attn_kernel SHARED.  sh_G = 1: off
+  int sh_P = 0, sh_G = 1, sh_row0 = 0;
 };
 
 static int gen_chunk(const ivg_engine* e) { return std::min(e->cfg.max_batch, 128); }
@@ -268,7 +271,8 @@ static int step_body(ivg_engine* e, hipStream_t st, const GenBuf& g, int B, cons
     gprof(cur[0], 4 * l + 0);
     CK(launch_skinny(cur[0], dt, st));
     CK(launch_decode_attn(qkv, kc_ptr(e, l, 0) + kv_off, kc_ptr(e, l, 1) + kv_off, attn, e->rope_cos, e->rope_sin, B, e->heads, e->hd,
-                          e->Lmax, state, e->attn_prof_on ? e->attn_prof + (size_t)l * IVG_ATTN_PROF_SLOTS * 2 * e->Lmax : nullptr, dt, st));
+                          e->Lmax, state, e->attn_prof_on ? e->attn_prof + (size_t)l * IVG_ATTN_PROF_SLOTS * 2 * e->Lmax : nullptr, dt, st,
+                          g.sh_P, g.sh_G, g.sh_row0));
     gprof(cur[1], 4 * l + 1);
     CK(launch_skinny(cur[1], dt, st));
     gprof(cur[2], 4 * l + 2);
@@ -287,9 +291,14 @@ static int step_body(ivg_engine* e, hipStream_t st, const GenBuf& g, int B, cons
   return 0;
 }
 
+// group > 1 (ivg_generate_shared): `prompt` holds one row per GROUP of `group` consecutive trajectories (B = groups x group rows of
+// actions / uniforms / ids_out).  Per chunk: the prompts of the groups the chunk's rows belong to are prefilled ONCE each -- positions
+// [0, L0 - 1), into cache rows 0 .. n_groups-1 -- and every trajectory then feeds the prompt's last token itself (step j = 0, exactly the
+// kept-cache entry of the step-wise callers: that slot carries the row's own action), appending from position L0 - 1 on in its own
+// cache row; the decode attention reads key rows < L0 - 1 from the group's row (decode_attn_kernel SHARED).
 int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, int n_new, const float* actions, int act_T, int ctx,
                   const float* uniforms, int top_k, int64_t* ids_out, float* reward_out, bool reuse_kv, const void* embeds,
-                  int64_t* new_ids_out, void* hidden_out, bool force_sdf) {
+                  int64_t* new_ids_out, void* hidden_out, bool force_sdf, int group) {
   const ivg_config& c = e->cfg;
   const DType dt = e->llm_dt;
   const int H = c.hidden_size, V = c.vocab_size;
@@ -297,7 +306,9 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
   size_t tot = 0;
   gen_layout(e, g, e->gen_buf, &tot);
   const long Ltot = (long)L0 + n_new;
+  const bool shared = group > 1;
   if (planning) {
+    if (shared) return prefill(nullptr, 0, std::min((std::min(B, g.Bc) + group - 1) / group + 1, std::min(B, g.Bc)), L0 - 1, nullptr, 0, ctx, false, nullptr, nullptr, nullptr);
     return reuse_kv ? 0 : prefill(nullptr, 0, std::min(B, g.Bc), L0, nullptr, 0, ctx, false, nullptr, nullptr, nullptr);
   }
   e->kv_len = 0; e->kv_B = 0;   // set again once every launch of this call is queued
@@ -317,7 +328,12 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
       CK((int)hipMemsetAsync(e->attn_prof, 0, (size_t)c.num_layers * IVG_ATTN_PROF_SLOTS * 2 * e->Lmax * 8, st));
       e->attn_prof_B = Bc;
     }
-    if (!embeds)
+    if (shared) {   // every trajectory starts from a copy of its group's prompt; groups g_lo .. g_hi have rows in this chunk
+      const int g_lo = b0 / group, g_hi = (b0 + Bc - 1) / group;
+      g.sh_P = L0 - 1; g.sh_G = group; g.sh_row0 = g_lo * group - b0;
+      CK(launch_expand_prompt_rows(prompt, prompt_stride, g.ids, g.ids_ld, Bc, L0, group, b0, st));
+      IVG_TRY(prefill(prompt + (long)g_lo * prompt_stride, prompt_stride, g_hi - g_lo + 1, L0 - 1, nullptr, 0, ctx, false, nullptr, nullptr, nullptr));
+    } else if (!embeds)
       CK((int)hipMemcpy2DAsync(g.ids, (size_t)g.ids_ld * 8, prompt + (long)b0 * prompt_stride, (size_t)prompt_stride * 8, (size_t)L0 * 8, Bc,
                                hipMemcpyDeviceToDevice, st));
     if (uniforms)
@@ -327,7 +343,7 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
       CK(launch_action_embed(actions + (long)b0 * act_T * c.action_dim, e->act_w, e->act_b, g.act_emb, dt, Bc * act_T, c.action_dim, H, st));
       if (B <= g.Bc) CK((int)hipMemcpyAsync(g.last_act, actions, (size_t)B * act_T * c.action_dim * 4, hipMemcpyDeviceToDevice, st));
     }
-    if (!reuse_kv) IVG_TRY(prefill(g.ids, g.ids_ld, Bc, L0, actions ? g.act_emb : nullptr, act_T, ctx, true, nullptr, g.logits, g.x, embeds));
+    if (!reuse_kv && !shared) IVG_TRY(prefill(g.ids, g.ids_ld, Bc, L0, actions ? g.act_emb : nullptr, act_T, ctx, true, nullptr, g.logits, g.x, embeds));
     if (embeds) {   // keep what the cache is (being) built from: the whole prompt after a prefill, its last row on the kept-cache path
       const int p0 = reuse_kv ? L0 - 1 : 0;
       CK((int)hipMemcpy2DAsync(e->emb_snap + (size_t)p0 * H * es, (size_t)e->Lmax * H * es, (const char*)embeds + (size_t)p0 * H * es,
@@ -339,7 +355,8 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
     // reuse_kv: the cache already holds positions [0, L0 - 1); the step counter starts at j = 0, whose "decision" is the
     // forced sdf the prompt ends with (0 % 17 == 0): the sampler re-embeds it with the new action and the forward pass of
     // that step appends position L0 - 1 and yields the logits of new token 1 -- exactly what the prefill would have left
-    CK(launch_state_set(g.state, reuse_kv ? L0 - 1 : L0, reuse_kv ? 0 : 1, st));
+    const bool feed_last = reuse_kv || shared;   // the cache holds [0, L0 - 1): step j = 0 feeds the prompt's last token
+    CK(launch_state_set(g.state, feed_last ? L0 - 1 : L0, feed_last ? 0 : 1, st));
     SampleArgs sa{};
     sa.logits = g.logits; sa.V = V;
     sa.uniforms = uniforms ? g.uni : nullptr; sa.n_uni = g.ids_ld;
@@ -358,7 +375,8 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
     const std::string key = std::to_string(Bc) + ":" + std::to_string(t_bits) + ":" + std::to_string(e->decode_lds_kb) + ":" + std::to_string(switches_generation()) +
                             ":" + (uniforms ? "s" : "g") + ":" + std::to_string(top_k) + ":" +
                             std::to_string(sa.forced_period) + ":" + std::to_string(ctx) + ":" + std::to_string(act_T) + ":" +
-                            std::to_string(L0) + (e->attn_prof_on ? ":p" : "") + (e->gemm_prof_on ? ":q" : "");   // (the same step graph serves both entry modes)
+                            std::to_string(L0) + (e->attn_prof_on ? ":p" : "") + (e->gemm_prof_on ? ":q" : "") +   // (the same step graph serves both entry modes)
+                            (shared ? ":sh" + std::to_string(group) + ":" + std::to_string(g.sh_row0) : "");
     // reward head: reads the residual stream left by the LAST forward pass, i.e. before the final decide-only step
     // overwrites it with the embedding of the last token (mbrl/video_predictor.py:311-313: hidden state of the last step)
     auto reward = [&]() -> int {
@@ -372,7 +390,7 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
       return 0;
     };
     int j = 1;
-    if (reuse_kv) IVG_TRY(step_body(e, st, g, Bc, sa, true, embeds != nullptr));   // j = 0: feed the prompt's last token
+    if (feed_last) IVG_TRY(step_body(e, st, g, Bc, sa, true, embeds != nullptr));   // j = 0: feed the prompt's last token
     if (n_new == 1) IVG_TRY(reward());
     if (n_new >= 1) { IVG_TRY(step_body(e, st, g, Bc, sa, j < n_new)); ++j; }
     // the step sequence is position-independent (all step-dependent scalars live in StepState): it is captured once as a graph of
@@ -438,7 +456,7 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
                                hipMemcpyDeviceToDevice, st));
     }
   }
-  if (B <= g.Bc) {   // the last new token is decided but never fed
+  if (B <= g.Bc && !shared) {   // the last new token is decided but never fed (a shared-context cache is not a per-trajectory cache: never kept)
     e->kv_len = L0 + n_new - 1; e->kv_B = B;
     e->snap_valid = embeds != nullptr; e->ids_valid = embeds == nullptr;
     e->last_act_T = actions ? act_T : 0;

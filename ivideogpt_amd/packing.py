@@ -55,6 +55,27 @@ def pack_x3(w):
     return torch.stack([hi.view(n, k // 4, 4), lo.view(n, k // 4, 4)], 2).reshape(n, 2 * k).contiguous()
 
 
+def pack_subpixel(w):
+    """Upsampler conv weight fp32 [Cout, Cin, 3, 3] -> fp32 [4 * Cout, 4 * Cin]: the SUB-PIXEL form of ``conv3x3(nearest_x2(x))``
+    (diffusers Upsample2D, /root/reference/ivideogpt/vq_model/vae.py:271-284 builds it through get_up_block).  Output pixel
+    (2 iy + py, 2 ix + px) reads upsampled rows 2 iy + py - 1 .. + 1, i.e. input rows {iy - 1, iy, iy} for py = 0 and {iy, iy, iy + 1}
+    for py = 1: the three row taps collapse to two, {W0, W1 + W2} resp. {W0 + W1, W2}; the columns alike.  Row block ``phase = 2 py +
+    px`` holds that phase's 2 x 2 convolution as [Cout][(kh2, kw2, c)] (K contiguous like every packed conv), where tap (kh2, kw2)
+    reads input pixel (iy + py + kh2 - 1, ix + px + kw2 - 1).  Summed in fp32 (rounded to the storage type by the caller)."""
+    w = w.float()
+    rows = ((w[:, :, 0], w[:, :, 1] + w[:, :, 2]), (w[:, :, 0] + w[:, :, 1], w[:, :, 2]))      # [py][kh2] -> [Cout, Cin, 3 (kw)]
+    out = []
+    for py in range(2):
+        for px in range(2):
+            taps = []
+            for kh2 in range(2):
+                r = rows[py][kh2]
+                cols = (r[:, :, 0], r[:, :, 1] + r[:, :, 2]) if px == 0 else (r[:, :, 0] + r[:, :, 1], r[:, :, 2])
+                taps += [cols[0], cols[1]]                                               # (kh2, kw2) order, each [Cout, Cin]
+            out.append(torch.stack(taps, 1).reshape(w.shape[0], -1))                        # [Cout, 4 * Cin]
+    return torch.cat(out, 0).contiguous()
+
+
 def pack_tokenizer(sd, cfg, device, enc_code, dec_code, dec_x3=False):
     """DF state dict of CompressiveVQModel -> {name: device tensor} for ivg_create.  dec_x3: the 3x3 convolutions of the two
     decoders also get their weights pre-split for the split-bf16 kernels (``<name>.x3``, beside the fp32 matrix other shapes use)."""
@@ -72,6 +93,11 @@ def pack_tokenizer(sd, cfg, device, enc_code, dec_code, dec_x3=False):
             out[k] = _conv(v, dt)
             if dec_x3 and top in ("decoder", "cond_decoder") and v.shape[2] == 3 and v.shape[1] % 16 == 0:
                 out[k + ".x3"] = pack_x3(out[k])
+            if top in ("decoder", "cond_decoder") and ".upsamplers." in k and v.shape[2] == 3:   # sub-pixel phase weights (conv3x3.hip SUBPIX)
+                sub = pack_subpixel(v)
+                out[k + ".subpix"] = sub.to(dt).contiguous()
+                if dec_x3 and v.shape[1] % 16 == 0:
+                    out[k + ".subpix.x3"] = pack_x3(sub)
         elif v.dim() == 2:
             out[k] = v.to(dt).contiguous()                # Linear / MHA in_proj / out_proj; quant_linear is already (ph, pw, c)
         else:

@@ -133,6 +133,76 @@ def test_conv3x3_halo_kernel(dt, H, Cin, Cout, ups, res):
     assert rel_err(Y.float().permute(0, 3, 1, 2), ref) < TOL[dt]
 
 
+@pytest.mark.parametrize("dt", ["fp32", "bf16", "x3"])
+@pytest.mark.parametrize("H,Cin,Cout,stats", [(16, 512, 512, 1), (32, 256, 256, 1), (32, 128, 64, 0), (16, 160, 64, 1), (64, 32, 128, 0),
+                                              (16, 64, 192, 1), (32, 96, 128, 0), (64, 128, 128, 1)])
+def test_upsampling_conv_subpixel_form(dt, H, Cin, Cout, stats, switches):
+    """Round 6: conv3x3(nearest_x2(x)) as four 2x2 phase convolutions over the low-resolution input with weights pre-summed per
+    output-pixel parity (packing.pack_subpixel; diffusers Upsample2D, vae.py:271-284): 2.25 x fewer multiplies.  Against fp64
+    ``conv2d(interpolate(x, 2, 'nearest'), w, padding=1)`` on the same inputs: both tile shapes (16 x 16 / 8 x 32 over the INPUT), one to
+    sixteen channel chunks incl. odd counts, ragged N (192), one / two / four N tiles, bias; every output pixel written exactly once
+    (NaN-filled output); the GroupNorm statistics of the epilogue (per image and group, summed over the 4 x tiles chunks); bf16, fp32
+    (f32-input MFMAs) and the split-bf16 arithmetic.  And the nine-tap kernel (IVG_SUBPIXEL=0) gives the same tensor up to the
+    rounding of the pre-summed weights."""
+    from ivideogpt_amd.packing import pack_subpixel, pack_x3
+    L, l = lib()
+    x3 = dt == "x3"
+    sdt = "fp32" if x3 else dt
+    if x3 and Cin % 16:
+        pytest.skip("x3 needs Cin % 16 == 0")
+    g = torch.Generator().manual_seed(H + Cin + Cout + 5)
+    Nb, groups = 3, 32
+    x = q(torch.randn(Nb, Cin, H, H, generator=g) * 1.3 + 0.2, sdt)
+    w = q(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5, sdt)
+    b = torch.randn(Cout, generator=g)
+    Ho = 2 * H
+    ref = F.conv2d(F.interpolate(x.double(), scale_factor=2.0, mode="nearest"), w.double(), b.double(), padding=1)
+    X = x.permute(0, 2, 3, 1).contiguous().to(DEV, tdt(sdt))
+    Wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(DEV, tdt(sdt))
+    sub32 = pack_subpixel(w)                                   # fp32 [4 Cout, 4 Cin], summed in fp32
+    Wsub = sub32.to(DEV, tdt(sdt)).contiguous()
+    W3 = pack_x3(Wp) if x3 else None
+    Wsub3 = pack_x3(sub32.to(DEV)) if x3 else None
+    bd = b.to(DEV)
+    outs = []
+    for sub in (1, 0):
+        switches(IVG_SUBPIXEL=str(sub))
+        Y = torch.full((Nb, Ho, Ho, Cout), float("nan"), device=DEV, dtype=tdt(sdt))
+        a = L.IvgIgemmArgs()
+        a.X, a.W, a.Y, a.R, a.bias = X.data_ptr(), Wp.data_ptr(), Y.data_ptr(), None, bd.data_ptr()
+        for k, v in dict(Nimg=Nb, Hin=H, Win=H, Cin=Cin, ldx=Cin, Hout=Ho, Wout=Ho, KH=3, KW=3, stride=1, pad=1, ups=1, N=Cout, ldw=9 * Cin,
+                         c_img=Ho * Ho * Cout, c_pix=Cout, c_ch=1, c_grp=1, c_grp_stride=0, flags=1, alpha=1.0, nb0=1, nb1=1, nb2=1).items():
+            setattr(a, k, v)
+        bound = ((Ho * Ho + 255) // 256) * ((Cout + 63) // 64)
+        part = torch.full((Nb * bound * groups * 2,), float("nan"), dtype=torch.float64, device=DEV) if stats and Cout % groups == 0 else None
+        n0 = l.ivg_debug_counter(b"conv3x3_subpixel")
+        if sub:
+            rc = l.ivg_op_conv_subpixel(C.byref(a), code(sdt), P(Wsub), P(W3), P(Wsub3), P(part), groups, stream())
+            assert rc >= 0, f"ivg_op_conv_subpixel rc={rc}"
+            assert l.ivg_debug_counter(b"conv3x3_subpixel") == n0 + 1
+            if part is not None:
+                assert 0 < rc <= bound
+                torch.cuda.synchronize()
+                st = part[:Nb * rc * groups * 2].view(Nb, rc, groups, 2).sum(1).cpu()
+                sv = Y.float().permute(0, 3, 1, 2).cpu().double().reshape(Nb, groups, -1)
+                assert ((st[..., 0] - sv.sum(-1)).abs() / (sv.abs().sum(-1) + 1e-9)).max().item() < 1e-5
+                assert ((st[..., 1] - (sv * sv).sum(-1)).abs() / (sv * sv).sum(-1)).max().item() < 1e-5
+        else:
+            if x3:
+                ws = torch.empty(Nb * (((H * H + 1023) // 1024) * groups * 16 + Cin * 8) + 256, dtype=torch.uint8, device=DEV)
+                assert l.ivg_op_conv_x3(C.byref(a), P(W3), groups, None, None, 1e-6, P(ws), stream()) == 0
+            else:
+                assert l.ivg_op_igemm(C.byref(a), code(sdt), stream()) == 0
+            assert l.ivg_debug_counter(b"conv3x3_subpixel") == n0, "IVG_SUBPIXEL=0 must take the nine-tap kernel"
+        torch.cuda.synchronize()
+        assert torch.isfinite(Y.float()).all(), "an output pixel was not written"
+        e = rel_err(Y.float().permute(0, 3, 1, 2), ref)
+        assert e < (2e-5 if sdt == "fp32" else TOL["bf16"]), (sub, e)
+        outs.append(Y.float())
+    d = (outs[0] - outs[1]).abs().max().item() / ref.abs().max().item()
+    assert d < (4e-5 if sdt == "fp32" else 2e-2), f"sub-pixel vs nine-tap kernel: {d:.3e}"
+
+
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 def test_conv_out_planar_video(dt):
     """Cout = 3 written straight into a planar (B, T, 3, H, W) fp32 clip at frame offsets (decoder tail)."""

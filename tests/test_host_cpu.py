@@ -490,3 +490,28 @@ def test_round5_host_fixes_policy_kwargs_gate_and_scratch_cache():
     t.join(5)
     assert got.is_set(), "the gate's lock must be free again after a failed __enter__"
     assert metrics._WS_MAX == 16 and isinstance(metrics._WS, dict)
+
+
+def test_pack_subpixel_is_the_upsampled_convolution():
+    """packing.pack_subpixel (round 6): conv3x3(nearest_x2(x), padding 1) == the four 2 x 2 phase convolutions over x it packs -- phase
+    (py, px) writes output pixels (2 iy + py, 2 ix + px), tap (kh2, kw2) reads input pixel (iy + py + kh2 - 1, ix + px + kw2 - 1), zero
+    outside the image -- checked in fp64 with plain torch, incl. the borders (where the upsampled image's zero padding must coincide
+    with the input's) and the [4 Cout, 4 Cin] layout with K ordered (kh2, kw2, c) the kernel reads (diffusers Upsample2D as built by
+    /root/reference/ivideogpt/vq_model/vae.py:271-284)."""
+    import torch.nn.functional as F
+    from ivideogpt_amd.packing import pack_subpixel
+    g = torch.Generator().manual_seed(3)
+    Cout, Cin, H, W = 5, 4, 6, 7
+    w = torch.randn(Cout, Cin, 3, 3, generator=g, dtype=torch.float64)
+    x = torch.randn(2, Cin, H, W, generator=g, dtype=torch.float64)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, padding=1)
+    sub = pack_subpixel(w.float()).double()        # the sums are formed in fp32 by design: compare with fp32-sized tolerance
+    assert sub.shape == (4 * Cout, 4 * Cin)
+    out = torch.zeros_like(ref)
+    xp = F.pad(x, (1, 1, 1, 1))
+    for py in range(2):
+        for px in range(2):
+            wk = sub[(2 * py + px) * Cout:(2 * py + px + 1) * Cout].view(Cout, 2, 2, Cin).permute(0, 3, 1, 2)   # [Cout, Cin, kh2, kw2]
+            # input rows iy + py + kh2 - 1 = padded rows iy + py + kh2: a 2 x 2 valid convolution over the padded image shifted by (py, px)
+            out[:, :, py::2, px::2] = F.conv2d(xp[:, :, py:py + H + 1, px:px + W + 1], wk)
+    assert (out - ref).abs().max().item() < 1e-5 * ref.abs().max().item()

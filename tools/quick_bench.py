@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--dec", default="bf16")
     ap.add_argument("--llm", default="bf16")
     ap.add_argument("--enc", default="fp32")
+    ap.add_argument("--decode-only", action="store_true", help="time detokenize alone on random valid token ids (no rollout)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     t0 = time.time()
@@ -32,6 +33,28 @@ def main():
     px = torch.rand(B, T, 3, a.res, a.res, device=dev).to(torch.bfloat16)
     n_new = 17 * F - 1
     res = {}
+    if a.decode_only:
+        g = torch.Generator().manual_seed(1)
+        ids = torch.randint(0, 8192, (B, 257 * ctx - 1 + 17 * F), generator=g)
+        ids[:, 257 * ctx:] += 8192
+        for f in range(ctx):
+            ids[:, 257 * f + 256 if f < ctx - 1 else 257 * ctx - 1] = 16384 if f < ctx - 1 else 16385
+        for f in range(F - 1):
+            ids[:, 257 * ctx + 17 * f + 16] = 16385
+        ids = ids.to(dev)
+        ts = []
+        for it in range(a.iters + 1):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            frames = tok.detokenize(ids, ctx)
+            e1.record()
+            torch.cuda.synchronize()
+            if it:
+                ts.append(e0.elapsed_time(e1))
+        print(json.dumps(dict(decode_ms=sorted(ts)[len(ts) // 2], decode_ms_all=[round(t, 2) for t in ts], batch=B, frames=T, res=a.res, dec=a.dec,
+                              finite=bool(torch.isfinite(frames.float()).all()))))
+        return
     for it in range(a.iters + 1):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         torch.cuda.synchronize()
