@@ -142,6 +142,12 @@ int ivg_detokenize(ivg_engine* e, const int64_t* ids, int B, int F, float* pixel
  * epilogue.  A cache remembers the element type it was filled with; reuse with another one is IVG_ERR_INVALID. */
 int ivg_detokenize_to(ivg_engine* e, const int64_t* ids, int B, int F, void* pixels_out, int pixel_dtype, ivg_cache* cache, int cache_mode,
                       ivg_stream stream);
+/* detokenize for a batch whose rows come in groups of `group_size` consecutive trajectories with the SAME context tokens (the samples of
+ * one clip, predict.py:65-72; VP2's candidates, vp/ivideogpt_interface.py:184-198): ids int64 (n_groups * group_size, 257*ctx - 1 + 17*F),
+ * of which columns [0, 257*ctx - 1) are read from the FIRST row of every group.  The context frames are decoded once per group (and copied
+ * to its other rows), the context decoder's features and the cross-attention K / V projections of the predicted frames exist once per
+ * group.  pixels_out (n_groups * group_size, ctx + F, 3, H, W) in pixel_dtype, as ivg_detokenize_to.  No cache. */
+int ivg_detokenize_shared(ivg_engine* e, const int64_t* ids, int n_groups, int group_size, int F, void* pixels_out, int pixel_dtype, ivg_stream stream);
 /* on != 0: ivg_detokenize writes clamp(frames, 0, 1) -- the post-processing every caller of the reference applies to the decoded
  * clip (inference/predict.py:73, vp/ivideogpt_interface.py:199, train_gpt.py:438) -- from the epilogue of the decoders' last
  * convolution instead of a separate pass over the clip.  Default off: CompressiveVQModel.detokenize returns the raw output. */

@@ -411,6 +411,16 @@ int ivg_detokenize_to(ivg_engine* e, const int64_t* ids, int B, int F, void* pix
   return plan_then_run(e, (hipStream_t)stream, [&](Run& r) { return r.detokenize(ids, B, F, pixels_out, (DType)pixel_dtype, cache, cache ? cache_mode : 0); });
 }
 
+int ivg_detokenize_shared(ivg_engine* e, const int64_t* ids, int n_groups, int group_size, int F, void* pixels_out, int pixel_dtype, ivg_stream stream) {
+  if (!e) return IVG_ERR_INVALID;
+  if (n_groups <= 0 || group_size <= 0) return e->fail(IVG_ERR_INVALID, "detokenize_shared: n_groups and group_size must be positive");
+  const int B = n_groups * group_size;
+  IVG_TRY(check_tok(e, B, e->ctx + F, "detokenize"));
+  if (F < 0) return e->fail(IVG_ERR_INVALID, "detokenize: token count does not match 257*ctx - 1 + 17*F");
+  if (pixel_dtype != IVG_F32 && pixel_dtype != IVG_BF16) return e->fail(IVG_ERR_INVALID, "detokenize: pixels are float32 or bfloat16");
+  return plan_then_run(e, (hipStream_t)stream, [&](Run& r) { return r.detokenize(ids, B, F, pixels_out, (DType)pixel_dtype, nullptr, 0, group_size); });
+}
+
 int ivg_detokenize(ivg_engine* e, const int64_t* ids, int B, int F, float* pixels_out, ivg_cache* cache, int cache_mode, ivg_stream stream) {
   return ivg_detokenize_to(e, ids, B, F, pixels_out, IVG_F32, cache, cache_mode, stream);
 }

@@ -19,6 +19,7 @@ struct Run {
   hipStream_t st;
   bool planning;  // true: only walk the allocation plan (no launches) to size the workspace
   bool x3 = false;   // the entry point running now computes its fp32 matrix products in split-bf16 arithmetic (IVG_F32X3 path)
+  int kv_group = 1;  // decoder_trunk: trajectories per shared context (cross-attention K / V projected once per group; detokenize sets it)
 
   // ---- primitives (tokenizer.cpp)
   int conv(DType dt, const void* X, int N, int H, int W, const ConvW& c, void* Y, int stride, int ups, const void* Rres, int flags,
@@ -43,7 +44,8 @@ struct Run {
   int decoder_trunk(const TrunkW& w, const void* z, int B, int per, int T_total, int t0, std::vector<Feature>* keep,
                     const std::vector<Feature>* cond, void* out_pixels, DType out_dt);
   int tokenize(const void* pixels, DType pix_dt, int B, int T, int64_t* ids, int64_t ids_stride, int64_t* labels, bool ctx_only);
-  int detokenize(const int64_t* ids, int B, int F, void* out_pixels, DType out_dt, ivg_cache* cache, int cache_mode);
+  int detokenize(const int64_t* ids, int B, int F, void* out_pixels, DType out_dt, ivg_cache* cache, int cache_mode,
+                 int group = 1 /* > 1: consecutive rows share their context (decoded / projected once per group) */);
 
   // ---- transformer (transformer.cpp)
   int prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const void* act_emb, int act_T, int ctx, bool all_slots,

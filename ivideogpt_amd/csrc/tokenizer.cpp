@@ -486,10 +486,13 @@ int Run::decoder_trunk(const TrunkW& w, const void* z, int B, int per, int T_tot
           if (s <= c.max_att_resolution) { ++seen; if (seen == (int)k) { fi = i + 2; break; } }
         }
       }
-      IVG_TRY(xatt_project_kv(dt, (*cond)[fi].p, B, x, kp, vp));
+      IVG_TRY(xatt_project_kv(dt, (*cond)[fi].p, B / kv_group, x, kp, vp));   // (shared context: one K / V projection per GROUP)
       Kp.push_back(kp); Vp.push_back(vp);
     }
   }
+  // cross-attention K / V addressing: frame n belongs to trajectory n / per; with kv_group trajectories sharing one context that is
+  // context n / (per * kv_group) -- the same kernel with (B / kv_group) "trajectories" of (per * kv_group) frames
+  const int Bk = B / kv_group, perk = per * kv_group;
   void* a = e->ws.alloc((size_t)N * max_el * esz(dt));
   void* b = e->ws.alloc((size_t)N * max_el * esz(dt));
   size_t st_bytes = 0;   // GroupNorm statistics travel with the activation (see encoder_trunk)
@@ -512,7 +515,7 @@ int Run::decoder_trunk(const TrunkW& w, const void* z, int B, int per, int T_tot
   if (keep && (*keep)[1].p && !planning)
     CK((int)hipMemcpyAsync((*keep)[1].p, a, (size_t)N * side * side * Ctop * esz(dt), hipMemcpyDeviceToDevice, st));
   int k = 0;
-  if (cond) { IVG_TRY(cross_attention(dt, a, B, per, w.xatt[0], Kp[0], Vp[0], b)); std::swap(a, b); std::swap(sa, sb); sa.chunks = 0; k = 1; }
+  if (cond) { IVG_TRY(cross_attention(dt, a, Bk, perk, w.xatt[0], Kp[0], Vp[0], b)); std::swap(a, b); std::swap(sa, sb); sa.chunks = 0; k = 1; }
   for (int i = 0; i < nl; ++i) {
     const int C = c.block_out_channels[nl - 1 - i];
     for (size_t j = 0; j < w.blocks[i].size(); ++j) {
@@ -525,7 +528,7 @@ int Run::decoder_trunk(const TrunkW& w, const void* z, int B, int per, int T_tot
       side *= 2;
     }
     if (cond && side <= c.max_att_resolution) {
-      IVG_TRY(cross_attention(dt, a, B, per, w.xatt[k], Kp[k], Vp[k], b));
+      IVG_TRY(cross_attention(dt, a, Bk, perk, w.xatt[k], Kp[k], Vp[k], b));
       std::swap(a, b); std::swap(sa, sb); sa.chunks = 0;
       ++k;
     }
@@ -570,9 +573,17 @@ int Run::decoder_trunk(const TrunkW& w, const void* z, int B, int per, int T_tot
   return 0;
 }
 
-int Run::detokenize(const int64_t* ids, int B, int F, void* out_pixels, DType out_dt, ivg_cache* cache, int cache_mode) {
+// group > 1 (ivg_detokenize_shared): rows [g * group, (g + 1) * group) of `ids` hold the SAME context tokens (the samples / candidate
+// action sequences of one clip: predict.py:65-72, vp/ivideogpt_interface.py:155-202).  The context frames are then decoded once per
+// GROUP (its first row's tokens) and copied to the group's other rows, the context decoder's features exist once per group, and the
+// predicted frames' cross-attention reads its K / V projections per group -- the reference decodes and projects them per row
+// (compressive_vq_model.py:236-266).
+int Run::detokenize(const int64_t* ids, int B, int F, void* out_pixels, DType out_dt, ivg_cache* cache, int cache_mode, int group) {
   Run& R = *this;
   x3 = e->dec_x3;
+  if (group < 1 || B % group != 0) return e->fail(IVG_ERR_INVALID, "detokenize: the batch is not a whole number of groups");
+  if (group > 1 && cache) return e->fail(IVG_ERR_INVALID, "detokenize: a cache and a shared context cannot be combined");
+  const int NG = B / group;   // contexts to decode
   if (out_dt != F32 && out_dt != e->dec_dt)
     return e->fail(IVG_ERR_INVALID, "detokenize: bfloat16 pixels are written by the bfloat16 decode path only (decode_dtype = IVG_BF16)");
   const size_t psz = out_dt == F32 ? 4 : 2;
@@ -599,7 +610,7 @@ int Run::detokenize(const int64_t* ids, int B, int F, void* out_pixels, DType ou
     size_t fi = 0;
     for (auto& f : feats) {
       if (!f.side) continue;
-      const size_t bytes = (size_t)B * ctx * f.side * f.side * f.C * esz(dt);
+      const size_t bytes = (size_t)NG * ctx * f.side * f.side * f.C * esz(dt);
       if (cache && cache_mode) {
         if (!planning) {
           if (fi >= cache->feat.size()) return e->fail(IVG_ERR_INVALID, "detokenize: cache layout mismatch");
@@ -612,15 +623,21 @@ int Run::detokenize(const int64_t* ids, int B, int F, void* out_pixels, DType ou
     }
   }
   if (!use_cache) {
-    const int N = B * ctx;
+    const int N = NG * ctx;
     void* qc = e->ws.alloc((size_t)N * 256 * dim * esz(dt));
     void* q2 = e->ws.alloc((size_t)N * 256 * lat * esz(dt));
     if (!planning) {
-      TokMap mp{256, ctx, L, 0, 257};
+      TokMap mp{256, ctx, L * group, 0, 257};   // (the first row of every group)
       CK(launch_gather_rows(ids, mp, e->cb_c, qc, dt, N * 256, dim, 0, c.num_vq_embeddings, st));
     }
     IVG_TRY(conv(dt, qc, N, 16, 16, e->post_quant_conv, q2, 1, 0, nullptr, 0, 0));
-    IVG_TRY(decoder_trunk(e->dec, q2, B, ctx, T, 0, &feats, nullptr, out_pixels, out_dt));
+    // (clip stride T * group: context g lands in output row g * group; the group's other rows get copies below)
+    IVG_TRY(decoder_trunk(e->dec, q2, NG, ctx, T * group, 0, &feats, nullptr, out_pixels, out_dt));
+    if (group > 1 && !planning) {
+      const size_t clip = (size_t)T * 3 * res * res * psz, cpart = (size_t)ctx * 3 * res * res * psz;
+      for (int k = 1; k < group; ++k)
+        CK((int)hipMemcpy2DAsync((char*)out_pixels + (size_t)k * clip, clip * group, out_pixels, clip * group, cpart, NG, hipMemcpyDeviceToDevice, st));
+    }
     if (cache && cache_mode == 1 && !planning) {
       // keep the decoded context frames: rows (b, t < ctx) of out_pixels
       CK((int)hipMemcpy2DAsync(cache->ctx_pixels, (size_t)ctx * 3 * res * res * psz, out_pixels, (size_t)T * 3 * res * res * psz,
@@ -644,7 +661,10 @@ int Run::detokenize(const int64_t* ids, int B, int F, void* out_pixels, DType ou
     }
     IVG_TRY(linear(dt, qd, (long)M * 16, e->post_quant_linear, q2, nullptr, 0, 0));
     if (!planning) CK(launch_unpatchify(q2, z, dt, M, 16 / p, lat, p, st));
-    IVG_TRY(decoder_trunk(e->cdec, z, B, F, T, ctx, nullptr, &feats, out_pixels, out_dt));
+    kv_group = group;
+    const int rc = decoder_trunk(e->cdec, z, B, F, T, ctx, nullptr, &feats, out_pixels, out_dt);
+    kv_group = 1;
+    IVG_TRY(rc);
   }
   e->ws.reset(m);
   return 0;

@@ -160,6 +160,16 @@ class Engine:
                        "detokenize")
             ids.record_stream(self._run); out.record_stream(self._run)
 
+    def detokenize_shared(self, ids, group_size, F, out, clamp=False):
+        """ivg_detokenize_shared: rows of ``ids`` / ``out`` in groups of ``group_size`` consecutive trajectories with the same context tokens."""
+        if clamp != self._clamp_out:
+            self.check(self.lib.ivg_set_output_clamp(self.h, int(bool(clamp))), "set_output_clamp")
+            self._clamp_out = bool(clamp)
+        with self.stream() as s:
+            self.check(self.lib.ivg_detokenize_shared(self.h, _ptr(ids), ids.shape[0] // int(group_size), int(group_size), int(F), _ptr(out),
+                                                      dtype_code(out.dtype), s), "detokenize_shared")
+            ids.record_stream(self._run); out.record_stream(self._run)
+
     def cache_create(self, B):
         h = C.c_void_p()
         self.check(self.lib.ivg_cache_create(self.h, int(B), C.byref(h)), "cache_create")
@@ -179,6 +189,19 @@ class Engine:
             self.check(fn(self.h, _ptr(prompt), prompt.stride(0), B, L0, int(n_new), _ptr(actions), act_T, int(ctx),
                                              _ptr(uniforms), int(top_k), _ptr(out), _ptr(reward), s), "generate")
             for t in (prompt, out, actions, uniforms, reward):
+                if t is not None:
+                    t.record_stream(self._run)
+
+    def generate_shared(self, prompts, group_size, n_new, out, actions=None, ctx=1, uniforms=None, top_k=100, reward=None, force_sdf=False):
+        """ivg_generate_shared: ``prompts`` (n_groups, L0), one row per group of ``group_size`` consecutive trajectories; actions /
+        uniforms / out / reward have n_groups * group_size rows (row g * group_size + k = sample k of prompt g)."""
+        n_groups, L0 = prompts.shape
+        act_T = actions.shape[1] if actions is not None else 0
+        with self.stream() as s:
+            self.check(self.lib.ivg_generate_shared(self.h, _ptr(prompts), prompts.stride(0), n_groups, int(group_size), L0, int(n_new), _ptr(actions),
+                                                    act_T, int(ctx), _ptr(uniforms), int(top_k), int(bool(force_sdf)), _ptr(out), _ptr(reward), s),
+                       "generate_shared")
+            for t in (prompts, out, actions, uniforms, reward):
                 if t is not None:
                     t.record_stream(self._run)
 

@@ -72,6 +72,39 @@ class _RewardLinear:
     forward = __call__
 
 
+def shared_prompt_groups(ids, repeat_times):
+    """The reference's multi-sample callers build their prompts as ``gen_input.repeat(t, 1)`` (inference/predict.py:65,
+    train_gpt.py:170,179): row ``k * B0 + b`` is sample k of prompt b.  ``repeat_times``:
+      * an int t > 1 -- the caller says so; checked on the device (one comparison kernel + a host read: a generate call is >= 100 ms);
+      * ``"auto"`` -- detect it: the largest t dividing B for which rows b, b + B0, ... are equal (1: nothing shared).
+    -> (t, B0).  Raises ValueError when an explicit t does not describe ``ids``."""
+    B = ids.shape[0]
+    if repeat_times == "auto":
+        for t in range(B, 1, -1):
+            if B % t == 0 and torch.equal(ids.reshape(t, B // t, -1), ids[:B // t].unsqueeze(0).expand(t, -1, -1)):
+                return t, B // t
+        return 1, B
+    t = int(repeat_times)
+    if t <= 1:
+        return 1, B
+    if B % t != 0 or not torch.equal(ids.reshape(t, B // t, -1), ids[:B // t].unsqueeze(0).expand(t, -1, -1)):
+        raise ValueError(f"shared_context={t}: input_ids is not `prompts.repeat({t}, 1)` (rows b, b + B/{t}, ... must be identical)")
+    return t, B // t
+
+
+def _to_group_major(x, t, B0):
+    """rows (k * B0 + b) -> rows (b * t + k): the engine keeps the t samples of a prompt in consecutive rows"""
+    if x is None or t == 1 or B0 == 1:
+        return x
+    return x.view(t, B0, *x.shape[1:]).transpose(0, 1).reshape(x.shape).contiguous()
+
+
+def _from_group_major(x, t, B0):
+    if x is None or t == 1 or B0 == 1:
+        return x
+    return x.view(B0, t, *x.shape[1:]).transpose(0, 1).reshape(x.shape).contiguous()
+
+
 class LlamaForCausalLM:
     def __init__(self, config, state_dict=None, dtype="bf16", prefix="", action_dim=None, reward_prediction=False, decode_lds_kb=0):
         self._decode_lds_kb = int(decode_lds_kb or 0)   # launch policy of THIS model's engine (set_decode_lds_kb)
@@ -232,8 +265,12 @@ class LlamaForCausalLM:
     @torch.no_grad()
     def generate(self, input_ids=None, do_sample=True, temperature=1.0, top_k=100, max_new_tokens=None, pad_token_id=None,
                  generator=None, uniforms=None, inputs_embeds=None, return_dict_in_generate=False, output_hidden_states=False,
-                 use_cache=True, **unused):
+                 use_cache=True, shared_context=None, **unused):
         """``input_ids`` prompt -> int64 (B, L0 + max_new_tokens), prompt included (HF convention).
+        ``shared_context`` (not in HF; round 6): ``t`` or ``"auto"`` when ``input_ids`` is ``prompts.repeat(t, 1)`` -- what
+        inference/predict.py:65 and train_gpt.py:170-184 pass.  The prompt is then prefilled ONCE per distinct row, its K / V rows are kept
+        once and shared by the t samples at every decode step (libivg ``ivg_generate_shared``); row order, uniforms and results are those
+        of the plain call (same tokens up to near-ties of the sampler: the prompt's last position goes through the decode-step kernels).
         ``inputs_embeds`` prompt (B, L0, hidden) -> only the new tokens (B, max_new_tokens), as HF does for embeddings prompts
         (action_model.py:101-110, mbrl/video_predictor.py:298-313).  With ``return_dict_in_generate`` the result has
         ``.sequences`` and, with ``output_hidden_states``, ``.hidden_states`` of which only what the callers read exists:
@@ -257,6 +294,11 @@ class LlamaForCausalLM:
         B, L0 = ids.shape
         out = torch.empty(B, L0 + max_new_tokens, dtype=torch.int64, device=self.device)
         u = uniforms if uniforms is not None else self._uniforms(B, max_new_tokens, do_sample, generator)
+        t, B0 = shared_prompt_groups(ids, shared_context) if shared_context else (1, B)
+        if t > 1 and L0 >= 2:
+            self._ensure(B).set_temperature(temperature).generate_shared(ids[:B0].contiguous(), t, max_new_tokens, out, uniforms=_to_group_major(u, t, B0),
+                                                                         top_k=top_k or self._cfg["vocab_size"])
+            return _from_group_major(out, t, B0)
         self._ensure(B).set_temperature(temperature).generate(ids, max_new_tokens, out, uniforms=u, top_k=top_k or self._cfg["vocab_size"])
         return out
 
@@ -387,9 +429,12 @@ class HeadModelWithAction:
 
     @torch.no_grad()
     def generate(self, inputs_token, do_sample=True, temperature=1.0, top_k=100, max_new_tokens=None, pad_token_id=50256,
-                 action=None, generator=None, uniforms=None, return_reward=False, reuse_cache=False):
+                 action=None, generator=None, uniforms=None, return_reward=False, reuse_cache=False, shared_context=None):
         """action_model.py:56-121: action (B, T, D); new token j is the forced sdf when j % 17 == 0; the i-th sdf slot's
         embedding gets ``action_linear(action[:, i + context - 1])``.  -> int64 (B, L0 + max_new_tokens).
+        ``shared_context``: as ``LlamaForCausalLM.generate`` -- ``inputs_token`` is ``prompts.repeat(t, 1)`` (train_gpt.py:170, VP2's
+        candidate action sequences over one context: vp/ivideogpt_interface.py:155-202); the ACTIONS stay per row (the shared prefix ends
+        before the first action slot).
         ``reuse_cache=True`` (step-wise rollouts, mbrl/video_predictor.py:286-317): the prompt is the previous call's full
         output plus the forced ``sdf``; the engine keeps the KV cache of that call and feeds only the last prompt token
         instead of prefilling the grown prompt again (raises AssertionError when the cache holds something else)."""
@@ -402,6 +447,13 @@ class HeadModelWithAction:
         out = torch.empty(B, L0 + max_new_tokens, dtype=torch.int64, device=llm.device)
         u = uniforms if uniforms is not None else llm._uniforms(B, max_new_tokens, do_sample, generator)
         reward = torch.empty(B, dtype=torch.float32, device=llm.device) if return_reward else None
+        t, B0 = shared_prompt_groups(ids, shared_context) if (shared_context and not reuse_cache) else (1, B)
+        if t > 1 and L0 == 257 * self.context:
+            llm._ensure(B, act.shape[1]).set_temperature(temperature).generate_shared(
+                ids[:B0].contiguous(), t, max_new_tokens, out, actions=_to_group_major(act, t, B0), ctx=self.context, uniforms=_to_group_major(u, t, B0),
+                top_k=top_k or llm._cfg["vocab_size"], reward=reward)
+            out, reward = _from_group_major(out, t, B0), _from_group_major(reward, t, B0)
+            return (out, reward) if return_reward else out
         llm._ensure(B, act.shape[1]).set_temperature(temperature).generate(ids, max_new_tokens, out, actions=act, ctx=self.context, uniforms=u,
                                               top_k=top_k or llm._cfg["vocab_size"], reward=reward, reuse_kv=reuse_cache)
         return (out, reward) if return_reward else out

@@ -212,8 +212,13 @@ class CompressiveVQModel:
         return ids
 
     @torch.no_grad()
-    def detokenize(self, indices, context_length=0, cache=None, return_cache=False, clamp=False, out_dtype=torch.float32):
-        """``clamp=True`` (not in the reference's signature): the frames come back as ``clamp(0, 1)`` -- the post-processing every
+    def detokenize(self, indices, context_length=0, cache=None, return_cache=False, clamp=False, out_dtype=torch.float32, shared_context=None):
+        """``shared_context`` (not in the reference's signature; round 6): ``t`` or ``"auto"`` when the rows of ``indices`` are the t
+        samples of B / t clips in ``repeat(t, 1)`` order (row k * B0 + b = sample k of clip b: what predict.py:65-72 and
+        train_gpt.py:170-184 produce, VP2's candidates with B0 = 1) -- their CONTEXT tokens are identical, so the context frames are
+        decoded once per clip and the predicted frames' cross-attention K / V are projected once per clip (libivg
+        ``ivg_detokenize_shared``); same pixels as the plain call.
+        ``clamp=True`` (not in the reference's signature): the frames come back as ``clamp(0, 1)`` -- the post-processing every
         caller applies (predict.py:73) -- written by the epilogue of the decoders' last convolution instead of a pass over the clip.
         ``out_dtype=torch.bfloat16`` (bf16 decode mode only): the clip in bfloat16, as the reference returns it under
         ``torch.autocast(bfloat16)`` (vp/ivideogpt_interface.py:180, mbrl/video_predictor.py:269) -- half the bytes."""
@@ -225,6 +230,12 @@ class CompressiveVQModel:
         res = self.config["resolution"]
         out = torch.empty(B, context_length + F, 3, res, res, dtype=out_dtype, device=self.device)
         eng = self._ensure(B, context_length + F)
+        if shared_context and cache is None and not return_cache and F > 0:
+            from .transformer import _from_group_major, _to_group_major, shared_prompt_groups
+            t, B0 = shared_prompt_groups(ids[:, :CTX_TOKENS * context_length - 1], shared_context)
+            if t > 1:
+                eng.detokenize_shared(_to_group_major(ids, t, B0), t, F, out, clamp=clamp)
+                return _from_group_major(out, t, B0)
         handle, mode = None, 0
         if cache is not None and (cache.engine is not eng or cache.engine.h is None):
             # the engine was rebuilt since the cache was filled (batch or clip length grew): the cached context features are

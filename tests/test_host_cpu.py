@@ -515,3 +515,24 @@ def test_pack_subpixel_is_the_upsampled_convolution():
             # input rows iy + py + kh2 - 1 = padded rows iy + py + kh2: a 2 x 2 valid convolution over the padded image shifted by (py, px)
             out[:, :, py::2, px::2] = F.conv2d(xp[:, :, py:py + H + 1, px:px + W + 1], wk)
     assert (out - ref).abs().max().item() < 1e-5 * ref.abs().max().item()
+
+
+def test_shared_context_row_order_helpers():
+    """ivideogpt_amd.transformer: the reference's multi-sample callers build ``prompts.repeat(t, 1)`` (row k * B0 + b = sample k of
+    prompt b: inference/predict.py:65, train_gpt.py:170); the engine keeps a prompt's samples in consecutive rows.  Detection of the
+    repetition (explicit t is verified, "auto" finds the largest t) and the two row permutations are inverse to each other."""
+    from ivideogpt_amd.transformer import _from_group_major, _to_group_major, shared_prompt_groups
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(0, 100, (3, 9), generator=g)
+    rep = ids.repeat(4, 1)
+    assert shared_prompt_groups(rep, "auto") == (4, 3) and shared_prompt_groups(rep, 4) == (4, 3) and shared_prompt_groups(rep, 2) == (2, 6)
+    assert shared_prompt_groups(ids, "auto") == (1, 3) and shared_prompt_groups(ids, 1) == (1, 3)
+    assert shared_prompt_groups(rep[:, :5], "auto") == (4, 3)          # a column slice (non-contiguous), as detokenize passes it
+    with pytest.raises(ValueError):
+        shared_prompt_groups(rep, 5)
+    with pytest.raises(ValueError):
+        shared_prompt_groups(torch.cat([ids, ids.flip(0)]), 2)
+    x = torch.arange(12 * 2).view(12, 2)
+    gm = _to_group_major(x, 4, 3)
+    assert gm[:, 0].tolist() == [2 * r for r in (0, 3, 6, 9, 1, 4, 7, 10, 2, 5, 8, 11)]      # rows of prompt 0 first
+    assert torch.equal(_from_group_major(gm, 4, 3), x) and _to_group_major(None, 4, 3) is None and _to_group_major(x, 12, 1) is x
