@@ -714,6 +714,70 @@ def main():
                 other[f"config_{k}"] = {"value": None, "error": repr(ex)[:200]}
             torch.cuda.empty_cache()
 
+    # ---- the reference's MULTI-SAMPLE callers (round 6): one clip's context, t rollouts.  BASELINE config 1 = inference/predict.py
+    # (--repeat_times 5 over one clip) and VP2's planner (vp/ivideogpt_interface.py: 200 candidate action sequences over the same two
+    # frames, generate_max_batchsize 100 / decode_max_batchsize 67 of vp/ivideogpt.yaml), each timed twice: the callers' own flow on
+    # the plain entries (every row prefills / stores / streams / decodes its copy of the context) and with shared_context (once per clip)
+    shared = {}
+    if world == 1 and default_run and not a.no_other_configs:
+        for key, spec in (("config_1", dict(t=5, frames=16, action_dim=0, gmax=5, dmax=5, steps=8,
+                                            what="inference/predict.py: 1 clip, --repeat_times 5, 2 context + 14 predicted frames, 64x64, small transformer")),
+                          ("vp2", dict(t=200, frames=12, action_dim=5, gmax=100, dmax=67, steps=4,
+                                       what="vp/ivideogpt_interface.py: 200 candidate action sequences (5-dim) over ONE 2-frame context, 10 predicted "
+                                            "frames, generate_max_batchsize 100, decode_max_batchsize 67 (vp/ivideogpt.yaml)"))):
+            try:
+                _, lc, _, _, tok_s, model_s = build_models(dev, 64, False, a.encode_dtype, a.decode_dtype, a.llm_dtype, spec["action_dim"], None, spec["frames"])
+                ctx_s, t_s = tok_s.context_length, spec["t"]
+                Fs = spec["frames"] - ctx_s
+                gs = torch.Generator(device=dev).manual_seed(5000 + t_s)
+                clip = torch.rand(1, spec["frames"], 3, 64, 64, device=dev, generator=gs).to(torch.bfloat16)
+                acts = torch.randn(t_s, spec["frames"], spec["action_dim"], device=dev, generator=gs) if spec["action_dim"] else None
+                n_new = 17 * Fs - 1
+
+                def flow(share):
+                    # the caller's own sequence (predict.py:47-73 / ivideogpt_interface.py:155-202), chunked as the caller chunks it
+                    outs = []
+                    for s0 in range(0, t_s, spec["gmax"]):
+                        n = min(spec["gmax"], t_s - s0)
+                        if share or key == "config_1":      # predict.py tokenizes the ONE clip and repeats the tokens (:53-65)
+                            prompt = tok_s.encode_context(clip, ctx_s).repeat(n, 1)
+                        else:                               # VP2 tokenizes every copy of the observation (:155-169)
+                            prompt = tok_s.encode_context(clip.expand(n, -1, -1, -1, -1).contiguous(), ctx_s)
+                        kw_s = {"action": acts[s0:s0 + n]} if acts is not None else {}
+                        toks = model_s.generate(prompt, do_sample=True, top_k=100, max_new_tokens=n_new, generator=gs,
+                                                shared_context=n if share and n > 1 else None, **kw_s)
+                        for d0 in range(0, n, spec["dmax"]):
+                            ch = toks[d0:d0 + spec["dmax"]]
+                            outs.append(tok_s.detokenize(ch, ctx_s, clamp=True, shared_context=ch.shape[0] if share and ch.shape[0] > 1 else None))
+                    return outs
+                res_s = {}
+                for mode, share in (("shared_context", True), ("plain", False)):
+                    flow(share)                             # warm-up: engines, workspace plans
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(spec["steps"]):
+                        outs = flow(share)
+                    torch.cuda.synchronize()
+                    el = time.perf_counter() - t0
+                    assert all(torch.isfinite(o).all() for o in outs)
+                    res_s[mode] = {"value": t_s * Fs * spec["steps"] / el, "unit": "predicted frames/s", "ms_per_call": el / spec["steps"] * 1e3, "steps": spec["steps"]}
+                # K / V bytes a decode step asks HBM for (algorithmic; bf16 K + V of every layer = kv_row bytes per cached position), mean over
+                # the rollout: every row streams all its positions (plain) vs the shared prefix ONCE per generate chunk + the rows' own tails
+                kv_row = 2 * lc["num_hidden_layers"] * lc["hidden_size"] * (2 if a.llm_dtype == "bf16" else 4)
+                P = 257 * ctx_s - 1
+                mean_len = P + 1 + (n_new - 1) / 2.0
+                chunks = -(-t_s // spec["gmax"])
+                shared[key] = dict(res_s, workload=spec["what"], speedup=res_s["shared_context"]["value"] / res_s["plain"]["value"],
+                                   kv_bytes_per_decode_step={"plain": t_s * mean_len * kv_row, "shared_context": (chunks * P + t_s * (mean_len - P)) * kv_row,
+                                                             "note": "algorithmic HBM bytes of the K / V rows one decode step reads, mean over the rollout; "
+                                                                     "shared: the prompt's rows once per generate chunk (the group's other rows hit L2 / Infinity Cache)"},
+                                   prompt_rows_prefilled={"plain": t_s, "shared_context": chunks}, context_frames_decoded={"plain": t_s * ctx_s,
+                                                           "shared_context": ctx_s * sum(-(-min(spec["gmax"], t_s - s0) // spec["dmax"]) for s0 in range(0, t_s, spec["gmax"]))})
+                del tok_s, model_s, outs
+            except Exception as ex:   # never lose the headline to a side measurement
+                shared[key] = {"value": None, "error": repr(ex)[:300]}
+            torch.cuda.empty_cache()
+
     if rank == 0:
         units = global_b * F * a.steps
         rl = rooflines(kstats, a)
@@ -751,6 +815,8 @@ def main():
         out.update(alt)
         if other:
             out["other_configs"] = other
+        if shared:
+            out["shared_context"] = shared
         if world == 1 and not a.no_cpu_baseline:
             # 32 threads: MORE threads make this port slower on the GPU box's host (4 trajectories: 4.35 frames/s on 32 threads, 2.11 on
             # 64, no result within 200 s on all 256 -- profiles/r04_cpu_baseline_threads.txt); --cpu-threads N overrides

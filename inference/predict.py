@@ -78,8 +78,10 @@ def predict(args, tokenizer, model, input, actions=None):
     if actions is not None:
         extra["action"] = actions.to(GPU, non_blocking=True)[None].repeat(reps, 1, 1)
     n_new = TOKENS_PER_FRAME * (args.segment_length - ctx) - 1
-    tokens = model.generate(prompt, do_sample=True, temperature=1.0, top_k=100, max_new_tokens=n_new, pad_token_id=50256, **extra)
-    recon = tokenizer.detokenize(tokens, ctx).clamp(0.0, 1.0)
+    # the `reps` rows share ONE context (predict.py:65 repeats it): prefilled / decoded once, its K / V rows kept once (shared_context)
+    tokens = model.generate(prompt, do_sample=True, temperature=1.0, top_k=100, max_new_tokens=n_new, pad_token_id=50256, shared_context=reps,
+                            **extra)
+    recon = tokenizer.detokenize(tokens, ctx, shared_context=reps).clamp(0.0, 1.0)
     save_outputs(args.output_path, clip[0], recon, tokens)
     return recon
 

@@ -11,8 +11,11 @@ import torch
 
 @torch.no_grad()
 def predict_frames(tokenizer, model, pixel_values, context_length, future_length, actions=None, do_sample=True, top_k=100,
-                   generator=None, uniforms=None, return_tokens=False, temperature=1.0, conv_gate=None, metrics_of=None, rollout_stream=None):
+                   generator=None, uniforms=None, return_tokens=False, temperature=1.0, conv_gate=None, metrics_of=None, rollout_stream=None,
+                   shared_context=None):
     """pixel_values (B, >=ctx, 3, H, W) on the GPU (fp32 or bf16, [0,1]).  -> float32 (B, ctx+F, 3, H, W) in [0,1].
+    ``shared_context=t``: t samples of every clip (predict.py's ``repeat_times``, VP2's candidates: ``actions`` then has t * B rows,
+    row k * B + b = sample k of clip b, like the result): the context is encoded, prefilled and decoded once per clip.
     ``conv_gate`` (parallel.PhaseGate, several batches in flight on one GPU): the two convolution phases -- context encode, frame
     decode -- are ordered against the other lanes' convolution phases; the rollout between them is not.  ``metrics_of`` (ground-truth
     clip): the per-trajectory metric rows of the predicted frames are computed inside the decode phase and returned beside the frames.
@@ -24,6 +27,10 @@ def predict_frames(tokenizer, model, pixel_values, context_length, future_length
         prompt = tokenizer.encode_context(pixel_values, context_length)
     n_new = 17 * future_length - 1
     kw = {} if temperature == 1.0 else {"temperature": temperature}
+    dkw = {}
+    if shared_context and int(shared_context) > 1:
+        prompt = prompt.repeat(int(shared_context), 1)
+        kw["shared_context"] = dkw["shared_context"] = int(shared_context)
     if actions is not None:
         kw["action"] = actions
     if do_sample and uniforms is None:   # drawn on the caller's stream (the generator's state is not tied to a stream)
@@ -39,7 +46,7 @@ def predict_frames(tokenizer, model, pixel_values, context_length, future_length
     else:
         tokens = model.generate(prompt, do_sample=do_sample, top_k=top_k, max_new_tokens=n_new, uniforms=uniforms, **kw)
     with gated():
-        frames = tokenizer.detokenize(tokens, context_length, clamp=True)   # clamp(0, 1) in the epilogue of the decoders' last convolution
+        frames = tokenizer.detokenize(tokens, context_length, clamp=True, **dkw)   # clamp(0, 1) in the epilogue of the decoders' last convolution
         rows = frame_metrics(frames, metrics_of, first_frame=context_length) if metrics_of is not None else None
     out = (frames, tokens) if return_tokens else (frames,)
     if metrics_of is not None:

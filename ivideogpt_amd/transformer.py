@@ -106,6 +106,7 @@ def _from_group_major(x, t, B0):
 
 
 class LlamaForCausalLM:
+    supports_shared_context = True   # generate / detokenize accept shared_context= (libivg ivg_generate_shared / ivg_detokenize_shared)
     def __init__(self, config, state_dict=None, dtype="bf16", prefix="", action_dim=None, reward_prediction=False, decode_lds_kb=0):
         self._decode_lds_kb = int(decode_lds_kb or 0)   # launch policy of THIS model's engine (set_decode_lds_kb)
         self._cfg = dict(W.LLAMA_SMALL)
@@ -341,6 +342,7 @@ class LlamaForCausalLM:
 
 class HeadModelWithAction:
     """action_model.py:8-45: wraps an ``llm`` and adds ``action_linear`` (+ optional ``reward_linear``)."""
+    supports_shared_context = True   # generate / detokenize accept shared_context= (libivg ivg_generate_shared / ivg_detokenize_shared)
 
     def __init__(self, llm, action_dim, prelude_tokens_num, tokens_num_per_dyna, context, segment_length, model_type="llama",
                  reward_prediction=False, action_recon=None, **kwargs):

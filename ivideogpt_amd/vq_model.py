@@ -38,6 +38,7 @@ class DetokenizeCache:
 
 
 class CompressiveVQModel:
+    supports_shared_context = True   # generate / detokenize accept shared_context= (libivg ivg_generate_shared / ivg_detokenize_shared)
     def __init__(self, config=None, state_dict=None, encode_dtype="fp32", decode_dtype="bf16", **kwargs):
         cfg = dict(config or {})
         cfg.update(kwargs)

@@ -60,6 +60,8 @@ def generate_multiple_times(gen_times, accelerator, model, gen_input, actions, g
         extra["action"] = actions.repeat(copies, 1, 1)
     if reward_prediction:
         extra["return_reward"] = True
+    if copies > 1 and getattr(net, "supports_shared_context", False):
+        extra["shared_context"] = copies   # rows k * B + b repeat prompt b: prefilled once, its K / V rows kept once (ivg_generate_shared)
     tokens, rewards = [], []
     for _ in range(calls):
         out = net.generate(prompts, **extra)
@@ -123,7 +125,10 @@ def evaluate(args, accelerator, tokenizer, model, eval_dataloader, evaluator, co
                                               gen_kwargs=dict(do_sample=True, temperature=1.0, top_k=100, max_new_tokens=budget),
                                               max_batch_size=args.max_generate_batchsize, reward_prediction=args.reward_prediction)
             sampled = sampled[0] if args.reward_prediction else sampled       # prompt included
-            decode = lambda ids: tok.detokenize(ids, ctx)
+            if args.eval_generate_times > 1 and getattr(tok, "supports_shared_context", False):
+                decode = lambda ids: tok.detokenize(ids, ctx, shared_context="auto")   # the samples of a clip share its context: decoded once per clip
+            else:
+                decode = lambda ids: tok.detokenize(ids, ctx)
             chunk = args.max_decode_batchsize
             recon = batch_forward(chunk, sampled, decode) if chunk is not None and sampled.shape[0] > chunk else decode(sampled)
             recon = recon.clamp(0.0, 1.0)

@@ -58,10 +58,16 @@ class iVideoGPTPredictor:
         outs = []
         for s in range(0, B, gmax):                                      # the reference chunks by generate_max_batchsize (:155-202)
             px, a = pixels[s:s + gmax], act[s:s + gmax]
-            prompt = self.tokenizer.encode_context(px, ctx)
+            n = px.shape[0]
+            # VP2's planner scores its candidate action sequences from ONE observation: the rows of `video` are copies of the same two
+            # frames (vp/ivideogpt_interface.py:155-169 tokenizes every copy).  When they are, the context is encoded, prefilled and
+            # decoded ONCE and its K / V rows are shared by all candidates (shared_context); the actions stay per row.
+            same = n > 1 and bool((px == px[:1]).all())
+            prompt = self.tokenizer.encode_context(px[:1], ctx).repeat(n, 1) if same else self.tokenizer.encode_context(px, ctx)
             tokens = self.model.generate(prompt, do_sample=True, temperature=1.0, top_k=100, max_new_tokens=17 * (T - ctx) - 1,
-                                         pad_token_id=50256, action=a)
+                                         pad_token_id=50256, action=a, shared_context=n if same else None)
             for d in range(0, tokens.shape[0], dmax):
-                outs.append(self.tokenizer.detokenize(tokens[d:d + dmax], ctx).clamp(0.0, 1.0))
+                chunk = tokens[d:d + dmax]
+                outs.append(self.tokenizer.detokenize(chunk, ctx, shared_context=chunk.shape[0] if same and chunk.shape[0] > 1 else None).clamp(0.0, 1.0))
         rec = torch.cat(outs, 0)[:, 1:]                                  # 11 frames: last context frame + 10 predictions (:199-205)
         return {"rgb": rec.permute(0, 1, 3, 4, 2).float().cpu().numpy()}
