@@ -139,14 +139,17 @@ KERNEL_NAMES = {
     "conv3x3": "ivg::conv3x3_kernel (LDS-halo 3x3 convolution, MFMA)",
     "igemm": "ivg::gemm256l_kernel + ivg::igemm_kernel<128,128,64> (dense GEMMs / implicit-GEMM convs other than 3x3, MFMA)",
 }
-PMC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json")
-TRACE_FILES = ("r05_kernel_trace_classes.json", "r04_kernel_trace_classes.json", "r03_kernel_trace_classes.json")
+PMC_FILES = ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json")
+TRACE_FILES = ("r06_kernel_trace_classes.json", "r05_kernel_trace_classes.json", "r04_kernel_trace_classes.json", "r03_kernel_trace_classes.json")
+# the same two evidence files for BASELINE config 4 (256 x 256, B = 16): rocprofv3 passes of `bench.py --config 4 --lanes 1 ...`
+PMC_FILES_C4 = ("r06_c4_pmc_traffic.json",)
+TRACE_FILES_C4 = ("r06_c4_kernel_trace_classes.json",)
 
 
-def _pmc_traffic(name):
+def _pmc_traffic(name, files=None):
     """HBM bytes per launch from the committed PMC passes (profiles/rNN_pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE runs of this same command, gfx950 corrections applied as the file states) -- NOT measured in this run."""
-    for fn in PMC_FILES:
+    for fn in (files or PMC_FILES):
         path = os.path.join(ROOT, "profiles", fn)
         try:
             with open(path) as f:
@@ -158,10 +161,10 @@ def _pmc_traffic(name):
     return None, None
 
 
-def _trace_mean_us(name):
+def _trace_mean_us(name, files=None):
     """Mean launch duration of a kernel class on the PROFILER's clock (rocprofv3 --kernel-trace of this command, committed under
     profiles/; includes the dispatch the kernels' own stamps do not see) -- NOT measured in this run."""
-    for fn in TRACE_FILES:
+    for fn in (files or TRACE_FILES):
         try:
             with open(os.path.join(ROOT, "profiles", fn)) as f:
                 v = json.load(f)["classes"].get(name)
@@ -172,10 +175,15 @@ def _trace_mean_us(name):
     return None, None
 
 
-def rooflines(kstats, a):
+def rooflines(kstats, a, config4=False):
     """One roofline object per measured kernel class, the one with the most kernel time per step first.
     decode_attn / decode_gemm are HBM-bound (algorithmic bytes = the K and V rows, resp. the weight matrix, one launch reads);
-    the conv / GEMM classes are MFMA-bound (2 * M * N * K flops per launch)."""
+    the conv / GEMM classes are MFMA-bound (2 * M * N * K flops per launch).
+    `frac` / `achieved` are THIS RUN's figures (HIP events on the launching stream for the conv / GEMM classes; the kernels' own
+    wall-clock stamps for the decode classes, which run inside replayed graphs / back to back without host access).  The committed
+    profiler figure of the same command -- rocprofv3 --kernel-trace mean duration, dispatch included -- sits beside them as
+    `frac_profiler` with its source file: the two must agree; a regression moves `frac` even when the committed file is stale."""
+    trace_files, pmc_files = (TRACE_FILES_C4, PMC_FILES_C4) if config4 else (None, None)
     peak_f = PEAK_BF16_TFLOPS if a.decode_dtype == "bf16" else PEAK_F32_TFLOPS
     out = []
     for name, s in kstats.items():
@@ -186,32 +194,40 @@ def rooflines(kstats, a):
                   "kernel_ms_per_step": s["total_ms"]}
         if name in ("decode_attn", "decode_gemm"):
             # Two clocks.  The kernels stamp their own launch window (first workgroup start -> last end on the 100 MHz wall clock: no
-            # dispatch) in THIS run; the profiler's mean duration of the class (rocprofv3 --kernel-trace of this command, committed
-            # under profiles/, dispatch included) is what profiles/ shows and what the class costs the step.  `frac` / `achieved` are
-            # the PROFILER-clock figures whenever the committed trace has the class; the stamp figures stay beside them.
+            # dispatch) in THIS run: that is `frac`.  The profiler's mean duration of the class (rocprofv3 --kernel-trace of this
+            # command, committed under profiles/, dispatch included -- what the class costs the step) gives `frac_profiler`.
             per_launch = s["total_bytes"] / s["launches"]
             ach_st = s["total_bytes"] / sec / 1e9
             r = {"bound": "hbm", "achieved": ach_st, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach_st / PEAK_HBM_GBS,
-                 "frac_clock": "kernel stamps of this run (no committed trace of the class)",
-                 "achieved_stamps": ach_st, "frac_stamps": ach_st / PEAK_HBM_GBS, "kernel_ms_per_step_stamps": s["total_ms"],
+                 "frac_clock": "this run: the kernels' own launch-window stamps (100 MHz wall clock, first workgroup start -> last end)",
                  "algorithmic_bytes_per_launch": per_launch}
-            mean_us, src = _trace_mean_us(name)
+            if "mean_launch_us_by_kind" in s:
+                r["mean_launch_us_by_kind"] = s["mean_launch_us_by_kind"]
+            mean_us, src = _trace_mean_us(name, trace_files)
             if mean_us:
-                r["achieved"] = per_launch / (mean_us * 1e-6) / 1e9
-                r["frac"] = r["achieved"] / PEAK_HBM_GBS
-                r["frac_clock"] = "profiler: " + src + " (rocprofv3 --kernel-trace mean duration of this class for this command, committed; not this run)"
-                common["avg_launch_ms"] = mean_us * 1e-3
-                common["kernel_ms_per_step"] = mean_us * 1e-3 * s["launches"]
+                r["achieved_profiler"] = per_launch / (mean_us * 1e-6) / 1e9
+                r["frac_profiler"] = r["achieved_profiler"] / PEAK_HBM_GBS
+                r["avg_launch_ms_profiler"] = mean_us * 1e-3
+                r["kernel_ms_per_step_profiler"] = mean_us * 1e-3 * s["launches"]
+                r["frac_profiler_source"] = src + " (rocprofv3 --kernel-trace mean duration of this class for this command, dispatch included; committed, not this run)"
         else:
             ach = s["total_flops"] / sec / 1e12
             r = {"bound": "mfma", "achieved": ach, "peak": peak_f, "unit": "TFLOP/s", "frac": ach / peak_f,
-                 "algorithmic_flops_per_launch": s["total_flops"] / s["launches"]}
+                 "frac_clock": "this run: HIP events around every launch of the class on the launching stream",
+                 "algorithmic_flops_per_launch": s["total_flops"] / s["launches"],
+                 "algorithmic_flops_note": "the REFERENCE algorithm's multiplies (an upsampling convolution counts its nine taps over the upsampled "
+                                           "grid; the sub-pixel form that runs does 2.25 x fewer)"}
+            mean_us, src = _trace_mean_us(name, trace_files)
+            if mean_us:
+                r["achieved_profiler"] = s["total_flops"] / s["launches"] / (mean_us * 1e-6) / 1e12
+                r["frac_profiler"] = r["achieved_profiler"] / peak_f
+                r["frac_profiler_source"] = src + " (rocprofv3 --kernel-trace mean duration of this class for this command; committed, not this run)"
             if a.decode_dtype == "bf16":
                 r["peak_sustained"] = SUSTAINED_BF16_TFLOPS
                 r["frac_of_sustained"] = ach / SUSTAINED_BF16_TFLOPS
                 r["peak_sustained_source"] = ("profiles/r05_mfma_power.txt: a pure bf16 MFMA stream on random operands at the socket's 1,400 W limit "
                                               "(committed micro-benchmark, not this run)")
-        r["traffic"], src = _pmc_traffic(name)
+        r["traffic"], src = _pmc_traffic(name, pmc_files)
         if src:
             r["traffic_source"] = src + " (committed rocprofv3 --pmc passes, not this run)"
         r.update(common)
@@ -404,11 +420,12 @@ def in_flight_pass(lanes, ctx, F, greedy, with_actions):
     per_lane, tot = [], {"attn": 0.0, "gemm": 0.0}
     for i, e in enumerate(engines):
         sa, sg = e.profile_read(_lib.IVG_K_DECODE_ATTN), e.profile_read(_lib.IVG_K_DECODE_GEMM)
+        kinds = {k: round(v[0], 2) for k, v in e.profile_gemm_kinds().items()}
         for k in (_lib.IVG_K_DECODE_ATTN, _lib.IVG_K_DECODE_GEMM):
             e.profile_enable(k, False)
         t = [ref.elapsed_time(ev) for ev in evs[i]]
         per_lane.append({"rollout_interval_ms": [t[1], t[2]], "rollout_host_enqueue_ms": host_ms[i], "decode_attn_mean_launch_us": 1e3 * sa["total_ms"] / max(1, sa["launches"]),
-                         "decode_gemm_mean_launch_us": 1e3 * sg["total_ms"] / max(1, sg["launches"]),
+                         "decode_gemm_mean_launch_us": 1e3 * sg["total_ms"] / max(1, sg["launches"]), "decode_gemm_mean_launch_us_by_kind": kinds,
                          "decode_attn_bytes": sa["total_bytes"], "decode_gemm_bytes": sg["total_bytes"]})
         tot["attn"] += sa["total_bytes"]
         tot["gemm"] += sg["total_bytes"]
@@ -432,7 +449,10 @@ def in_flight_pass(lanes, ctx, F, greedy, with_actions):
             "decode_attn_mean_launch_us_in_flight": mean_attn,
             "per_lane": per_lane,
             "note": "the launches of one lane are slower beside the other lanes' kernels than alone (roofline: one batch alone); the chip as a whole "
-                    "moves this many bytes per second while the rollouts overlap -- the figure the headline mode is bound by"}
+                    "moves this many bytes per second while the rollouts overlap -- the figure the headline mode is bound by",
+            "evidence": "timing only: these stamps and one rocprofv3 --kernel-trace of the lanes-only command (profiles/r06_lanes4_overlap.txt); a "
+                        "--pmc pass of this mode does not exist -- rocprofv3 serialises kernels under --pmc (device-wide counters), so its per-launch "
+                        "traffic would be the one-lane figure by construction"}
 
 
 def main():
@@ -593,10 +613,11 @@ def main():
     per_rank = parallel.gather_metric_rows_even(torch.tensor([[B * F * steps_timed / my_elapsed]], device=dev, dtype=torch.float32)).flatten().tolist()
 
     # ---- profiled pass (untimed): per-kernel-class durations for the rooflines
-    kstats, attn_fit = {}, (0.0, 0.0)
-    llm_engine = (model.llm if a.action_dim else model)._engine
-    if not a.no_profile:
-        prof_engines = [tok._engine, llm_engine]
+    def profile_classes(tok_engine, lm_engine, step_fn):
+        """-> (kstats per kernel class, line fit of the decode attention): HIP events around every conv / GEMM launch of the two engines,
+        the decode kernels' own launch-window stamps; one capture step, one profiled step."""
+        ks = {}
+        prof_engines = [tok_engine, lm_engine]
         bf = a.decode_dtype == "bf16"
         ev_classes = {"igemm": _lib.IVG_K_IGEMM_BF16 if bf else _lib.IVG_K_IGEMM_F32,
                       "conv3x3": _lib.IVG_K_CONV3X3_BF16 if bf else _lib.IVG_K_CONV3X3_F32}
@@ -604,23 +625,30 @@ def main():
             for k in ev_classes.values():
                 e.profile_read(k)
                 e.profile_enable(k, True)
-        llm_engine.profile_enable(_lib.IVG_K_DECODE_ATTN, True)   # the step graph is re-captured with the stamps on
-        llm_engine.profile_enable(_lib.IVG_K_DECODE_GEMM, True)
-        step()          # capture
+        lm_engine.profile_enable(_lib.IVG_K_DECODE_ATTN, True)   # the step graph is re-captured with the stamps on
+        lm_engine.profile_enable(_lib.IVG_K_DECODE_GEMM, True)
+        step_fn()       # capture
         for e in prof_engines:
             for k in ev_classes.values():
                 e.profile_read(k)
-        step()          # the profiled step
+        step_fn()       # the profiled step
         for name, k in ev_classes.items():
             st = [e.profile_read(k) for e in prof_engines]
             for e in prof_engines:
                 e.profile_enable(k, False)
-            kstats[name] = {key: sum(x[key] for x in st) for key in ("launches", "total_ms", "total_flops", "total_bytes")}
-        kstats["decode_attn"] = llm_engine.profile_read(_lib.IVG_K_DECODE_ATTN)
-        attn_fit = llm_engine.profile_attn_fit()
-        kstats["decode_gemm"] = llm_engine.profile_read(_lib.IVG_K_DECODE_GEMM)
-        llm_engine.profile_enable(_lib.IVG_K_DECODE_ATTN, False)
-        llm_engine.profile_enable(_lib.IVG_K_DECODE_GEMM, False)
+            ks[name] = {key: sum(x[key] for x in st) for key in ("launches", "total_ms", "total_flops", "total_bytes")}
+        ks["decode_attn"] = lm_engine.profile_read(_lib.IVG_K_DECODE_ATTN)
+        fit = lm_engine.profile_attn_fit()
+        ks["decode_gemm"] = lm_engine.profile_read(_lib.IVG_K_DECODE_GEMM)
+        ks["decode_gemm"]["mean_launch_us_by_kind"] = {k: round(v[0], 2) for k, v in lm_engine.profile_gemm_kinds().items()}
+        lm_engine.profile_enable(_lib.IVG_K_DECODE_ATTN, False)
+        lm_engine.profile_enable(_lib.IVG_K_DECODE_GEMM, False)
+        return ks, fit
+
+    kstats, attn_fit = {}, (0.0, 0.0)
+    llm_engine = (model.llm if a.action_dim else model)._engine
+    if not a.no_profile:
+        kstats, attn_fit = profile_classes(tok._engine, llm_engine, step)
 
     # not part of a prediction step: the eval path's full-clip tokenize (train_gpt.py:356: context encoder on the ctx frames +
     # CONDITIONAL encoder with cross-attention on all F future frames of every trajectory, SURVEY.md rows a1 / a3 at batch)
@@ -694,6 +722,27 @@ def main():
                                         "workload": f"{c['batch']} trajectories per GPU, {ctx_o} context + {Fo} predicted frames, {c['res']}x{c['res']}, "
                                                     f"{'medium (436 M)' if c['medium'] else 'small (138 M)'} transformer"
                                                     + (f", {c['action_dim']}-dim actions" if c["action_dim"] else "")}
+                if k == 4 and not a.no_profile:
+                    # BASELINE config 4 is labelled "HBM-bound conv decode": its stage split and its dominant kernel class, measured here
+                    # (events / stamps of this run) with the committed rocprofv3 evidence of `bench.py --config 4 --lanes 1` beside it
+                    ev4 = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                    sp4 = []
+                    for _ in range(3):
+                        ev4[0].record()
+                        pr4 = tok_o.encode_context(px_o, ctx_o)
+                        ev4[1].record()
+                        tk4 = model_o.generate(pr4, do_sample=not a.greedy, top_k=100, max_new_tokens=17 * Fo - 1, generator=go)
+                        ev4[2].record()
+                        tok_o.detokenize(tk4, ctx_o, clamp=True)
+                        ev4[3].record()
+                        torch.cuda.synchronize()
+                        sp4.append([ev4[i].elapsed_time(ev4[i + 1]) for i in range(3)])
+                    other["config_4"]["stage_ms"] = {"encode_ms": median([p[0] for p in sp4]), "rollout_ms": median([p[1] for p in sp4]),
+                                                     "decode_ms": median([p[2] for p in sp4]), "passes": 3}
+                    ks4, _ = profile_classes(tok_o._engine, model_o._engine,
+                                             lambda: predict_frames(tok_o, model_o, px_o, ctx_o, Fo, do_sample=not a.greedy, top_k=100, generator=go))
+                    rl4 = rooflines(ks4, a, config4=True)
+                    other["config_4"]["roofline"], other["config_4"]["roofline_other"] = rl4[0], rl4[1:]
                 if a.lanes > 1:
                     lanes_o = [dict(tok=tok_o, model=model_o, pixels=px_o, actions=act_o, gen=go, stream=main_stream)]
                     for i in range(1, a.lanes):

@@ -277,6 +277,9 @@ int ivg_profile_read(ivg_engine* e, int kernel_class, ivg_profile_stats* out);  
 /* after ivg_profile_read(IVG_K_DECODE_ATTN): least-squares line  launch duration = fixed_us + bytes / gbps  over the launches
  * of the last ivg_generate (their cache lengths differ) -- separates the per-launch overhead from the streaming rate */
 int ivg_profile_attn_fit(ivg_engine* e, double* fixed_us, double* gbps);
+/* after ivg_profile_read(IVG_K_DECODE_GEMM): mean launch window (us) and launch count of the decode-step GEMMs by kind --
+ * [0] q/k/v, [1] o-proj, [2] gate/up, [3] down, [4] lm_head (arrays of 5) */
+int ivg_profile_gemm_kinds(ivg_engine* e, double* mean_us, int64_t* launches);
 
 /* ---- op-level entry points (unit parity tests call the kernels through these) */
 typedef struct {
@@ -331,6 +334,12 @@ int ivg_op_vq_argmin(const float* z, const float* codebook, float* ee_ws /* n_e 
 int ivg_op_add_rmsnorm(void* x, const float* w, void* out, int M, int H, float eps, int dtype, ivg_stream stream);
 int ivg_op_conv_in(const void* video, int video_dtype, const float* w, const float* bias, void* Y, int dtype, int N, int per,
                    int T_total, int t0, int H, int W, int C0, ivg_stream stream);
+/* One decode-attention step of a shared-context rollout (ivg_generate_shared): qkv (B, 3 * heads * hd) of the tokens being fed (RoPE
+ * at `pos` is applied inside, the new k / v are appended at cache position `pos` of every row), caches kc / vc
+ * (rows, heads, Lmax, hd) in which group slot s = (b - row0) / G (row0 <= 0) holds the shared prompt rows [0, P) in cache row s and
+ * every trajectory b its own rows [P, pos) in cache row b; out (B, heads * hd).  With G = 1 and P = 0: the plain step. */
+int ivg_op_shared_decode_attn(const void* qkv, void* kc, void* vc, void* out, const float* cos_t, const float* sin_t, int B, int heads, int hd, int Lmax,
+                              int pos, int P, int G, int row0, int dtype, ivg_stream stream);
 /* one top-k draw per logits row [B][V] fp32 with the rollout's sampler (uniforms [B] in [0,1), or NULL = greedy): HF
  * TemperatureLogitsWarper (logits / temperature, > 0) + TopKLogitsWarper + softmax + draw as restated by oracle/llama.py
  * sample_from_logits */

@@ -94,6 +94,7 @@ EXPORTS = {
     "ivg_profile_enable": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ivg_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(IvgProfileStats)]),
     "ivg_profile_attn_fit": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "ivg_profile_gemm_kinds": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "ivg_op_igemm": (C.c_int, [C.POINTER(IvgIgemmArgs), C.c_int, C.c_void_p]),
     "ivg_op_conv_gn": (C.c_int, [C.POINTER(IvgIgemmArgs), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int,
                                  C.c_void_p]),
@@ -101,6 +102,7 @@ EXPORTS = {
     "ivg_op_conv_x3": (C.c_int, [C.POINTER(IvgIgemmArgs), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "ivg_op_xattn": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 7 + [C.c_void_p]),
     "ivg_op_conv_subpixel": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "ivg_op_shared_decode_attn": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 9 + [C.c_void_p]),
     "ivg_op_skinny": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]),
     "ivg_op_skinny_policy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 10 + [C.c_void_p]),
     "ivg_op_groupnorm": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_float, C.c_int, C.c_int, C.c_void_p]),

@@ -719,6 +719,7 @@ int ivg_profile_read(ivg_engine* e, int k, ivg_profile_stats* out) {
     const double wbytes[5] = {3 * H * H * es, H * H * es, 2 * I * H * es, H * I * es, V * H * es};
     std::vector<unsigned long long> h((size_t)ng * NS * 2 * L);
     API_CK(hipMemcpy(h.data(), e->gemm_prof, h.size() * 8, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 5; ++i) { e->gemm_kind_ms[i] = 0; e->gemm_kind_n[i] = 0; }
     for (int g = 0; g < ng; ++g)
       for (int p = 0; p < L; ++p) {
         unsigned long long s = ~0ull, t = 0;
@@ -731,6 +732,8 @@ int ivg_profile_read(ivg_engine* e, int k, ivg_profile_stats* out) {
         const double wb = g == 4 * nl ? wbytes[4] : wbytes[g & 3];
         out->launches++;
         out->total_ms += (double)(t - s) * 1e-5;
+        e->gemm_kind_ms[g == 4 * nl ? 4 : (g & 3)] += (double)(t - s) * 1e-5;
+        e->gemm_kind_n[g == 4 * nl ? 4 : (g & 3)] += 1;
         out->total_bytes += wb;
         out->total_flops += wb / es * 2.0 * e->gemm_prof_B;
       }
@@ -744,6 +747,12 @@ int ivg_profile_read(ivg_engine* e, int k, ivg_profile_stats* out) {
     pc.pool.push_back(s);
   }
   pc.used.clear();
+  return IVG_OK;
+}
+
+int ivg_profile_gemm_kinds(ivg_engine* e, double* mean_us, int64_t* launches) {
+  if (!e || !mean_us || !launches) return IVG_ERR_INVALID;
+  for (int i = 0; i < 5; ++i) { launches[i] = e->gemm_kind_n[i]; mean_us[i] = e->gemm_kind_n[i] ? 1e3 * e->gemm_kind_ms[i] / (double)e->gemm_kind_n[i] : 0.0; }
   return IVG_OK;
 }
 
@@ -898,6 +907,20 @@ int ivg_op_add_rmsnorm(void* x, const float* w, void* out, int M, int H, float e
 int ivg_op_conv_in(const void* video, int video_dtype, const float* w, const float* bias, void* Y, int dtype, int N, int per, int T_total, int t0,
                    int H, int W, int C0, ivg_stream stream) {
   return launch_conv_in(video, (DType)video_dtype, w, bias, Y, (DType)dtype, N, per, T_total, t0, H, W, C0, (hipStream_t)stream) ? IVG_ERR_HIP : IVG_OK;
+}
+
+int ivg_op_shared_decode_attn(const void* qkv, void* kc, void* vc, void* out, const float* cos_t, const float* sin_t, int B, int heads, int hd, int Lmax,
+                              int pos, int P, int G, int row0, int dtype, ivg_stream stream) {
+  // unit-test hook of one decode-attention step of a shared-context rollout (decode_attn_kernel SHARED)
+  if (B <= 0 || G < 1 || P < 0 || P > pos || pos >= Lmax || row0 > 0) return IVG_ERR_INVALID;
+  StepState* state = nullptr;
+  if (hipMalloc((void**)&state, sizeof(StepState)) != hipSuccess) return IVG_ERR_HIP;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = launch_state_set(state, pos, 1, st);
+  if (!rc) rc = launch_decode_attn(qkv, kc, vc, out, cos_t, sin_t, B, heads, hd, Lmax, state, nullptr, (DType)dtype, st, P, G, row0);
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(state);
+  return rc == 0 ? IVG_OK : (rc > 0 ? IVG_ERR_HIP : IVG_ERR_INVALID);
 }
 
 int ivg_op_sample(const float* logits, int B, int V, int top_k, float temperature, const float* uniforms, int64_t* out, ivg_stream stream) {

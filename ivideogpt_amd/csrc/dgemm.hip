@@ -452,6 +452,7 @@ int launch_dgemm(const SkinnyArgs& a, DType dtype, hipStream_t stream) {
     nburst = total / lgv;
   }
   while (MF > 1 && waves * lgv * (MF + FN) * 2048 > budget) MF >>= 1;
+  if (a.w_shared && sw().dg2_mf_cap > 0) MF = std::min(MF, sw().dg2_mf_cap);   // development A/B (IVG_DG2_MF_CAP)
   DgDev d{a.X, a.W, a.Y, a.M, a.N, a.K, a.ldx, a.ldw, a.ldy, a.flags, a.eps, a.bump, nburst, a.pos ? a.prof : nullptr, a.pos, a.prof_ld, a.dbg,
           nullptr, 0u, 0, 0, a.w_shared ? 0 : 1};
   if (a.next_W && a.next_tile_bytes >= 1024 && a.next_tiles > 0 && sw().dg3_warm) {

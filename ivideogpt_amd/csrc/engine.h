@@ -106,6 +106,8 @@ struct ivg_engine {
   unsigned long long* gemm_prof = nullptr;  // [layers * 4 + 1][IVG_GEMM_PROF_SLOTS][2][Lmax] stamps of the decode-step GEMMs (allocated on first use)
   bool gemm_prof_on = false;                // ivg_profile_enable(IVG_K_DECODE_GEMM): part of the step-graph key
   int gemm_prof_B = 0;
+  double gemm_kind_ms[5] = {0, 0, 0, 0, 0};   // last ivg_profile_read(IVG_K_DECODE_GEMM) by kind: q/k/v, o-proj, gate/up, down, lm_head
+  long long gemm_kind_n[5] = {0, 0, 0, 0, 0};
   int kv_len = 0, kv_B = 0;                 // the KV cache holds positions [0, kv_len) of kv_B trajectories (last generate call)
   // what that cache was built from, kept so that a step-wise caller's "same prefix" claim can be VERIFIED on the device:
   //   token path: the ids are in the persistent id buffer (gen_buf), the action table of the call in last_act;

@@ -211,29 +211,40 @@ int launch_gemm256(const IgemmArgs& a, DType dtype, hipStream_t stream) {
   if (M < 4096 || M > 0x7fffffffL || a.N % 128 != 0 || a.Cin % 32 != 0 || a.Cin < 64 || a.ldw % 8 != 0 || a.c_pix % 8 != 0) return -1;
   if (((uintptr_t)a.X & 15) || ((uintptr_t)a.W & 15) || ((uintptr_t)a.Y & 15) || ((a.flags & IG_RESIDUAL) && ((uintptr_t)a.R & 7))) return -1;
   if (glu && (a.flags & IG_BIAS_N)) return -1;
-  G256Dev d;
-  d.X = (const bf16_t*)a.X; d.W = (const bf16_t*)a.W; d.Y = (bf16_t*)a.Y; d.R = (const bf16_t*)a.R; d.bias = a.bias;
-  d.M = (int)M; d.N = a.N; d.K = a.Cin; d.ldx = a.ldx; d.ldw = a.ldw; d.ldy = (int)a.c_pix;
-  d.tiles_n = a.N / BN;
-  d.flags = a.flags;
-  d.tiles_m = cdiv(M, 256);
-  {  // N-tile groups whose weight slabs (gn x 256 rows x K bf16) stay within ~2.5 MB of the 4 MB L2 of an XCD
-    const long slab = (long)BN * d.K * 2;
-    d.gn = (int)std::max(1L, std::min<long>((5L << 19) / slab, d.tiles_n));
-  }
-  const long tiles = (long)cdiv(M, 256) * d.tiles_n;
   // whole-line requests: K steps of 64 elements; other K (no released shape) -> generic implicit GEMM
-  if (d.K % 64 != 0 || (long)d.M * d.ldx * 2 >= (1L << 31) || (long)d.N * d.ldw * 2 >= (1L << 31)) return -1;
+  if (a.Cin % 64 != 0 || (long)a.N * a.ldw * 2 >= (1L << 31)) return -1;
+  // The kernel addresses its operands with 32-bit byte offsets: a launch covers at most 2 GiB of X and of Y.  Larger row counts
+  // (256 x 256 frames: 14.7 M rows of the top decoder level's 1 x 1 shortcuts, 7.5 GB of activations -- round 6: they fell back to the
+  // implicit GEMM, 4.8 ms instead of ~2.4) run as consecutive launches over row ranges; rows are dense, so a range is just an offset.
+  const long row_bytes = 2L * std::max<long>(a.ldx, a.c_pix);
+  long rows_max = ((1L << 31) - 1) / row_bytes / 256 * 256;
+  if (rows_max < 4096) return -1;
   static DynLdsOnce once_l, once_h;
   const int smem_l = 256 * G256_PITCH > 2 * G256L_STAGE ? 256 * G256_PITCH : 2 * G256L_STAGE;
-  if (BN == 256) {
-    if (hipError_t e = ensure_dyn_lds(once_l, (const void*)gemm256l_kernel<256>, 160 * 1024); e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(gemm256l_kernel<256>, dim3((unsigned)tiles), dim3(1024), smem_l, stream, d);
-  } else {
-    if (hipError_t e = ensure_dyn_lds(once_h, (const void*)gemm256l_kernel<128>, 160 * 1024); e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(gemm256l_kernel<128>, dim3((unsigned)tiles), dim3(1024), smem_l, stream, d);
+  for (long r0 = 0; r0 < M; r0 += rows_max) {
+    const long rows = std::min(rows_max, M - r0);
+    G256Dev d;
+    d.X = (const bf16_t*)a.X + r0 * a.ldx; d.W = (const bf16_t*)a.W; d.Y = (bf16_t*)a.Y + r0 * a.c_pix;
+    d.R = a.R ? (const bf16_t*)a.R + r0 * a.c_pix : nullptr; d.bias = a.bias;
+    d.M = (int)rows; d.N = a.N; d.K = a.Cin; d.ldx = a.ldx; d.ldw = a.ldw; d.ldy = (int)a.c_pix;
+    d.tiles_n = a.N / BN;
+    d.flags = a.flags;
+    d.tiles_m = cdiv(rows, 256);
+    {  // N-tile groups whose weight slabs (gn x 256 rows x K bf16) stay within ~2.5 MB of the 4 MB L2 of an XCD
+      const long slab = (long)BN * d.K * 2;
+      d.gn = (int)std::max(1L, std::min<long>((5L << 19) / slab, d.tiles_n));
+    }
+    const long tiles = (long)cdiv(rows, 256) * d.tiles_n;
+    if (BN == 256) {
+      if (hipError_t e = ensure_dyn_lds(once_l, (const void*)gemm256l_kernel<256>, 160 * 1024); e != hipSuccess) return (int)e;
+      hipLaunchKernelGGL(gemm256l_kernel<256>, dim3((unsigned)tiles), dim3(1024), smem_l, stream, d);
+    } else {
+      if (hipError_t e = ensure_dyn_lds(once_h, (const void*)gemm256l_kernel<128>, 160 * 1024); e != hipSuccess) return (int)e;
+      hipLaunchKernelGGL(gemm256l_kernel<128>, dim3((unsigned)tiles), dim3(1024), smem_l, stream, d);
+    }
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
   }
-  return (int)hipGetLastError();
+  return 0;
 }
 
 }  // namespace ivg

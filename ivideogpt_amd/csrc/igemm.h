@@ -90,6 +90,8 @@ struct SkinnyArgs {
   bool w_shared = false;      // the weight matrix is read by OTHER engines' launches too within the same few microseconds (replicas over one
                               // copy of the weights, batches in flight): default cache policy instead of non-temporal requests
   int lds_kb = 0;             // LDS budget of a workgroup in KiB (the calling engine's policy); 0: the process default (IVG_DECODE_LDS_KB)
+  int kind = -1;              // which GEMM of the decode step this is (0 q/k/v, 1 o-proj, 2 gate/up, 3 down, 4 lm_head; -1: unknown) -- selects the
+                              // per-kind budget of the batches-in-flight profile (switches.h: inflight_kb)
   long long* dbg = nullptr;   // development: phase stamps of the second / third-generation kernel (tools/ubench/dgemm_phase.hip)
   // cache warm-up (dgemm3.hip): the weight matrix the NEXT launch of the chain streams, as next_tiles contiguous tiles of
   // next_tile_bytes (= rows one workgroup of that launch owns x K bytes); tile t is pulled by a workgroup of XCD t % 8

@@ -1,7 +1,9 @@
 // The switch table of libivg (switches.h): read from the environment, published through one atomic pointer.
 #include "switches.h"
 
+#include <algorithm>
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 
@@ -29,6 +31,14 @@ static Switches read_env() {
   s.conv_cap = dv("IVG_CONV_CAP", 0) == 1;
   s.decode_w_shared = dv("IVG_DECODE_W_SHARED", 1) != 0;
   s.inflight_warm = dv("IVG_INFLIGHT_WARM", 0) != 0;
+  s.dg2_mf_cap = dv("IVG_DG2_MF_CAP", 0);
+  if (s.dg2_mf_cap != 1 && s.dg2_mf_cap != 2) s.dg2_mf_cap = 0;
+  s.inflight_gemm256 = dv("IVG_INFLIGHT_GEMM256", 1) != 0;
+  if (const char* v = dev ? getenv("IVG_INFLIGHT_KB") : nullptr) {
+    int k[5] = {0, 0, 0, 0, 0};
+    if (sscanf(v, "%d,%d,%d,%d,%d", &k[0], &k[1], &k[2], &k[3], &k[4]) == 5)
+      for (int i = 0; i < 5; ++i) s.inflight_kb[i] = (k[i] >= 16 && k[i] <= 160) ? k[i] : 0;
+  }
   s.graph = env_int("IVG_GRAPH", 0) == 1;
   s.decode_lds_kb = env_int("IVG_DECODE_LDS_KB", 160);
   if (s.decode_lds_kb < 16 || s.decode_lds_kb > 160) s.decode_lds_kb = 160;
@@ -39,7 +49,8 @@ bool Switches::operator==(const Switches& o) const {
   return conv3x3 == o.conv3x3 && subpixel == o.subpixel && gemm256 == o.gemm256 && dg3 == o.dg3 && flash_prefill == o.flash_prefill &&
          flash_xatt == o.flash_xatt && gn_fuse == o.gn_fuse && gn_apply_fuse == o.gn_apply_fuse && x3 == o.x3 && graph == o.graph &&
          dg3_warm == o.dg3_warm && conv_cap == o.conv_cap && decode_lds_kb == o.decode_lds_kb && decode_w_shared == o.decode_w_shared &&
-         inflight_warm == o.inflight_warm;
+         inflight_warm == o.inflight_warm && dg2_mf_cap == o.dg2_mf_cap && inflight_gemm256 == o.inflight_gemm256 &&
+         std::equal(inflight_kb, inflight_kb + 5, o.inflight_kb);
 }
 
 // A reload that CHANGES the table publishes a new immutable one through one atomic pointer and never frees or rewrites the old

@@ -29,13 +29,20 @@
 //   IVG_CONV_CAP             0        1: conv3x3 grids at ONE workgroup per CU (LDS padded past half a CU's 160 KiB)
 //   IVG_DECODE_W_SHARED      1        engines with the batches-in-flight profile: 0 = non-temporal weight requests as for one batch alone
 //   IVG_INFLIGHT_WARM        0        the same engines: 1 = keep warming the next launch's weights
+//   IVG_DG2_MF_CAP           0        the same engines: > 0 caps the row tiles per workgroup of the second-generation decode GEMMs (smaller
+//                                        workgroups, more of them co-resident per CU; row grouping only -- never a summation order)
+//   IVG_INFLIGHT_KB          -        "q,o,g,d,l": per-kind LDS budgets (KiB, 0 = the engine's) of the same engines' decode GEMMs (q/k/v, o-proj,
+//                                        gate/up, down, lm_head): which GEMMs may keep their whole K range in flight (one memory round trip)
+//   IVG_INFLIGHT_GEMM256     1        the same engines: 0 = prompt-pass GEMMs on the 256-thread implicit-GEMM kernel instead of the 1024-thread /
+//                                        128 KiB gemm256l workgroups (which wait for a whole CU to drain while other batches are in flight)
 #pragma once
 
 namespace ivg {
 
 struct Switches {
   int conv3x3 = 1, subpixel = 1, gemm256 = 1, dg3 = 1, flash_prefill = 1, flash_xatt = 1, gn_fuse = 1, gn_apply_fuse = 1, x3 = 1;
-  int graph = 0, dg3_warm = 1, conv_cap = 0, decode_lds_kb = 160, decode_w_shared = 1, inflight_warm = 0;
+  int graph = 0, dg3_warm = 1, conv_cap = 0, decode_lds_kb = 160, decode_w_shared = 1, inflight_warm = 0, dg2_mf_cap = 0, inflight_gemm256 = 1;
+  int inflight_kb[5] = {0, 0, 0, 0, 0};
   bool operator==(const Switches& o) const;
 };
 

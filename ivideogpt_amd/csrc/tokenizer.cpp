@@ -79,7 +79,8 @@ int Run::gemm(DType dt, const IgemmArgs& a0, double flops, double bytes) {
   IgemmArgs a = a0;
   a.x3 = dt == F32 && x3 && sw().x3;
   prof_begin(dt, flops, bytes);
-  int rc = launch_gemm256(a, dt, st);   // large dense GEMMs (prompt pass); -1 = not covered
+  int rc = -1;
+  if (!(e->in_flight() && !sw().inflight_gemm256)) rc = launch_gemm256(a, dt, st);   // large dense GEMMs (prompt pass); -1 = not covered
   if (rc == -1) rc = launch_igemm(a, dt, st);
   CK(rc);
   prof_end(dt);

@@ -246,7 +246,10 @@ static int step_body(ivg_engine* e, hipStream_t st, const GenBuf& g, int B, cons
   };
   auto layer_args = [&](int l, SkinnyArgs* g) {
     const LayerW& w = e->layers[l];
-    for (int k = 0; k < 4; ++k) { g[k].x3 = e->llm_x3 && sw().x3; g[k].lds_kb = e->decode_lds_kb; g[k].w_shared = w_shared; }
+    for (int k = 0; k < 4; ++k) {
+      g[k].x3 = e->llm_x3 && sw().x3; g[k].lds_kb = e->decode_lds_kb; g[k].w_shared = w_shared; g[k].kind = k;
+      if (in_flight && sw().inflight_kb[k] > 0) g[k].lds_kb = sw().inflight_kb[k];
+    }
     SkinnyArgs& s = g[0];
     s.X = x; s.W = w.wqkv; s.Y = qkv; s.M = B; s.N = 3 * H; s.K = H; s.ldx = H; s.ldw = H; s.ldy = 3 * H;
     s.flags = SK_NORM; s.eps = c.rms_norm_eps;
@@ -260,7 +263,8 @@ static int step_body(ivg_engine* e, hipStream_t st, const GenBuf& g, int B, cons
   };
   SkinnyArgs lm;
   lm.X = x; lm.W = e->lm_head; lm.Y = logits; lm.M = B; lm.N = V; lm.K = H; lm.ldx = H; lm.ldw = H; lm.ldy = V;
-  lm.flags = IG_OUT_F32 | SK_NORM; lm.eps = c.rms_norm_eps; lm.lds_kb = e->decode_lds_kb; lm.w_shared = w_shared;
+  lm.flags = IG_OUT_F32 | SK_NORM; lm.eps = c.rms_norm_eps; lm.lds_kb = e->decode_lds_kb; lm.w_shared = w_shared; lm.kind = 4;
+  if (in_flight && sw().inflight_kb[4] > 0) lm.lds_kb = sw().inflight_kb[4];
   lm.bump = (int*)state;  // pos += 1, j += 1 once the last reader of this chain's state (its last attention) is done
   SkinnyArgs cur[4], nxt[4];
   layer_args(0, cur);
@@ -331,6 +335,8 @@ int Run::generate(const int64_t* prompt, int64_t prompt_stride, int B, int L0, i
     if (shared) {   // every trajectory starts from a copy of its group's prompt; groups g_lo .. g_hi have rows in this chunk
       const int g_lo = b0 / group, g_hi = (b0 + Bc - 1) / group;
       g.sh_P = L0 - 1; g.sh_G = group; g.sh_row0 = g_lo * group - b0;
+      // (attending the prompt rows once per 16 trajectories on the matrix cores -- tools/ubench/prefix_attn_mfma.hip -- shortens the
+      // attention launch but needs a launch of its own per layer: every call measured slower, profiles/r06_shared_prefix_mfma_ab.txt)
       CK(launch_expand_prompt_rows(prompt, prompt_stride, g.ids, g.ids_ld, Bc, L0, group, b0, st));
       IVG_TRY(prefill(prompt + (long)g_lo * prompt_stride, prompt_stride, g_hi - g_lo + 1, L0 - 1, nullptr, 0, ctx, false, nullptr, nullptr, nullptr));
     } else if (!embeds)

@@ -278,6 +278,12 @@ class Engine:
         self.check(self.lib.ivg_profile_attn_fit(self.h, C.byref(f), C.byref(r)), "profile_attn_fit")
         return f.value, r.value
 
+    def profile_gemm_kinds(self):
+        """{kind: (mean launch window in us, launches)} of the decode-step GEMMs, after profile_read(IVG_K_DECODE_GEMM)."""
+        us, n = (C.c_double * 5)(), (C.c_int64 * 5)()
+        self.check(self.lib.ivg_profile_gemm_kinds(self.h, us, n), "profile_gemm_kinds")
+        return {k: (us[i], n[i]) for i, k in enumerate(("qkv", "o_proj", "gate_up", "down", "lm_head"))}
+
     def profile_read(self, kclass):
         st = _lib.IvgProfileStats()
         self.check(self.lib.ivg_profile_read(self.h, kclass, C.byref(st)), "profile_read")

@@ -609,6 +609,29 @@ def test_gemm256_half_width_tile_for_128_output_channels(switches):
     assert (outs[0].float() - outs[1].float()).abs().max().item() < 0.1      # two kernels, one result up to bf16 rounding
 
 
+def test_gemm256_rows_beyond_2gib_run_as_row_ranges():
+    """A dense 1x1 layer whose activations exceed the kernel's 32-bit operand offsets (the 256 -> 128 shortcuts of the top decoder level
+    at 256 x 256: 14.7 M rows; here 4.2 M rows x 256 channels = 2.15 GB): the launcher splits the rows into ranges of < 2 GiB
+    (round 6; such layers fell back to the implicit GEMM before).  Rows on both sides of the range boundary, the first and the ragged
+    last tile against fp64; bias + in-place residual."""
+    M, N, K = (1 << 22) + 333, 128, 256
+    rows_max = ((1 << 31) - 1) // (2 * K) // 256 * 256
+    assert 4096 < rows_max < M
+    g = torch.Generator(device=DEV).manual_seed(3)
+    Xd = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+    Wd = (torch.randn(N, K, device=DEV, generator=g) / K ** 0.5).to(torch.bfloat16)
+    bd = torch.randn(N, device=DEV, generator=g)
+    Y = torch.randn(M, N, device=DEV, generator=g).to(torch.bfloat16)
+    pick = torch.cat([torch.arange(0, 300), torch.arange(rows_max - 300, rows_max + 300), torch.arange(M - 400, M),
+                      torch.randint(0, M, (500,), generator=torch.Generator().manual_seed(1))])
+    ref = Xd[pick.to(DEV)].double().cpu() @ Wd.double().cpu().T + bd.double().cpu() + Y[pick.to(DEV)].double().cpu()
+    before = Y[rows_max + 100].clone()
+    igemm("bf16", Xd, Wd, Y, Y, bd, Win=M, Wout=M, Cin=K, ldx=K, N=N, ldw=K, c_pix=N, flags=1 | 4)
+    got = Y[pick.to(DEV)].double().cpu()
+    assert torch.isfinite(got).all() and rel_err(got, ref) < TOL["bf16"]
+    assert not torch.equal(Y[rows_max + 100], before), "rows of the second range were not written"
+
+
 @pytest.mark.parametrize("mode", ["plain", "bias_residual_inplace", "glu", "silu", "k_short", "k_odd_steps", "nimg"])
 def test_gemm256_large_dense(mode, switches):
     """256 x 256-tile GEMM of the prompt pass (bf16, rows not a multiple of 256): every epilogue against fp64, and bit-for-bit

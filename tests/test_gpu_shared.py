@@ -118,6 +118,13 @@ def test_shared_full_width_small_llama(dtype):
     m = make_llm(cfg, sd, dtype)
     out = m.generate(prompt.repeat(t, 1).to(DEV), do_sample=True, top_k=100, max_new_tokens=n_new, uniforms=u.to(DEV), shared_context=t).cpu()
     assert torch.equal(out[1], out[3]), "rows of a group with the same uniforms must be identical"
+    if dtype == "bf16":   # a larger group over several 16-row tiles of the decode GEMMs
+        t2 = 24
+        u2 = torch.rand(t2, n_new, generator=gen)
+        u2[11], u2[17] = u2[2], u2[2]
+        o2 = m.generate(prompt.repeat(t2, 1).to(DEV), do_sample=True, top_k=100, max_new_tokens=n_new, uniforms=u2.to(DEV), shared_context=t2).cpu()
+        assert torch.equal(o2[2], o2[11]) and torch.equal(o2[2], o2[17]) and (o2[0] != o2[1]).any()
+        assert ((o2 >= 0) & (o2 < cfg["vocab_size"])).all() and torch.equal(o2[:, :514], prompt.repeat(t2, 1))
     assert ((out >= 0) & (out < cfg["vocab_size"])).all() and torch.equal(out[:, :514], prompt.repeat(t, 1))
     if dtype == "fp32":
         ora = oracle_llama(cfg, sd)
@@ -125,6 +132,65 @@ def test_shared_full_width_small_llama(dtype):
         assert_sampled_rollout_matches(out, ref, ora, u, 100, 514, what="full-width shared rollout")
         og = m.generate(prompt.repeat(2, 1).to(DEV), do_sample=False, max_new_tokens=n_new, shared_context=2).cpu()
         assert torch.equal(og, generate_cached(ora, prompt.repeat(2, 1), n_new))
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp32"])
+@pytest.mark.parametrize("B,G,row0,P,pos", [(40, 40, 0, 513, 600), (37, 16, -5, 256, 256), (100, 100, 0, 513, 513), (7, 3, 0, 65, 97), (16, 200, -150, 513, 750),
+                                            (9, 1, 0, 0, 300)])
+def test_shared_decode_attention_step_vs_fp64(B, G, row0, P, pos, dt):
+    """One decode-attention step of a shared-context rollout at op level (ivg_op_shared_decode_attn -> decode_attn_kernel SHARED) against
+    softmax(q k^T / 8) v in fp64 over the keys each trajectory logically sees -- its group's prompt rows [0, P) (stored ONCE, in cache
+    row `slot`), its own rows [P, pos) and the token being fed -- with RoPE at `pos`.  Groups that start before / end after the chunk
+    (row0 < 0, ragged last group), a prefix that is not a multiple of the row block, pos == P (no own rows yet), G = 1 (the plain
+    kernel), and the k / v append."""
+    import ctypes as C
+    from ivideogpt_amd import _lib
+    l = _lib.load()
+    heads, hd, Lmax = 12, 64, 1024
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float32
+    gen = torch.Generator().manual_seed(B + G + pos)
+    n_slots = (B - 1 - row0) // G + 1
+    rows = max(B, n_slots)
+    kc = (torch.randn(rows, heads, Lmax, hd, generator=gen) * 1.2).to(tdt)
+    vc = torch.randn(rows, heads, Lmax, hd, generator=gen).to(tdt)
+    qkv = (torch.randn(B, 3 * heads * hd, generator=gen) * 1.5).to(tdt)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    fr = torch.arange(Lmax, dtype=torch.float32)[:, None] * inv[None, :]
+    cos, sin = fr.cos().to(tdt).float(), fr.sin().to(tdt).float()          # tables as the engine holds them (rounded through the model dtype)
+
+    def rope(x):                                                             # x (B, heads, hd) in T -> roped, rounded to T
+        x = x.float()
+        a, b = x[..., :hd // 2], x[..., hd // 2:]
+        c, s_ = cos[pos], sin[pos]
+        return torch.cat([a * c - b * s_, b * c + a * s_], -1).to(tdt)
+    q = rope(qkv[:, :heads * hd].view(B, heads, hd))
+    kn = rope(qkv[:, heads * hd:2 * heads * hd].view(B, heads, hd))
+    vn = qkv[:, 2 * heads * hd:].view(B, heads, hd)
+    ref = torch.empty(B, heads, hd, dtype=torch.float64)
+    for b in range(B):
+        s_ = (b - row0) // G
+        K = torch.cat([kc[s_, :, :P], kc[b, :, P:pos], kn[b][:, None]], 1).double()     # (heads, pos + 1, hd)
+        V = torch.cat([vc[s_, :, :P], vc[b, :, P:pos], vn[b][:, None]], 1).double()
+        w = torch.softmax(torch.einsum("hd,hkd->hk", q[b].double(), K) / 8.0, -1)
+        ref[b] = torch.einsum("hk,hkd->hd", w, V)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    cd, sd = cos.to(DEV), sin.to(DEV)
+    kd, vd, qd = kc.to(DEV), vc.to(DEV), qkv.to(DEV)
+    out = torch.full((B, heads * hd), float("nan"), dtype=tdt, device=DEV)
+    rc = l.ivg_op_shared_decode_attn(C.c_void_p(qd.data_ptr()), C.c_void_p(kd.data_ptr()), C.c_void_p(vd.data_ptr()), C.c_void_p(out.data_ptr()),
+                                     C.c_void_p(cd.data_ptr()), C.c_void_p(sd.data_ptr()), B, heads, hd, Lmax, pos, P, G, row0, 1 if dt == "bf16" else 0, st)
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    got = out.float().view(B, heads, hd).cpu().double()
+    assert torch.isfinite(got).all()
+    err = ((got - ref).abs().max() / ref.abs().max()).item()
+    assert err < (1.5e-2 if dt == "bf16" else 2e-5), f"rel err {err:.3e}"
+    # the append: position `pos` of every trajectory's own cache row holds the roped k (up to one rounding: the kernel contracts the
+    # rotation into fused multiply-adds) and, bit for bit, the v of the fed token
+    kgot = kd[:B, :, pos].float().cpu()
+    assert (kgot - kn.float()).abs().max().item() <= (2.0 ** -7 if dt == "bf16" else 1e-5) * kn.float().abs().max().item()
+    assert torch.equal(vd[:B, :, pos].cpu(), vn)
+    assert torch.equal(kd[:, :, :pos].cpu(), kc[:, :, :pos]), "cached rows must not be touched"
 
 
 # ------------------------------------------------------------------------------------------------ detokenize
