@@ -28,6 +28,7 @@ static Switches read_env() {
   s.gn_apply_fuse = dv("IVG_GN_APPLY_FUSE", 1) != 0;
   s.x3 = dv("IVG_X3", 1) != 0;
   s.dg3_warm = dv("IVG_DG3_WARM", 1) != 0;
+  s.warm_gate_up = dv("IVG_WARM_GATE_UP", 0) != 0;
   s.conv_cap = dv("IVG_CONV_CAP", 0) == 1;
   s.decode_w_shared = dv("IVG_DECODE_W_SHARED", 1) != 0;
   s.inflight_warm = dv("IVG_INFLIGHT_WARM", 0) != 0;
@@ -48,7 +49,7 @@ static Switches read_env() {
 bool Switches::operator==(const Switches& o) const {
   return conv3x3 == o.conv3x3 && subpixel == o.subpixel && gemm256 == o.gemm256 && dg3 == o.dg3 && flash_prefill == o.flash_prefill &&
          flash_xatt == o.flash_xatt && gn_fuse == o.gn_fuse && gn_apply_fuse == o.gn_apply_fuse && x3 == o.x3 && graph == o.graph &&
-         dg3_warm == o.dg3_warm && conv_cap == o.conv_cap && decode_lds_kb == o.decode_lds_kb && decode_w_shared == o.decode_w_shared &&
+         dg3_warm == o.dg3_warm && warm_gate_up == o.warm_gate_up && conv_cap == o.conv_cap && decode_lds_kb == o.decode_lds_kb && decode_w_shared == o.decode_w_shared &&
          inflight_warm == o.inflight_warm && dg2_mf_cap == o.dg2_mf_cap && inflight_gemm256 == o.inflight_gemm256 &&
          std::equal(inflight_kb, inflight_kb + 5, o.inflight_kb);
 }

@@ -26,6 +26,7 @@
 //   IVG_GN_APPLY_FUSE        1        0: GroupNorm + SiLU as a separate apply pass (1: inside the consuming conv3x3's halo staging)
 //   IVG_X3                   1        0: the fp32 decode path of the tokenizer on f32-input MFMAs (1: split-bf16 "x3" convolutions)
 //   IVG_DG3_WARM             1        0: decode GEMMs do not pull the next launch's weights toward the chip
+//   IVG_WARM_GATE_UP         0        1: o-proj also warms the gate/up matrix (round 5's behaviour; measured neutral in time, 1.6 x the traffic)
 //   IVG_CONV_CAP             0        1: conv3x3 grids at ONE workgroup per CU (LDS padded past half a CU's 160 KiB)
 //   IVG_DECODE_W_SHARED      1        engines with the batches-in-flight profile: 0 = non-temporal weight requests as for one batch alone
 //   IVG_INFLIGHT_WARM        0        the same engines: 1 = keep warming the next launch's weights
@@ -41,7 +42,7 @@ namespace ivg {
 
 struct Switches {
   int conv3x3 = 1, subpixel = 1, gemm256 = 1, dg3 = 1, flash_prefill = 1, flash_xatt = 1, gn_fuse = 1, gn_apply_fuse = 1, x3 = 1;
-  int graph = 0, dg3_warm = 1, conv_cap = 0, decode_lds_kb = 160, decode_w_shared = 1, inflight_warm = 0, dg2_mf_cap = 0, inflight_gemm256 = 1;
+  int graph = 0, dg3_warm = 1, warm_gate_up = 0, conv_cap = 0, decode_lds_kb = 160, decode_w_shared = 1, inflight_warm = 0, dg2_mf_cap = 0, inflight_gemm256 = 1;
   int inflight_kb[5] = {0, 0, 0, 0, 0};
   bool operator==(const Switches& o) const;
 };

@@ -237,8 +237,13 @@ static int step_body(ivg_engine* e, hipStream_t st, const GenBuf& g, int B, cons
   const bool warm = !in_flight || sw().inflight_warm;
   // every launch also pulls the weight tiles of the NEXT launch of the chain toward the CUs that will consume them (dgemm3.hip): the
   // dependent GEMM then starts on (Infinity-)cache hits instead of a cold HBM stream
+  // Conditional per shape (round 6, profiles/r06_warmup_by_kind.txt): the gate/up matrix -- half of a layer's weight bytes -- is NOT warmed:
+  // requesting its 9.4 MB under o-proj lengthens o-proj by what it then saves gate/up (3.36 / 4.91 us warmed vs 2.9 / 5.35 cold), and
+  // those requests were most of the class's counted traffic (2.4 x the algorithmic bytes; Infinity-Cache re-reads).  q/k/v, o-proj, down
+  // and lm_head keep their warm-up (0.4 - 1.8 us per launch each).
   auto link_next = [&](SkinnyArgs& cur, const SkinnyArgs& nxt) {
     if (!warm) return;
+    if ((nxt.flags & IG_GLU) && !sw().warm_gate_up) return;
     int rows = dgemm3_w_rows_per_block(nxt, dt);
     if (rows <= 0) rows = dgemm_w_rows_per_block(nxt, dt);   // the next launch runs on the second-generation kernel
     if (rows <= 0 || nxt.ldw != nxt.K) return;
