@@ -605,8 +605,6 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   const int b = blockIdx.x / heads, h = blockIdx.x % heads;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int sub = tid % lpk, grp = tid / lpk;
-  const int pos = state->pos;        // position of the token being fed = number of cached keys
-  const int n_keys = pos + 1;
   const int H = heads * hd, half = hd / 2;
   const float scale = rsqrtf((float)hd);
   T* kb = kc + ((long)b * heads + h) * Lmax * hd;
@@ -618,7 +616,11 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   // rows beyond the cached keys are not requested (on average half of the last block of 256: re-reading a clamped row instead
   // measured +1 us per launch); 32-bit byte offsets from the (wave-uniform) head base
   const unsigned lane_off = (unsigned)(sub * VEC) * (unsigned)sizeof(T);
-  auto load_rows = [&](Chunk16 (&dst)[UNR], const T* base, int t0) {
+  // `limit`: rows below it are requested.  Every call but the first passes the number of cached keys; the FIRST round of key rows goes
+  // out before the step counter is even read (limit = Lmax: the rows exist in the cache buffer whatever they hold; rows >= pos are
+  // never used -- the score and value passes test t < pos) -- the counter's load, a dependent memory round trip at the head of every
+  // launch, then overlaps that round instead of preceding it (round 6)
+  auto load_rows = [&](Chunk16 (&dst)[UNR], const T* base, int t0, int limit) {
     const char* bb = (const char*)base;
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
@@ -626,7 +628,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
       const char* rb = bb;
       if constexpr (SHARED) rb = t < sh_P ? bb + sh_delta : bb;
       const Chunk16* src = (const Chunk16*)(rb + ((unsigned)(t * hd) * (unsigned)sizeof(T) + lane_off));
-      dst[u] = t < pos ? ((NT && !SHARED) ? __builtin_nontemporal_load(src) : *src) : Chunk16{0u, 0u, 0u, 0u};
+      dst[u] = t < limit ? ((NT && !SHARED) ? __builtin_nontemporal_load(src) : *src) : Chunk16{0u, 0u, 0u, 0u};
     }
   };
   Chunk16 cur[UNR], nxt[UNR];
@@ -636,12 +638,14 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
   T va = from_f32<T>(0.f), vb2 = from_f32<T>(0.f);
   if (tid < half) {
     const T* row = qkv + (long)b * 3 * H + h * hd;
-    rc = cosT[(long)pos * half + tid]; rs = sinT[(long)pos * half + tid];
     q1 = to_f32(row[tid]); q2 = to_f32(row[tid + half]);
     k1 = to_f32(row[H + tid]); k2 = to_f32(row[H + tid + half]);
     va = row[2 * H + tid]; vb2 = row[2 * H + tid + half];
   }
-  load_rows(cur, kb, 0);  // the first key rows are in flight while q is roped
+  load_rows(cur, kb, 0, Lmax);  // the first key rows are in flight while the step counter arrives and q is roped
+  const int pos = state->pos;        // position of the token being fed = number of cached keys
+  const int n_keys = pos + 1;
+  if (tid < half) { rc = cosT[(long)pos * half + tid]; rs = sinT[(long)pos * half + tid]; }
   if (tid < half) {  // RoPE (HF rotate_half) of q and the new k; append k, v to the cache
     const T qa = from_f32<T>(q1 * rc - q2 * rs), qb = from_f32<T>(q2 * rc + q1 * rs);
     const T ka = from_f32<T>(k1 * rc - k2 * rs), kb2 = from_f32<T>(k2 * rc + k1 * rs);
@@ -675,12 +679,12 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
     int t0 = 0;
     bool in_nxt = false;   // the rows to consume next are in `nxt`
     while (t0 < pos) {
-      if (t0 + step < pos) load_rows(nxt, kb, t0 + step); else load_rows(nxt, vb, 0);
+      if (t0 + step < pos) load_rows(nxt, kb, t0 + step, pos); else load_rows(nxt, vb, 0, pos);
       scores(cur, t0);
       t0 += step;
       in_nxt = true;
       if (t0 >= pos) break;
-      if (t0 + step < pos) load_rows(cur, kb, t0 + step); else load_rows(cur, vb, 0);
+      if (t0 + step < pos) load_rows(cur, kb, t0 + step, pos); else load_rows(cur, vb, 0, pos);
       scores(nxt, t0);
       t0 += step;
       in_nxt = false;
@@ -723,10 +727,10 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const T* __restrict__ 
     }
   };
     for (int t0 = 0; t0 < pos; t0 += 2 * step) {  // cur holds value rows [t0, t0 + step) (requested during pass A / the last iteration)
-      if (t0 + step < pos) load_rows(nxt, vb, t0 + step);
+      if (t0 + step < pos) load_rows(nxt, vb, t0 + step, pos);
       weighted(cur, t0);
       if (t0 + step >= pos) break;
-      if (t0 + 2 * step < pos) load_rows(cur, vb, t0 + 2 * step);
+      if (t0 + 2 * step < pos) load_rows(cur, vb, t0 + 2 * step, pos);
       weighted(nxt, t0 + step);
     }
   if (grp == 0) {
