@@ -75,8 +75,11 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
   constexpr int RING = SUBPIX ? 4 : 3;     // weight ring slots of the one-step loop (slot of step s = s % RING must be a function of the tap)
   constexpr int VEC = Traits<T>::VEC;
   constexpr int CK = 4 * VEC;              // channels per chunk: one 64-byte LDS row per halo pixel (one MFMA K-step)
-  constexpr int WN = BN / 2;               // 8 waves = 4 (pixels) x 2 (channels)
-  constexpr int FM = 4, FN = WN / 16;
+  // 8 waves = 4 (pixel groups of 64) x 2 (channel halves); BN = 16 (round 6: the decoders' tail, 3 output channels -- the 64-channel
+  // instance computed 61 channels nobody stores): 8 pixel groups of 32 x one 16-channel fragment
+  constexpr int PG = BN == 16 ? 8 : 4;     // pixel groups (waves along the tile's pixels)
+  constexpr int WN = BN == 16 ? 16 : BN / 2;
+  constexpr int FM = 256 / PG / 16, FN = WN / 16;
   constexpr int W_BYTES = BN * 64;
   // ---- tile geometry
   constexpr int TH = 256 / TW, TWS = TW == 32 ? 5 : 4;
@@ -94,8 +97,8 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform values stay in scalar registers
   const int lr = lane & 15, lg = lane >> 4;
-  const int wm = wave & 3, wn = wave >> 2;
-  const int pyw = TW == 16 ? wm * 4 : wm * 2;
+  const int wm = BN == 16 ? wave : (wave & 3), wn = BN == 16 ? 0 : (wave >> 2);
+  const int pyw = wm * (256 / PG / TW);    // first tile row of this wave's pixels (64 / TW rows per group; 32 / TW for BN = 16)
 
   // ---- XCD-aware block order (blocks b, b+8, ... share an XCD/L2): give each XCD a contiguous run of work items
   // with the N tile fastest, so the N tiles of one spatial tile hit the same L2 (bijective for any grid size)
@@ -149,13 +152,13 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
   // counts the same number of outstanding transfers.
   unsigned woff;
   {
-    const int q = BN == 128 ? tid : (tid & 255);
+    const int q = BN == 128 ? tid : (BN == 64 ? (tid & 255) : (tid & 63));   // (BN = 16: one 1 KiB transfer, repeated by every wave)
     const int n = q >> 2, slot = q & 3;
     const int c = slot ^ swz_key(n);
     const int nrow = min(n_base + n, p.N - 1);
     woff = (unsigned)((SUBPIX ? phase * p.N + nrow : nrow) * p.ldw) * (unsigned)sizeof(T) + (unsigned)(c * VEC * (int)sizeof(T));
   }
-  const int w_dst = (BN == 128 ? wave : (wave & 3)) * 1024;
+  const int w_dst = (BN == 128 ? wave : (BN == 64 ? (wave & 3) : 0)) * 1024;
   auto issue_w = [&](int tap, int chunk, int ring) {
     // (the 64-byte-per-row shape of these requests is not what bounds the kernel: requesting the same bytes as whole 128-byte
     // lines -- a probe with wrong results -- changed nothing, profiles/r02_conv3x3_wline_probe.txt)
@@ -500,7 +503,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
         }
       }
       if (staged) {
-        unsigned char* dst = smem + (wm * 64 + b * 16 + lr) * PITCH + (wn * WN + a * 16 + lg * 4) * (int)sizeof(T);
+        unsigned char* dst = smem + (wm * (FM * 16) + b * 16 + lr) * PITCH + (wn * WN + a * 16 + lg * 4) * (int)sizeof(T);
         if constexpr (sizeof(T) == 2) *(bf16x4*)dst = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
         else *(f32x4*)dst = f32x4{v[0], v[1], v[2], v[3]};
       } else if (flags & IG_OUT_F32) {
@@ -523,8 +526,8 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
     }
   }
   if (gn) {
-    float* ch_s = (float*)(smem + p.gn_off);          // [4 pixel waves][BN channels]
-    float* ch_q = ch_s + (4) * BN;
+    float* ch_s = (float*)(smem + p.gn_off);          // [PG pixel waves][BN channels]
+    float* ch_q = ch_s + (PG) * BN;
 #pragma unroll
     for (int a = 0; a < FN; ++a)
 #pragma unroll
@@ -536,12 +539,12 @@ __global__ __launch_bounds__(512, 4) void conv3x3_kernel(const Conv3Dev p) {
   if (staged || gn) __syncthreads();
   if (gn && tid < p.gn_groups) {
     const float* ch_s = (const float*)(smem + p.gn_off);
-    const float* ch_q = ch_s + (4) * BN;
+    const float* ch_q = ch_s + (PG) * BN;
     const int cpg = p.N / p.gn_groups;
     const int c0 = max(tid * cpg, n_base), c1 = min(min((tid + 1) * cpg, n_base + BN), p.N);
     double a1 = 0.0, a2 = 0.0;
     for (int c = c0; c < c1; ++c)
-      for (int w = 0; w < 4; ++w) { a1 += (double)ch_s[w * BN + c - n_base]; a2 += (double)ch_q[w * BN + c - n_base]; }
+      for (int w = 0; w < PG; ++w) { a1 += (double)ch_s[w * BN + c - n_base]; a2 += (double)ch_q[w * BN + c - n_base]; }
     const long chunk = (long)(SUBPIX ? t_in * 4 + phase : t_in) * p.tiles_n + tile_n;
     p.gn_part[((long)img * p.tiles_per_img * (SUBPIX ? 4 : 1) * p.tiles_n + chunk) * p.gn_groups + tid] = double2{a1, a2};
   }
@@ -572,7 +575,7 @@ static int launch_c3(const Conv3Dev& d, int nimg, hipStream_t stream) {
   dd.stage_ok = stage <= 80 * 1024;                      // keeps two workgroups per CU (fp32 x 128 channels stores directly)
   if (dd.stage_ok && smem < stage) smem = stage;
   // the statistics partials of the epilogue sit behind the staging tile (the main-loop buffers are dead by then)
-  if (d.gn_part) { dd.gn_off = dd.stage_ok ? ((stage + 15) & ~15) : 0; smem = std::max(smem, dd.gn_off + 2 * 4 * BN * 4); }
+  if (d.gn_part) { dd.gn_off = dd.stage_ok ? ((stage + 15) & ~15) : 0; smem = std::max(smem, dd.gn_off + 2 * (BN == 16 ? 8 : 4) * BN * 4); }
   if constexpr (GNA) { dd.coef_off = (smem + 15) & ~15; smem = dd.coef_off + 2 * (4 * Traits<T>::VEC) * 8; }
   // IVG_CONV_CAP=1: ONE workgroup per CU -- the request is padded past half of a CU's 160 KiB, so a second workgroup of this grid
   // never fits beside the first and half of the LDS, of the wave slots (8 of 16 per SIMD pair) and of the registers stay free for the
@@ -614,7 +617,8 @@ int launch_conv3x3(const IgemmArgs& a, DType dtype, hipStream_t stream) {
   const int Ht = subpix ? a.Hin : Ho, Wt = subpix ? a.Win : Wo;   // the grid the 256-pixel tiles cover
   const int TW = Wt >= 32 ? 32 : Wt;   // 16x16 or 8x32 tiles: halo <= 10 x 34 pixels = 24 KiB per buffer
   if (TW != 16 && TW != 32) return -1;
-  const int bn = a.N > 64 ? 128 : 64;
+  // (16: the decoders' fused tail -- GroupNorm inside the staging, <= 16 output channels, bf16: one 16-channel fragment per wave)
+  const int bn = a.N > 64 ? 128 : ((a.N <= 16 && a.gn_in_coef && dtype == BF16 && !a.W_x3 && !a.ups) ? 16 : 64);
   const int TH = 256 / TW;
   if (Wt % TW != 0 || Ht % TH != 0) return -1;
   if (((uintptr_t)a.X & 15) || ((uintptr_t)a.W & 15)) return -1;
@@ -658,6 +662,7 @@ int launch_conv3x3(const IgemmArgs& a, DType dtype, hipStream_t stream) {
 #undef IVG_C3X_BN
 #undef IVG_C3X_TW
   }
+  if (gna && bn == 16) return IVG_C3_TW(bf16_t, 16, false, true, false);
   if (gna) return dtype == BF16 ? IVG_C3_BN(bf16_t, false, true, false) : IVG_C3_BN(float, false, true, false);
   // (measured per shape, profiles/r02_conv3x3_tpb.txt: +2 ... +3.5 % on the plain convolutions, -0.8 % on the upsampling ones,
   // whose 32-pixel-row instance also spills registers in the two-step form: those keep one step per barrier)
