@@ -343,6 +343,14 @@ int ivg_op_shared_decode_attn(const void* qkv, void* kc, void* vc, void* out, co
 /* one top-k draw per logits row [B][V] fp32 with the rollout's sampler (uniforms [B] in [0,1), or NULL = greedy): HF
  * TemperatureLogitsWarper (logits / temperature, > 0) + TopKLogitsWarper + softmax + draw as restated by oracle/llama.py
  * sample_from_logits */
+/* The 24-bit K / V cache of the IVG_F32X3 rollout (head_dim 64): per (trajectory, head) a block of Lmax * 192 bytes -- [Lmax][64] uint16,
+ * the upper halves of the fp32 values rounded to 24 bits (nearest even), then [Lmax][64] uint8, the next byte.  ivg_op_kv24_pack: fp32
+ * rows [0, L) of k32 / v32 [BH][Lmax][64] -> the planes (what the prefill does per layer).  ivg_op_decode_attn24: one decode-attention
+ * step at cache position pos (RoPE of q / the new k, append of the rounded k / v, softmax(q K^T / 8) V over [0, pos]); qkv [B][3 * heads * 64]
+ * fp32, out [B][heads * 64] fp32; P / G / row0 as ivg_op_shared_decode_attn (G = 1: every trajectory reads its own rows). */
+int ivg_op_kv24_pack(const float* k32, const float* v32, void* kc, void* vc, int BH, int L, int Lmax, ivg_stream stream);
+int ivg_op_decode_attn24(const float* qkv, void* kc, void* vc, float* out, const float* cos_t, const float* sin_t, int B, int heads, int Lmax, int pos,
+                         int P, int G, int row0, ivg_stream stream);
 int ivg_op_sample(const float* logits, int B, int V, int top_k, float temperature, const float* uniforms, int64_t* out, ivg_stream stream);
 /* test hook: launches since the library was loaded of the kernel family `name` selects ("decode_gemm_gen3" / "decode_gemm_gen2":
  * decode-step GEMMs the dispatcher sent to dgemm3.hip / dgemm.hip; "conv3x3_subpixel": upsampling convolutions run as four 2x2 phase

@@ -103,6 +103,8 @@ EXPORTS = {
     "ivg_op_xattn": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 7 + [C.c_void_p]),
     "ivg_op_conv_subpixel": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ivg_op_shared_decode_attn": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 9 + [C.c_void_p]),
+    "ivg_op_kv24_pack": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),
+    "ivg_op_decode_attn24": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 7 + [C.c_void_p]),
     "ivg_op_skinny": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]),
     "ivg_op_skinny_policy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 10 + [C.c_void_p]),
     "ivg_op_groupnorm": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_float, C.c_int, C.c_int, C.c_void_p]),

@@ -323,7 +323,8 @@ int ivg_create(const ivg_config* cfg, const ivg_tensor* weights, int n_weights, 
   if (cfg->num_layers > 0) {
     int rc = build_transformer(e); if (rc) return bail(rc);
     const int kb = std::min(cfg->max_batch, 128);
-    const size_t kvb = (size_t)cfg->num_layers * 2 * kb * e->heads * e->Lmax * e->hd * dtype_size(e->llm_dt);
+    e->kv24 = e->llm_x3 && e->hd == 64 && sw().x3 && sw().kv24;   // (IVG_X3=0: an x3 engine IS the fp32 engine)
+    const size_t kvb = (size_t)cfg->num_layers * 2 * kb * e->heads * e->Lmax * e->hd * e->kv_elem_bytes();
     const size_t vtb = (size_t)kb * e->heads * e->hd * ((e->Lmax + 63) / 64 * 64) * dtype_size(e->llm_dt);
     e->gen_bytes = gen_buffer_bytes(e);
     if (hipMalloc((void**)&e->kv, kvb) != hipSuccess || hipMalloc((void**)&e->vt, vtb) != hipSuccess || hipMalloc((void**)&e->gen_buf, e->gen_bytes) != hipSuccess) {
@@ -694,7 +695,7 @@ int ivg_profile_read(ivg_engine* e, int k, ivg_profile_stats* out) {
         }
         if (t == 0 || s == ~0ull || t < s) continue;
         const double ms = (double)(t - s) * 1e-5;   // 100 MHz wall clock -> ms
-        const double bytes = 2.0 * e->attn_prof_B * e->heads * (double)(p + 1) * e->hd * dtype_size(e->llm_dt);
+        const double bytes = 2.0 * e->attn_prof_B * e->heads * (double)(p + 1) * e->hd * (double)e->kv_elem_bytes();
         out->launches++;
         out->total_ms += ms;
         out->total_bytes += bytes;
@@ -765,7 +766,8 @@ int ivg_op_igemm(const ivg_igemm_args* a, int dtype, ivg_stream stream) {
   g.c_img = a->c_img; g.c_pix = a->c_pix; g.c_ch = a->c_ch; g.c_grp = a->c_grp; g.c_grp_stride = a->c_grp_stride;
   g.flags = a->flags; g.alpha = a->alpha; g.nb0 = a->nb0; g.nb1 = a->nb1; g.nb2 = a->nb2;
   for (int i = 0; i < 3; ++i) { g.sa[i] = a->sa[i]; g.sw[i] = a->sw[i]; g.sy[i] = a->sy[i]; }
-  if (g.KH == 3 && g.KW == 3 && g.stride == 1) {  // same dispatch as the engine: LDS-halo kernel first
+  if (dtype == IVG_F32X3) { g.x3 = true; dtype = IVG_F32; }   // fp32 tensors, split-bf16 arithmetic: what Run::gemm sets for an x3 engine
+  if (g.KH == 3 && g.KW == 3 && g.stride == 1 && !g.x3) {  // same dispatch as the engine: LDS-halo kernel first
     const int rc = launch_conv3x3(g, (DType)dtype, (hipStream_t)stream);
     if (rc == 0) return IVG_OK;
     if (rc > 0) return IVG_ERR_HIP;
@@ -868,6 +870,7 @@ int ivg_op_conv_x3(const ivg_igemm_args* a, const void* w_x3, int groups, const 
 
 int64_t ivg_debug_counter(const char* name) {
   if (name && !strcmp(name, "conv3x3_subpixel")) return conv3x3_subpixel_launches();
+  if (name && !strcmp(name, "gemm256x3")) return gemm256x3_launches();
   if (name && !strcmp(name, "decode_gemm_gen3")) return decode_gemm_launches(3);
   if (name && !strcmp(name, "decode_gemm_gen2")) return decode_gemm_launches(2);
   return -1;
@@ -918,6 +921,25 @@ int ivg_op_shared_decode_attn(const void* qkv, void* kc, void* vc, void* out, co
   hipStream_t st = (hipStream_t)stream;
   int rc = launch_state_set(state, pos, 1, st);
   if (!rc) rc = launch_decode_attn(qkv, kc, vc, out, cos_t, sin_t, B, heads, hd, Lmax, state, nullptr, (DType)dtype, st, P, G, row0);
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(state);
+  return rc == 0 ? IVG_OK : (rc > 0 ? IVG_ERR_HIP : IVG_ERR_INVALID);
+}
+
+int ivg_op_kv24_pack(const float* k32, const float* v32, void* kc, void* vc, int BH, int L, int Lmax, ivg_stream stream) {
+  if (BH <= 0 || L < 0 || L > Lmax) return IVG_ERR_INVALID;
+  return launch_kv24_pack(k32, v32, kc, vc, BH, L, Lmax, (hipStream_t)stream) ? IVG_ERR_HIP : IVG_OK;
+}
+
+int ivg_op_decode_attn24(const float* qkv, void* kc, void* vc, float* out, const float* cos_t, const float* sin_t, int B, int heads, int Lmax, int pos,
+                         int P, int G, int row0, ivg_stream stream) {
+  // unit-test hook of one decode-attention step over the 24-bit K / V cache of the x3 rollout (decode_attn24_kernel; G > 1: SHARED)
+  if (B <= 0 || G < 1 || P < 0 || P > pos || pos >= Lmax || row0 > 0) return IVG_ERR_INVALID;
+  StepState* state = nullptr;
+  if (hipMalloc((void**)&state, sizeof(StepState)) != hipSuccess) return IVG_ERR_HIP;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = launch_state_set(state, pos, 1, st);
+  if (!rc) rc = launch_decode_attn24(qkv, kc, vc, out, cos_t, sin_t, B, heads, Lmax, state, nullptr, st, P, G, row0);
   (void)hipStreamSynchronize(st);
   (void)hipFree(state);
   return rc == 0 ? IVG_OK : (rc > 0 ? IVG_ERR_HIP : IVG_ERR_INVALID);

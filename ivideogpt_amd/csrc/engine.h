@@ -74,6 +74,8 @@ struct ivg_engine {
   bool clamp_out = false;   // detokenize writes clamp(frames, 0, 1) (conv_out epilogue) instead of the raw decoder output (ivg_set_output_clamp)
   ivg::DType enc_dt, dec_dt, llm_dt;   // element types in HBM
   bool dec_x3 = false, llm_x3 = false;  // IVG_F32X3: fp32 tensors, split-bf16 matrix arithmetic on that path
+  bool kv24 = false;         // x3 rollout, head_dim 64: the K / V cache keeps 24 of the 32 bits in two planes (llama_ops.hip: decode_attn24_kernel)
+  size_t kv_elem_bytes() const { return kv24 ? 3 : (llm_dt == ivg::BF16 ? 2 : 4); }
   // tokenizer
   ivg::TrunkW enc, cenc, dec, cdec;
   ivg::ConvW quant_conv, post_quant_conv, quant_linear, post_quant_linear;
@@ -86,7 +88,7 @@ struct ivg_engine {
   const float* rope_cos = nullptr; const float* rope_sin = nullptr;
   const float* act_w = nullptr; const float* act_b = nullptr; const float* rew_w = nullptr; const float* rew_b = nullptr;
   int heads = 0, hd = 0, Lmax = 0;
-  char* kv = nullptr;        // [layers][2][Bmax][heads][Lmax][hd]
+  char* kv = nullptr;        // [layers][2][Bmax][heads][Lmax][hd]  (kv24: [layers][2][Bmax][heads]{[Lmax][hd] u16 | [Lmax][hd] u8})
   char* vt = nullptr;        // [Bmax][heads][hd][Lmax] transposed V scratch for the prefill
   char* gen_buf = nullptr;   // persistent decode-step buffers (fixed addresses -> graph replay)
   size_t gen_bytes = 0;

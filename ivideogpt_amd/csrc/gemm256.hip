@@ -14,6 +14,7 @@
 //     the (now free) ring so that global stores are whole 16-byte runs of an output row;
 //   * XCD-aware block order: the N tiles of one M tile run on one XCD and share its L2 copy of the A slab.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 #include "igemm.h"
@@ -34,7 +35,8 @@ struct G256Dev {
 // W against 4 MB of L2 -> 129 x 9.4 MB = 1.2 GB from beyond the L2 per GEMM.  Blocked: the N tiles are taken in groups whose W
 // slabs fit the L2 (gn x 256 rows x K), every M tile is walked inside a group before the next group starts: W is fetched once
 // per XCD and group, A once per group (gate/up: 3-4 x 50 MB instead of 1.2 GB).
-__device__ __forceinline__ void g256_tile(const G256Dev& p, int v, int& tile_m, int& tile_n) {
+template <typename Dev>
+__device__ __forceinline__ void g256_tile(const Dev& p, int v, int& tile_m, int& tile_n) {
   const int per_group = p.gn * p.tiles_m;
   const int g = v / per_group, rem = v - g * per_group;
   const int gsize = min(p.gn, p.tiles_n - g * p.gn);
@@ -195,8 +197,191 @@ __global__ __launch_bounds__(1024) void gemm256l_kernel(const G256Dev p) {
   g256_epilogue<BN>(p, acc, smem, m0, n0, wm, wn, lr, lg, tid);
 }
 
+// ---- split-bf16 ("x3") instance (round 6): fp32 operands in HBM and in LDS, 256 x 256 output tile.  The prompt pass of the
+// 1e-3-compliant rollout mode (IVG_F32X3) ran on the 128 x 128 implicit GEMM (igemm_kernel<float, ..., X3>): 57 of the mode's 437 ms per
+// step.  Same whole-line staging as gemm256l_kernel -- a step is one 128-byte line per row = 32 fp32 elements of K, two stages of
+// 64 KiB (A | W) -- and the arithmetic of the other X3 kernels: a fragment slot (4 fp32 of K) is split in registers into
+// [bf16 hi(4) | bf16 lo(4)], the weight slot is duplicated into [w_hi | w_hi] and [w_lo | w_lo], and two K = 32 bf16 MFMAs produce all
+// four partial products with fp32 accumulation.  64 MFMAs per wave and stage (four per fragment pair) against the bf16 kernel's 32:
+// the per-CU ingest that bounds gemm256l (64 KiB per 2,048 matrix clocks) is halved here (64 KiB per 4,096).  fp32 output straight
+// from the registers (a lane owns 4 consecutive columns = one 16-byte store); epilogues as gemm256l.
+struct G256XDev {
+  const float* X; const float* W; float* Y; const float* R; const float* bias;
+  int M, N, K, ldx, ldw, ldy;
+  int tiles_n;
+  int flags;
+  int tiles_m, gn;
+};
+
+__device__ __forceinline__ Chunk16 g256_split_hi_lo(const Chunk16 raw) {
+  const f32x4 x = __builtin_bit_cast(f32x4, raw);
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const bf16_t hi = (bf16_t)x[j]; o[j] = hi; o[4 + j] = (bf16_t)(x[j] - (float)hi); }
+  return __builtin_bit_cast(Chunk16, o);
+}
+
+__global__ __launch_bounds__(1024) void gemm256x3_kernel(const G256XDev p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int wm = wave & 3, wn = wave >> 2;
+  const int nwg = gridDim.x;
+  int v;
+  {
+    const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  int tile_m, tile_n;
+  g256_tile(p, v, tile_m, tile_n);
+  const int m0 = tile_m * 256, n0 = tile_n * 256;
+  const int steps = p.K >> 5;          // 32 fp32 of K = one 128-byte line per row
+  const int r8 = lane >> 3, jj = lane & 7;
+  unsigned aoff[2], woff[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int r = h * 8 + r8;
+    const unsigned sw = (unsigned)(jj ^ ((r >> 1) & 7)) * 16u;
+    aoff[h] = (unsigned)min(m0 + wave * 16 + r, p.M - 1) * (unsigned)(p.ldx * 4) + sw;   // rows beyond M re-read row M - 1 (never stored)
+    woff[h] = (unsigned)(n0 + wave * 16 + r) * (unsigned)(p.ldw * 4) + sw;
+  }
+  const unsigned lds0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) const void*)smem;
+  auto issue = [&](int step) {
+    const unsigned base = lds0 + (step & 1) * G256L_STAGE + wave * 2048;
+    const char* xs = (const char*)p.X + (size_t)step * 128;
+    const char* ws = (const char*)p.W + (size_t)step * 128;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) g256l_dma16(xs, aoff[h], base + h * 1024);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) g256l_dma16(ws, woff[h], base + G256L_HALF + h * 1024);
+  };
+  f32x4 acc[4][4];   // [a: N fragment][b: M fragment]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fslot0 = lr * 8, fkey = (lr >> 1) & 7;
+  issue(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int s = 0; s < steps; ++s) {
+    if (s + 1 < steps) issue(s + 1);
+    const unsigned char* sa = smem + (s & 1) * G256L_STAGE;
+    const unsigned char* sw_ = sa + G256L_HALF;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int slot = fslot0 + ((tt * 4 + lg) ^ fkey);
+      Chunk16 xs[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) xs[b] = g256_split_hi_lo(*(const Chunk16*)(sa + ((wm * 4 + b) * 128 + slot) * 16));
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const Chunk16 ws = g256_split_hi_lo(*(const Chunk16*)(sw_ + ((wn * 4 + a) * 128 + slot) * 16));
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {   // one duplicated half live at a time (registers); an accumulator is revisited after 4 MFMAs
+          Chunk16 wd = Chunk16{ws[2 * h], ws[2 * h + 1], ws[2 * h], ws[2 * h + 1]};
+          asm volatile("" : "+v"(wd));
+#pragma unroll
+          for (int b0 = 0; b0 < 4; ++b0) {
+            const int b = ((a * 2 + h) & 1) ? 3 - b0 : b0;   // snake order: the activation fragment stays when the weight half changes
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wd), __builtin_bit_cast(bf16x8, xs[b]),
+                                                                acc[a][b], 0, 0, 0);
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  // ---- epilogue in registers: lane holds columns ncol .. ncol + 3 of row (wm * 64 + b * 16 + lr)
+  const int flags = p.flags;
+  const bool glu = flags & IG_GLU;
+  const int out_n0 = glu ? (n0 >> 1) : n0;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int m = m0 + wm * 64 + b * 16 + lr;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      if (glu && (a & 1)) continue;
+      float v4[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v4[r] = acc[a][b][r];
+      const int ncol = wn * 64 + a * 16 + lg * 4;
+      if (flags & IG_BIAS_N) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v4[r] += p.bias[n0 + ncol + r];
+      }
+      int ocol = ncol;
+      if (glu) {  // rows [16 gate | 16 up] per 32 packed weight rows: fragment a = gate, a + 1 = up of the same 16 outputs
+        const int a1 = a + 1 < 4 ? a + 1 : a;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v4[r] = silu_t<float>(v4[r]) * acc[a1][b][r];
+        ocol = (wn * 64 + a * 16) / 2 + lg * 4;
+      }
+      float* dst = p.Y + (long)m * p.ldy + out_n0 + ocol;
+      if (flags & IG_RESIDUAL) {
+        const f32x4 rv = *(const f32x4*)(p.R + (long)m * p.ldy + out_n0 + ocol);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v4[r] += rv[r];
+      }
+      if (flags & IG_SILU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v4[r] = silu_t<float>(v4[r]);
+      }
+      *(f32x4*)dst = f32x4{v4[0], v4[1], v4[2], v4[3]};
+    }
+  }
+}
+
+static std::atomic<long long> g_gemm256x3_launches{0};
+long long gemm256x3_launches() { return g_gemm256x3_launches.load(); }
+
+// fp32 tensors, split-bf16 arithmetic (a.x3): -1 when the shape is not covered (caller: igemm_kernel<float, ..., X3>)
+static int launch_gemm256_x3(const IgemmArgs& a, hipStream_t stream) {
+  if (!sw().gemm256) return -1;
+  if (a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0 || a.ups) return -1;
+  if (a.nb0 * a.nb1 * a.nb2 != 1 || a.alpha != 1.0f) return -1;
+  if (a.flags & ~(IG_BIAS_N | IG_RESIDUAL | IG_SILU | IG_GLU | IG_OUT_F32)) return -1;
+  const long M = (long)a.Nimg * a.Hout * a.Wout;
+  if (a.Hout != a.Hin || a.Wout != a.Win || a.ldx != a.Cin) return -1;   // dense rows
+  if (a.c_ch != 1 || (a.c_grp > 1)) return -1;
+  if (a.Nimg > 1 && a.c_img != (long)a.Hout * a.Wout * a.c_pix) return -1;
+  const bool glu = a.flags & IG_GLU;
+  if (M < 4096 || a.N % 256 != 0 || a.Cin % 32 != 0 || a.Cin < 64 || a.ldw % 4 != 0 || a.c_pix % 4 != 0) return -1;
+  if (((uintptr_t)a.X & 15) || ((uintptr_t)a.W & 15) || ((uintptr_t)a.Y & 15) || ((a.flags & IG_RESIDUAL) && ((uintptr_t)a.R & 15))) return -1;
+  if (glu && (a.flags & IG_BIAS_N)) return -1;
+  if ((long)a.N * a.ldw * 4 >= (1L << 32)) return -1;
+  const long row_bytes = 4L * std::max<long>(a.ldx, a.c_pix);
+  const long rows_max = ((1L << 32) - 1) / row_bytes / 256 * 256;   // 32-bit byte offsets of the operand rows
+  if (rows_max < 4096) return -1;
+  static DynLdsOnce once_x;
+  for (long r0 = 0; r0 < M; r0 += rows_max) {
+    const long rows = std::min(rows_max, M - r0);
+    G256XDev d;
+    d.X = (const float*)a.X + r0 * a.ldx; d.W = (const float*)a.W; d.Y = (float*)a.Y + r0 * a.c_pix;
+    d.R = a.R ? (const float*)a.R + r0 * a.c_pix : nullptr; d.bias = a.bias;
+    d.M = (int)rows; d.N = a.N; d.K = a.Cin; d.ldx = a.ldx; d.ldw = a.ldw; d.ldy = (int)a.c_pix;
+    d.tiles_n = a.N / 256;
+    d.flags = a.flags;
+    d.tiles_m = cdiv(rows, 256);
+    {
+      const long slab = 256L * d.K * 4;
+      d.gn = (int)std::max(1L, std::min<long>((5L << 19) / slab, d.tiles_n));
+    }
+    const long tiles = (long)cdiv(rows, 256) * d.tiles_n;
+    if (hipError_t e = ensure_dyn_lds(once_x, (const void*)gemm256x3_kernel, 160 * 1024); e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(gemm256x3_kernel, dim3((unsigned)tiles), dim3(1024), 2 * G256L_STAGE, stream, d);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
+    g_gemm256x3_launches.fetch_add(1);
+  }
+  return 0;
+}
+
 // Returns -1 when the shape is not covered (caller uses launch_igemm).
 int launch_gemm256(const IgemmArgs& a, DType dtype, hipStream_t stream) {
+  if (dtype == F32 && a.x3 && sw().gemm256x3) return launch_gemm256_x3(a, stream);
   if (dtype != BF16 || !sw().gemm256) return -1;
   if (a.KH != 1 || a.KW != 1 || a.stride != 1 || a.pad != 0 || a.ups) return -1;
   if (a.nb0 * a.nb1 * a.nb2 != 1 || a.alpha != 1.0f) return -1;

@@ -66,6 +66,7 @@ int launch_igemm(const IgemmArgs& a, DType dtype, hipStream_t stream);
 int launch_gemm256(const IgemmArgs& a, DType dtype, hipStream_t stream);
 // LDS-halo 3x3 stride-1 kernel (conv3x3.hip); returns -1 when the shape is not covered (use launch_igemm then)
 int launch_conv3x3(const IgemmArgs& a, DType dtype, hipStream_t stream);
+long long gemm256x3_launches();         // gemm256.hip: launches of the 256 x 256-tile split-bf16 GEMM since load (test hook)
 long long conv3x3_subpixel_launches();   // conv3x3.hip: upsampling convolutions launched in sub-pixel form since load (test hook)
 long long decode_gemm_launches(int generation);   // dgemm.hip: decode GEMMs the dispatcher sent to generation 3 / 2 since load (test hook)
 // upper bound of the GroupNorm statistics chunks a conv3x3 launch with this output geometry writes per image

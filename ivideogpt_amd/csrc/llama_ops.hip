@@ -778,6 +778,252 @@ int launch_decode_attn(const void* qkv, void* kc, void* vc, void* out, const flo
   return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ 24-bit K / V cache of the x3 rollout
+// The 1e-3-compliant rollout mode (IVG_F32X3) keeps fp32 tensors, and its decode attention streamed an fp32 cache: 249 MB per layer
+// and step at config 2, 130 of the mode's 425 ms per step.  The arithmetic of that mode carries 2^-17 per operand anyway (bf16 hi +
+// bf16 lo), so the cache keeps 24 of the 32 bits: sign, exponent and 15 mantissa bits, rounded to nearest even -- 2^-17 relative --
+// as TWO PLANES per (trajectory, head): the upper 16 bits of every element ([Lmax][64] uint16, a bf16 image of the row) followed by
+// the next 8 bits ([Lmax][64] uint8).  A key row is 128 + 64 bytes instead of 256; a lane reads 16 + 8 bytes (8 elements) and
+// rebuilds each fp32 value with one v_perm_b32.  Everything else is decode_attn_kernel's structure (8 lanes per key row, as its bf16
+// instance): first round of key rows before the step counter, scores -> LDS, softmax statistics, weighted value sum in fixed order.
+// The appended k / v are rounded BEFORE they are used for this step's own score and output, so a later step reads exactly what
+// this one computed with.  The prefill keeps fp32 K / V of one layer in scratch (its score GEMM reads K as a matrix) and packs the
+// rows into the planes afterwards (kv24_pack_kernel).
+__device__ __forceinline__ unsigned f24_round(float x) {   // fp32 bits rounded to 24 (RNE), low byte zero
+  unsigned u = __float_as_uint(x);
+  u += 0x7fu + ((u >> 8) & 1u);
+  return u & 0xffffff00u;
+}
+struct Row24 { Chunk16 hi; unsigned lo0, lo1; };
+__device__ __forceinline__ void row24_unpack(const Row24& r, float (&f)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const unsigned h = r.hi[j >> 1];
+    const unsigned l = j < 4 ? r.lo0 : r.lo1;
+    // result bytes: [0] = 0, [1] = byte (j & 3) of the low plane's dword, [2..3] = the element's 16 upper bits
+    const unsigned sel = (j & 1) ? (0x07060000u | ((unsigned)(j & 3) << 8) | 0x0cu) : (0x05040000u | ((unsigned)(j & 3) << 8) | 0x0cu);
+    f[j] = __uint_as_float(__builtin_amdgcn_perm(h, l, sel));
+  }
+}
+
+template <bool SHARED>
+__global__ __launch_bounds__(256) void decode_attn24_kernel(const float* __restrict__ qkv, unsigned char* __restrict__ kc, unsigned char* __restrict__ vc,
+                                                            float* __restrict__ out, const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                                            int heads, int Lmax, const StepState* __restrict__ state, unsigned long long* prof,
+                                                            int sh_P, int sh_G, int sh_row0) {
+  constexpr int HD = 64, HALF = 32, LPK = 8, GPB = 32, UNR = 8;
+  const unsigned long long t_start = prof ? wall_clock64() : 0ull;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* sq = (float*)smem;
+  float* sk = sq + HD;
+  float* sv = sk + HD;
+  float* sc = sv + HD;               // [Lmax] scores
+  float* red = sc + Lmax;            // [GPB][HD] partial outputs
+  __shared__ float sred[8];
+  const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int sub = tid % LPK, grp = tid / LPK;
+  const int H = heads * HD;
+  const float scale = rsqrtf((float)HD);
+  const long blk = (long)Lmax * (HD * 3);                          // bytes of one (trajectory, head): [Lmax][64] u16 | [Lmax][64] u8
+  unsigned char* kb = kc + ((long)b * heads + h) * blk;
+  unsigned char* vb = vc + ((long)b * heads + h) * blk;
+  const unsigned lo_plane = (unsigned)Lmax * (HD * 2);
+  long sh_delta = 0;
+  if constexpr (SHARED) sh_delta = ((long)((b - sh_row0) / sh_G) - b) * heads * blk;
+  const int step = GPB * UNR;
+  auto load_rows = [&](Row24 (&dst)[UNR], const unsigned char* base, int t0, int limit) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int t = t0 + u * GPB + grp;
+      const unsigned char* rb = base;
+      if constexpr (SHARED) rb = t < sh_P ? base + sh_delta : base;
+      const Chunk16* ph = (const Chunk16*)(rb + ((unsigned)t * (HD * 2) + (unsigned)sub * 16u));
+      typedef unsigned int U2 __attribute__((ext_vector_type(2)));
+      const U2* pl = (const U2*)(rb + (lo_plane + (unsigned)t * HD + (unsigned)sub * 8u));
+      if (t < limit) {
+        if constexpr (SHARED) { dst[u].hi = *ph; const U2 l2 = *pl; dst[u].lo0 = l2[0]; dst[u].lo1 = l2[1]; }
+        else { dst[u].hi = __builtin_nontemporal_load(ph); const U2 l2 = __builtin_nontemporal_load(pl); dst[u].lo0 = l2[0]; dst[u].lo1 = l2[1]; }
+      } else {
+        dst[u].hi = Chunk16{0u, 0u, 0u, 0u}; dst[u].lo0 = 0u; dst[u].lo1 = 0u;
+      }
+    }
+  };
+  Row24 cur[UNR], nxt[UNR];
+  float rc = 0.f, rs = 0.f, q1 = 0.f, q2 = 0.f, k1 = 0.f, k2 = 0.f, va = 0.f, vb2 = 0.f;
+  if (tid < HALF) {
+    const float* row = qkv + (long)b * 3 * H + h * HD;
+    q1 = row[tid]; q2 = row[tid + HALF];
+    k1 = row[H + tid]; k2 = row[H + tid + HALF];
+    va = row[2 * H + tid]; vb2 = row[2 * H + tid + HALF];
+  }
+  load_rows(cur, kb, 0, Lmax);       // the first key rows are in flight while the step counter arrives and q is roped
+  const int pos = state->pos;
+  const int n_keys = pos + 1;
+  if (tid < HALF) { rc = cosT[(long)pos * HALF + tid]; rs = sinT[(long)pos * HALF + tid]; }
+  if (tid < HALF) {
+    const unsigned ka = f24_round(k1 * rc - k2 * rs), kb2 = f24_round(k2 * rc + k1 * rs);
+    const unsigned v1 = f24_round(va), v2 = f24_round(vb2);
+    sq[tid] = q1 * rc - q2 * rs; sq[tid + HALF] = q2 * rc + q1 * rs;
+    sk[tid] = __uint_as_float(ka); sk[tid + HALF] = __uint_as_float(kb2);
+    sv[tid] = __uint_as_float(v1); sv[tid + HALF] = __uint_as_float(v2);
+    unsigned short* kh = (unsigned short*)kb + (long)pos * HD;
+    unsigned short* vh = (unsigned short*)vb + (long)pos * HD;
+    unsigned char* kl = kb + lo_plane + (long)pos * HD;
+    unsigned char* vl = vb + lo_plane + (long)pos * HD;
+    kh[tid] = (unsigned short)(ka >> 16); kh[tid + HALF] = (unsigned short)(kb2 >> 16);
+    kl[tid] = (unsigned char)(ka >> 8); kl[tid + HALF] = (unsigned char)(kb2 >> 8);
+    vh[tid] = (unsigned short)(v1 >> 16); vh[tid + HALF] = (unsigned short)(v2 >> 16);
+    vl[tid] = (unsigned char)(v1 >> 8); vl[tid + HALF] = (unsigned char)(v2 >> 8);
+  }
+  __syncthreads();
+  float qf[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) qf[j] = sq[sub * 8 + j];
+  auto scores = [&](Row24 (&rows)[UNR], int t0) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int t = t0 + u * GPB + grp;
+      float kf[8];
+      row24_unpack(rows[u], kf);
+      float d = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d = fmaf(qf[j], kf[j], d);
+      d = group_sum(d, LPK);
+      if (t < pos && sub == 0) sc[t] = d * scale;
+    }
+  };
+  {
+    int t0 = 0;
+    bool in_nxt = false;
+    while (t0 < pos) {
+      if (t0 + step < pos) load_rows(nxt, kb, t0 + step, pos); else load_rows(nxt, vb, 0, pos);
+      scores(cur, t0);
+      t0 += step;
+      in_nxt = true;
+      if (t0 >= pos) break;
+      if (t0 + step < pos) load_rows(cur, kb, t0 + step, pos); else load_rows(cur, vb, 0, pos);
+      scores(nxt, t0);
+      t0 += step;
+      in_nxt = false;
+    }
+    if (in_nxt) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) cur[u] = nxt[u];
+    }
+  }
+  if (grp == 0) {
+    float d = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d = fmaf(qf[j], sk[sub * 8 + j], d);
+    d = group_sum(d, LPK);
+    if (sub == 0) sc[pos] = d * scale;
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int t = tid; t < n_keys; t += 256) mx = fmaxf(mx, sc[t]);
+  mx = wave_max(mx);
+  if (lane == 0) sred[wv] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
+  float sum = 0.f;
+  for (int t = tid; t < n_keys; t += 256) { const float e = expf(sc[t] - mx); sc[t] = e; sum += e; }
+  sum = wave_sum(sum);
+  if (lane == 0) sred[4 + wv] = sum;
+  __syncthreads();
+  sum = (sred[4] + sred[5]) + (sred[6] + sred[7]);
+  float of[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) of[j] = 0.f;
+  auto weighted = [&](Row24 (&rows)[UNR], int t0) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int t = t0 + u * GPB + grp;
+      if (t < pos) {
+        float vf[8];
+        row24_unpack(rows[u], vf);
+        const float pw = sc[t];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) of[j] = fmaf(pw, vf[j], of[j]);
+      }
+    }
+  };
+  for (int t0 = 0; t0 < pos; t0 += 2 * step) {
+    if (t0 + step < pos) load_rows(nxt, vb, t0 + step, pos);
+    weighted(cur, t0);
+    if (t0 + step >= pos) break;
+    if (t0 + 2 * step < pos) load_rows(cur, vb, t0 + 2 * step, pos);
+    weighted(nxt, t0 + step);
+  }
+  if (grp == 0) {
+    const float pw = sc[pos];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) of[j] = fmaf(pw, sv[sub * 8 + j], of[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[grp * HD + sub * 8 + j] = of[j];
+  __syncthreads();
+  if (tid < HD) {
+    float a = 0.f;
+    for (int g = 0; g < GPB; ++g) a += red[g * HD + tid];
+    out[(long)b * H + h * HD + tid] = a / sum;
+  }
+  if (prof && tid == 0) {
+    unsigned long long* slot = prof + (size_t)((blockIdx.x * 7 + blockIdx.y) % IVG_ATTN_PROF_SLOTS) * 2 * Lmax;
+    atomicMax(slot + pos, ~t_start);
+    atomicMax(slot + Lmax + pos, (unsigned long long)wall_clock64());
+  }
+}
+
+int launch_decode_attn24(const void* qkv, void* kc, void* vc, void* out, const float* cosT, const float* sinT, int B, int heads, int Lmax,
+                         const StepState* state, unsigned long long* prof, hipStream_t st, int sh_P, int sh_G, int sh_row0) {
+  const size_t smem = (size_t)(3 * 64 + Lmax + 32 * 64) * sizeof(float);
+  dim3 g(B * heads);
+  if (sh_G > 1) {
+    if (sh_P < 0 || sh_row0 > 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(decode_attn24_kernel<true>, g, dim3(256), smem, st, (const float*)qkv, (unsigned char*)kc, (unsigned char*)vc, (float*)out, cosT, sinT,
+                       heads, Lmax, state, prof, sh_P, sh_G, sh_row0);
+  } else {
+    hipLaunchKernelGGL(decode_attn24_kernel<false>, g, dim3(256), smem, st, (const float*)qkv, (unsigned char*)kc, (unsigned char*)vc, (float*)out, cosT, sinT,
+                       heads, Lmax, state, prof, 0, 1, 0);
+  }
+  return (int)hipGetLastError();
+}
+
+// fp32 rows [0, L) of K / V ([B * heads][Lmax][64], what rope_kv wrote for the prompt) -> the 24-bit planes of the cache
+__global__ __launch_bounds__(256) void kv24_pack_kernel(const float* __restrict__ k32, const float* __restrict__ v32, unsigned char* __restrict__ kc,
+                                                        unsigned char* __restrict__ vc, int L, int Lmax) {
+  const int bh = blockIdx.y, tid = threadIdx.x;
+  const int row = blockIdx.x * 32 + (tid >> 3), sub = tid & 7;
+  if (row >= L) return;
+  const long blk = (long)Lmax * 192;
+  const unsigned lo_plane = (unsigned)Lmax * 128u;
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    const float* src = (which ? v32 : k32) + ((long)bh * Lmax + row) * 64 + sub * 8;
+    unsigned char* dst = (which ? vc : kc) + (long)bh * blk;
+    const f32x4 a = *(const f32x4*)src, c = *(const f32x4*)(src + 4);
+    unsigned u[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { u[j] = f24_round(a[j]); u[4 + j] = f24_round(c[j]); }
+    Chunk16 hi;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) hi[j] = (u[2 * j] >> 16) | (u[2 * j + 1] & 0xffff0000u);
+    uint2 lo;
+    lo.x = ((u[0] >> 8) & 0xffu) | (u[1] & 0xff00u) | ((u[2] << 8) & 0xff0000u) | ((u[3] << 16) & 0xff000000u);
+    lo.y = ((u[4] >> 8) & 0xffu) | (u[5] & 0xff00u) | ((u[6] << 8) & 0xff0000u) | ((u[7] << 16) & 0xff000000u);
+    *(Chunk16*)(dst + (unsigned)row * 128u + (unsigned)sub * 16u) = hi;
+    *(uint2*)(dst + lo_plane + (unsigned)row * 64u + (unsigned)sub * 8u) = lo;
+  }
+}
+
+int launch_kv24_pack(const void* k32, const void* v32, void* kc, void* vc, int BH, int L, int Lmax, hipStream_t st) {
+  if (L <= 0) return 0;
+  hipLaunchKernelGGL(kv24_pack_kernel, dim3((unsigned)cdiv(L, 32), (unsigned)BH), dim3(256), 0, st, (const float*)k32, (const float*)v32, (unsigned char*)kc,
+                     (unsigned char*)vc, L, Lmax);
+  return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ sampling
 // One workgroup per trajectory.  Restates HF TopKLogitsWarper(top_k) + softmax + one draw as an
 // explicit-uniform inverse CDF over the kept tokens in ascending id order (oracle/llama.py

@@ -78,6 +78,11 @@ bool xattn_covers(int P, int kv, int C, int nh, DType dt);   // pure predicate (
 int launch_decode_attn(const void* qkv, void* kc, void* vc, void* out, const float* cosT, const float* sinT, int B, int heads, int hd,
                        int Lmax, const StepState* state, unsigned long long* prof, DType dt, hipStream_t st, int sh_P = 0, int sh_G = 1,
                        int sh_row0 = 0);
+// 24-bit K / V cache of the x3 rollout (llama_ops.hip): per (trajectory, head) [Lmax][64] uint16 (upper halves) | [Lmax][64] uint8 (next byte);
+// head_dim 64, fp32 q / output.  launch_kv24_pack: fp32 rows [0, L) of [BH][Lmax][64] K and V (the prefill's scratch) -> the planes
+int launch_decode_attn24(const void* qkv, void* kc, void* vc, void* out, const float* cosT, const float* sinT, int B, int heads, int Lmax,
+                         const StepState* state, unsigned long long* prof, hipStream_t st, int sh_P = 0, int sh_G = 1, int sh_row0 = 0);
+int launch_kv24_pack(const void* k32, const void* v32, void* kc, void* vc, int BH, int L, int Lmax, hipStream_t st);
 int launch_expand_prompt_rows(const int64_t* prompts, long pstride, int64_t* ids, long ids_ld, int rows, int L, int G, int b0, hipStream_t st);
 // token decision + embedding of the decided token (+ action embedding on forced sdf slots) + state advance
 struct SampleArgs {

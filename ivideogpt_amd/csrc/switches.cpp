@@ -21,6 +21,8 @@ static Switches read_env() {
   s.conv3x3 = dv("IVG_CONV3X3", 1) != 0;
   s.subpixel = dv("IVG_SUBPIXEL", 1) != 0;
   s.gemm256 = dv("IVG_GEMM256", 1) != 0;
+  s.gemm256x3 = dv("IVG_GEMM256X3", 1) != 0;
+  s.kv24 = dv("IVG_KV24", 1) != 0;
   s.dg3 = dv("IVG_DG3", 1) != 0;
   s.flash_prefill = dv("IVG_FLASH_PREFILL", 1) != 0;
   s.flash_xatt = dv("IVG_FLASH_XATT", 1) != 0;
@@ -48,7 +50,7 @@ static Switches read_env() {
 
 bool Switches::operator==(const Switches& o) const {
   return conv3x3 == o.conv3x3 && subpixel == o.subpixel && gemm256 == o.gemm256 && dg3 == o.dg3 && flash_prefill == o.flash_prefill &&
-         flash_xatt == o.flash_xatt && gn_fuse == o.gn_fuse && gn_apply_fuse == o.gn_apply_fuse && x3 == o.x3 && graph == o.graph &&
+         flash_xatt == o.flash_xatt && gn_fuse == o.gn_fuse && gn_apply_fuse == o.gn_apply_fuse && x3 == o.x3 && gemm256x3 == o.gemm256x3 && kv24 == o.kv24 && graph == o.graph &&
          dg3_warm == o.dg3_warm && warm_gate_up == o.warm_gate_up && conv_cap == o.conv_cap && decode_lds_kb == o.decode_lds_kb && decode_w_shared == o.decode_w_shared &&
          inflight_warm == o.inflight_warm && dg2_mf_cap == o.dg2_mf_cap && inflight_gemm256 == o.inflight_gemm256 &&
          std::equal(inflight_kb, inflight_kb + 5, o.inflight_kb);

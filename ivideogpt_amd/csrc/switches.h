@@ -19,6 +19,8 @@
 //   IVG_SUBPIXEL             1        0: nearest-x2 upsampling convolutions as nine taps over the upsampled grid (1: four 2x2 phase
 //                                        convolutions over the low-resolution input with pre-summed weights, conv3x3.hip SUBPIX)
 //   IVG_GEMM256              1        0: large dense GEMMs on the generic implicit GEMM
+//   IVG_KV24                 1        0: the x3 rollout keeps an fp32 K / V cache (1: 24 bits per element in two planes, llama_ops.hip)
+//   IVG_GEMM256X3            1        0: large dense split-bf16 ("x3") GEMMs on the generic implicit GEMM's X3 instance (1: 256 x 256 tiles)
 //   IVG_DG3                  1        0: decode GEMMs on the second-generation kernel (dgemm.hip)
 //   IVG_FLASH_PREFILL        1        0: prompt attention as score GEMM + softmax + P.V GEMM (what the fp32 engine mode runs)
 //   IVG_FLASH_XATT           1        0: tokenizer attention as score GEMM + softmax + P.V GEMM
@@ -41,7 +43,7 @@
 namespace ivg {
 
 struct Switches {
-  int conv3x3 = 1, subpixel = 1, gemm256 = 1, dg3 = 1, flash_prefill = 1, flash_xatt = 1, gn_fuse = 1, gn_apply_fuse = 1, x3 = 1;
+  int conv3x3 = 1, subpixel = 1, gemm256 = 1, dg3 = 1, flash_prefill = 1, flash_xatt = 1, gn_fuse = 1, gn_apply_fuse = 1, x3 = 1, gemm256x3 = 1, kv24 = 1;
   int graph = 0, dg3_warm = 1, warm_gate_up = 0, conv_cap = 0, decode_lds_kb = 160, decode_w_shared = 1, inflight_warm = 0, dg2_mf_cap = 0, inflight_gemm256 = 1;
   int inflight_kb[5] = {0, 0, 0, 0, 0};
   bool operator==(const Switches& o) const;

@@ -68,7 +68,7 @@ size_t gen_buffer_bytes(const ivg_engine* e) {
 }
 
 static char* kc_ptr(const ivg_engine* e, int layer, int which) {
-  const size_t per = (size_t)gen_chunk(e) * e->heads * e->Lmax * e->hd * esz(e->llm_dt);
+  const size_t per = (size_t)gen_chunk(e) * e->heads * e->Lmax * e->hd * e->kv_elem_bytes();
   return e->kv + ((size_t)layer * 2 + which) * per;
 }
 
@@ -94,6 +94,11 @@ int Run::prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const voi
   char* act = (char*)e->ws.alloc((size_t)M * I * esz(dt));
   const bool flash = flash_prefill_covers(dt, hd);   // one-pass causal attention: no score matrix in HBM
   float* S = flash ? nullptr : (float*)e->ws.alloc((size_t)B * heads * L * Lp * 4);
+  // 24-bit cache (x3 rollout): RoPE writes one layer's fp32 K / V rows here -- the score GEMM reads K as a matrix -- and
+  // kv24_pack_kernel moves them into the cache's planes
+  const bool kv24 = e->kv24;
+  char* k32 = kv24 ? (char*)e->ws.alloc((size_t)B * heads * Lmax * hd * 4) : nullptr;
+  char* v32 = kv24 ? (char*)e->ws.alloc((size_t)B * heads * Lmax * hd * 4) : nullptr;
   char* Pm = flash ? nullptr : (char*)e->ws.alloc((size_t)B * heads * L * Lp * esz(dt));
   if (!planning) {
     e->kv_len = 0; e->kv_B = 0;   // the cache rows are about to be overwritten (ivg_generate re-validates them at its end)
@@ -114,14 +119,17 @@ int Run::prefill(const int64_t* ids, int64_t ids_stride, int B, int L, const voi
     if (!planning) CK(launch_add_rmsnorm(x, H, e->ones, xn, (int)M, H, c.rms_norm_eps, dt, st));
     ConvW wq; wq.w = w.wqkv; wq.cin = H; wq.cout = 3 * H;
     IVG_TRY(linear(dt, xn, M, wq, qkv, nullptr, 0, 0));
-    if (!planning)
-      CK(launch_rope_kv(qkv, kc_ptr(e, l, 0), kc_ptr(e, l, 1), e->vt, Lp, e->rope_cos, e->rope_sin, B, L, heads, hd, Lmax, nullptr, 0, dt, st));
+    char* kl = kv24 ? k32 : kc_ptr(e, l, 0);
+    if (!planning) {
+      CK(launch_rope_kv(qkv, kl, kv24 ? v32 : kc_ptr(e, l, 1), e->vt, Lp, e->rope_cos, e->rope_sin, B, L, heads, hd, Lmax, nullptr, 0, dt, st));
+      if (kv24) CK(launch_kv24_pack(k32, v32, kc_ptr(e, l, 0), kc_ptr(e, l, 1), B * heads, L, Lmax, st));
+    }
     if (flash) {
-      if (!planning) CK(launch_flash_prefill(qkv, kc_ptr(e, l, 0), e->vt, attn, B, L, Lp, heads, hd, Lmax, dt, st));
+      if (!planning) CK(launch_flash_prefill(qkv, kl, e->vt, attn, B, L, Lp, heads, hd, Lmax, dt, st));
     } else {
     {  // S[b][h] = Q K^T / sqrt(hd)
       IgemmArgs g;
-      g.X = qkv; g.W = kc_ptr(e, l, 0); g.Y = S;
+      g.X = qkv; g.W = kl; g.Y = S;
       g.Nimg = 1; g.Hin = 1; g.Win = L; g.Cin = hd; g.ldx = 3 * H; g.Hout = 1; g.Wout = L;
       g.N = L; g.ldw = hd; g.c_pix = Lp; g.c_ch = 1; g.flags = IG_OUT_F32; g.alpha = 1.0f / sqrtf((float)hd);
       g.nb0 = B; g.nb1 = heads;
@@ -209,7 +217,7 @@ static int step_body(ivg_engine* e, hipStream_t st, const GenBuf& g, int B, cons
   char* attn = g.attn + (size_t)b0 * H * es;
   char* act = g.act + (size_t)b0 * I * es;
   float* logits = g.logits + (size_t)b0 * V;
-  const size_t kv_off = (size_t)b0 * e->heads * e->Lmax * e->hd * es;
+  const size_t kv_off = (size_t)b0 * e->heads * e->Lmax * e->hd * e->kv_elem_bytes();
   SampleArgs sa = sa0;
   sa.logits = logits;
   if (sa.uniforms) sa.uniforms += (size_t)b0 * sa.n_uni;
@@ -279,9 +287,13 @@ static int step_body(ivg_engine* e, hipStream_t st, const GenBuf& g, int B, cons
     link_next(cur[0], cur[1]); link_next(cur[1], cur[2]); link_next(cur[2], cur[3]); link_next(cur[3], last ? lm : nxt[0]);
     gprof(cur[0], 4 * l + 0);
     CK(launch_skinny(cur[0], dt, st));
-    CK(launch_decode_attn(qkv, kc_ptr(e, l, 0) + kv_off, kc_ptr(e, l, 1) + kv_off, attn, e->rope_cos, e->rope_sin, B, e->heads, e->hd,
-                          e->Lmax, state, e->attn_prof_on ? e->attn_prof + (size_t)l * IVG_ATTN_PROF_SLOTS * 2 * e->Lmax : nullptr, dt, st,
-                          g.sh_P, g.sh_G, g.sh_row0));
+    unsigned long long* aprof = e->attn_prof_on ? e->attn_prof + (size_t)l * IVG_ATTN_PROF_SLOTS * 2 * e->Lmax : nullptr;
+    if (e->kv24)
+      CK(launch_decode_attn24(qkv, kc_ptr(e, l, 0) + kv_off, kc_ptr(e, l, 1) + kv_off, attn, e->rope_cos, e->rope_sin, B, e->heads, e->Lmax, state,
+                              aprof, st, g.sh_P, g.sh_G, g.sh_row0));
+    else
+      CK(launch_decode_attn(qkv, kc_ptr(e, l, 0) + kv_off, kc_ptr(e, l, 1) + kv_off, attn, e->rope_cos, e->rope_sin, B, e->heads, e->hd,
+                            e->Lmax, state, aprof, dt, st, g.sh_P, g.sh_G, g.sh_row0));
     gprof(cur[1], 4 * l + 1);
     CK(launch_skinny(cur[1], dt, st));
     gprof(cur[2], 4 * l + 2);

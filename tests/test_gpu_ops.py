@@ -22,7 +22,7 @@ def tdt(name):
 
 
 def code(name):
-    return 0 if name == "fp32" else 1
+    return {"fp32": 0, "bf16": 1, "x3": 2}[name]   # x3 = IVG_F32X3: fp32 tensors, split-bf16 arithmetic
 
 
 def P(t):
@@ -675,6 +675,57 @@ def test_gemm256_large_dense(mode, switches):
         Y2 = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
         igemm(dt, Xd, Wd, Y2, **kw)
         assert rel_err(Y2.float(), ref) < TOL[dt] and (Y2.float() - Y.float()).abs().max().item() <= 2 * TOL[dt] * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("mode", ["plain", "bias_residual_inplace", "glu", "silu", "k_one_step", "nimg", "narrow_falls_back"])
+def test_gemm256_x3_large_dense(mode, switches):
+    """256 x 256-tile split-bf16 ("x3") GEMM (round 6: the prompt pass and the dense 1x1 layers of the 1e-3-compliant mode left the
+    128 x 128 implicit GEMM): fp32 tensors, both operands split into bf16 (hi, lo) in registers, four partial products, fp32
+    accumulate -- against fp64 on the SAME fp32 inputs, 2e-5 relative (2^-17 per operand; the bar of the other x3 kernels).  Rows not a
+    multiple of 256, every epilogue, K of one 128-byte step per row pair, a dense 1x1 layer over images; N = 384 is not covered and
+    must fall to igemm_kernel<float, ..., X3> with the same bar.  The debug counter shows which kernel ran."""
+    L, l = lib()
+    g = torch.Generator().manual_seed(7 + len(mode))
+    M, N, K = 4900, {"narrow_falls_back": 384}.get(mode, 512), {"k_one_step": 64}.get(mode, 416)
+    X = torch.randn(M, K, generator=g) * 1.3 + 0.2
+    W_ = torch.randn(N, K, generator=g) / K ** 0.5
+    Xd, Wd = X.to(DEV), W_.to(DEV)
+    kw = dict(Win=M, Wout=M, Cin=K, ldx=K, N=N, ldw=K, c_pix=N)
+    if mode == "nimg":
+        kw.update(Nimg=49, Hin=10, Win=10, Hout=10, Wout=10, c_img=100 * N)
+    before = l.ivg_debug_counter(b"gemm256x3")
+    if mode == "glu":
+        I = N // 2
+        gate, up = W_[:I], W_[I:]
+        wgu = torch.stack([gate.view(I // 16, 16, K), up.view(I // 16, 16, K)], 1).reshape(N, K).contiguous().to(DEV)
+        ref = F.silu(X.double() @ gate.double().T) * (X.double() @ up.double().T)
+        Y = torch.full((M, I), float("nan"), device=DEV)
+        kw.update(c_pix=I, flags=16)
+        igemm("x3", Xd, wgu, Y, **kw)
+    elif mode == "bias_residual_inplace":
+        b = torch.randn(N, generator=g)
+        R = torch.randn(M, N, generator=g)
+        ref = X.double() @ W_.double().T + b.double() + R.double()
+        Y = R.to(DEV).clone()
+        igemm("x3", Xd, Wd, Y, Y, b.to(DEV), flags=1 | 4, **kw)
+    else:
+        ref = X.double() @ W_.double().T
+        if mode == "silu":
+            ref = F.silu(ref)
+        Y = torch.full((M, N), float("nan"), device=DEV)
+        igemm("x3", Xd, Wd, Y, flags=8 if mode == "silu" else 0, **kw)
+    ran = l.ivg_debug_counter(b"gemm256x3") - before
+    assert ran == (0 if mode == "narrow_falls_back" else 1), ran
+    assert torch.isfinite(Y).all()
+    e = rel_err(Y, ref)
+    assert e < 2e-5, f"{mode}: rel err {e:.3e}"
+    assert e > 1e-8, "suspiciously exact: is this an f32-input MFMA path?"
+    if mode == "plain":   # the implicit GEMM's X3 instance on the same operands: same bar, and the two agree far inside it
+        switches(IVG_GEMM256X3="0")
+        Y2 = torch.full((M, N), float("nan"), device=DEV)
+        igemm("x3", Xd, Wd, Y2, **kw)
+        assert l.ivg_debug_counter(b"gemm256x3") - before == 1
+        assert rel_err(Y2, ref) < 2e-5 and (Y2 - Y).abs().max().item() < 4e-5 * ref.abs().max().item()
 
 
 # ------------------------------------------------------------------------------------------------ frame metrics / clip ingest

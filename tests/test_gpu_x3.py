@@ -133,6 +133,35 @@ def test_x3_decode_path_at_released_widths_vs_oracle(width, lds_kb):
         assert torch.equal(part, full[rows]), f"{width}: rows {rows} differ between the 64-row batch and the shard"
 
 
+def test_x3_shared_context_rollout_over_the_24_bit_cache(switches):
+    """x3 rollout of t samples over ONE prompt (shared-context path: the prompt's rows live once in the 24-bit cache, SHARED instance of
+    decode_attn24_kernel): greedy rows equal the oracle's tokens, sampled rows equal the oracle's up to near-ties, rows with the same
+    uniforms are identical; and the same engine configuration with the fp32 cache (IVG_KV24=0) decodes the same greedy tokens."""
+    from oracle.llama import generate_cached
+    from ivideogpt_amd import weights as W
+    cfg = dict(W.LLAMA_SMALL)
+    cfg["num_hidden_layers"] = 4
+    sd = W.random_llama_state_dict(cfg, 43)
+    gen = torch.Generator().manual_seed(19)
+    prompt = torch.randint(0, 8192, (1, 514), generator=gen)
+    prompt[:, 256], prompt[:, -1] = cfg["vocab_size"] - 2, cfg["vocab_size"] - 1
+    t, n_new = 5, 24
+    u = torch.rand(t, n_new, generator=gen)
+    u[3] = u[1]
+    ora = oracle_llama(cfg, sd)
+    m = make_llm(cfg, sd, "x3")
+    out = m.generate(prompt.repeat(t, 1).to(DEV), do_sample=True, top_k=100, max_new_tokens=n_new, uniforms=u.to(DEV), shared_context=t).cpu()
+    assert torch.equal(out[1], out[3])
+    ref = generate_cached(ora, prompt.repeat(t, 1), n_new, top_k=100, uniforms=u)
+    assert_sampled_rollout_matches(out, ref, ora, u, 100, 514, what="x3 shared rollout over the 24-bit cache")
+    og = m.generate(prompt.repeat(2, 1).to(DEV), do_sample=False, max_new_tokens=n_new, shared_context=2).cpu()
+    ref_g = generate_cached(ora, prompt.repeat(2, 1), n_new)
+    assert torch.equal(og, ref_g)
+    switches(IVG_KV24="0")
+    m32 = make_llm(cfg, sd, "x3")
+    assert torch.equal(m32.generate(prompt.repeat(2, 1).to(DEV), do_sample=False, max_new_tokens=n_new, shared_context=2).cpu(), ref_g)
+
+
 def test_x3_switch_off_is_the_fp32_path(switches):
     """IVG_X3=0: an engine created in x3 mode runs the f32-input MFMA kernels -- bit-identical to the fp32 mode."""
     cfg, sd, ctx, px, g = tokenizer_fixture("tok_mini64_ctx2.npz")
@@ -150,3 +179,88 @@ def test_zz_record_x3_margins():
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "r04_x3_margins.json"), "w") as f:
         json.dump(RECORD, f, indent=1)
+
+
+# ------------------------------------------------------------------------------------------------ 24-bit K / V cache (round 6)
+def _round24(x):
+    """fp32 -> the nearest value with 24 of the 32 bits (sign, exponent, 15 mantissa bits; ties to even): what the cache keeps"""
+    u = x.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    u = (u + 0x7F + ((u >> 8) & 1)) & 0xFFFFFF00
+    return (u - ((u >> 31) << 32)).to(torch.int32).view(torch.float32)
+
+
+@pytest.mark.parametrize("B,G,row0,P,pos", [(40, 1, 0, 0, 600), (9, 1, 0, 0, 255), (5, 1, 0, 0, 256), (3, 1, 0, 0, 1), (37, 16, -5, 256, 256),
+                                            (40, 40, 0, 513, 700), (7, 3, 0, 65, 97)])
+def test_decode_attention_over_the_24_bit_cache_vs_fp64(B, G, row0, P, pos):
+    """The K / V cache of the x3 rollout keeps 24 bits per element in two planes (csrc/llama_ops.hip: decode_attn24_kernel,
+    kv24_pack_kernel).  (a) the pack kernel's planes hold exactly round-to-nearest-even of the fp32 rows (decoded here from the bytes);
+    (b) one decode-attention step equals softmax(q k^T / 8) v in fp64 over THOSE rounded rows within 2e-5 -- and the fp64 result over
+    the un-rounded fp32 rows within 4e-5: the cache format costs 2^-17 per element, the error class of the mode's arithmetic;
+    (c) the append: position `pos` holds the rounded roped k and the rounded v of the fed token, earlier rows untouched;
+    (d) shared-context groups (G > 1) read rows < P from the group's cache row.  Cache lengths around the 256-row block edges."""
+    import ctypes as C
+    from ivideogpt_amd import _lib
+    l = _lib.load()
+    heads, hd, Lmax = 12, 64, 1024
+    gen = torch.Generator().manual_seed(B + G + pos)
+    n_slots = (B - 1 - row0) // G + 1
+    rows = max(B, n_slots)
+    k32 = torch.randn(rows, heads, Lmax, hd, generator=gen) * 1.2
+    v32 = torch.randn(rows, heads, Lmax, hd, generator=gen)
+    qkv = torch.randn(B, 3 * heads * hd, generator=gen) * 1.5
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    fr = torch.arange(Lmax, dtype=torch.float32)[:, None] * inv[None, :]
+    cos, sin = fr.cos(), fr.sin()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    kd32, vd32 = k32.to(DEV), v32.to(DEV)
+    kc = torch.zeros(rows, heads, Lmax * 192, dtype=torch.uint8, device=DEV)
+    vc = torch.zeros_like(kc)
+    rc = l.ivg_op_kv24_pack(C.c_void_p(kd32.data_ptr()), C.c_void_p(vd32.data_ptr()), C.c_void_p(kc.data_ptr()), C.c_void_p(vc.data_ptr()),
+                            rows * heads, pos, Lmax, st)
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+
+    def planes_to_f32(c):                    # (rows, heads, Lmax * 192) uint8 -> (rows, heads, Lmax, 64) fp32
+        c = c.cpu()
+        hi = c[..., :Lmax * 128].contiguous().view(torch.int16).view(rows, heads, Lmax, hd).to(torch.int64) & 0xFFFF
+        lo = c[..., Lmax * 128:].view(rows, heads, Lmax, hd).to(torch.int64)
+        u = (hi << 16) | (lo << 8)
+        return (u - ((u >> 31) << 32)).to(torch.int32).view(torch.float32)
+    k24, v24 = _round24(k32), _round24(v32)
+    assert torch.equal(planes_to_f32(kc)[:, :, :pos], k24[:, :, :pos]) and torch.equal(planes_to_f32(vc)[:, :, :pos], v24[:, :, :pos])
+    assert (planes_to_f32(kc)[:, :, pos:] == 0).all(), "rows beyond L must not be written"
+    assert ((k24 - k32).abs() <= 2.0 ** -16 * k32.abs()).all()
+
+    def rope(x):
+        a, b = x[..., :hd // 2], x[..., hd // 2:]
+        c, s_ = cos[pos], sin[pos]
+        return torch.cat([a * c - b * s_, b * c + a * s_], -1)
+    q = rope(qkv[:, :heads * hd].view(B, heads, hd))
+    kn = rope(qkv[:, heads * hd:2 * heads * hd].view(B, heads, hd))
+    vn = qkv[:, 2 * heads * hd:].view(B, heads, hd)
+    ref24 = torch.empty(B, heads, hd, dtype=torch.float64)
+    ref32 = torch.empty_like(ref24)
+    for b in range(B):
+        s_ = (b - row0) // G
+        for ref, kk, vv, knn, vnn in ((ref24, k24, v24, _round24(kn), _round24(vn)), (ref32, k32, v32, kn, vn)):
+            K = torch.cat([kk[s_, :, :P], kk[b, :, P:pos], knn[b][:, None]], 1).double()
+            V = torch.cat([vv[s_, :, :P], vv[b, :, P:pos], vnn[b][:, None]], 1).double()
+            w = torch.softmax(torch.einsum("hd,hkd->hk", q[b].double(), K) / 8.0, -1)
+            ref[b] = torch.einsum("hk,hkd->hd", w, V)
+    cd, sd, qd = cos.to(DEV), sin.to(DEV), qkv.to(DEV)
+    out = torch.full((B, heads * hd), float("nan"), device=DEV)
+    before_k = kc.clone()
+    rc = l.ivg_op_decode_attn24(C.c_void_p(qd.data_ptr()), C.c_void_p(kc.data_ptr()), C.c_void_p(vc.data_ptr()), C.c_void_p(out.data_ptr()),
+                                C.c_void_p(cd.data_ptr()), C.c_void_p(sd.data_ptr()), B, heads, Lmax, pos, P, G, row0, st)
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    got = out.view(B, heads, hd).cpu().double()
+    assert torch.isfinite(got).all()
+    e24 = ((got - ref24).abs().max() / ref24.abs().max()).item()
+    e32 = ((got - ref32).abs().max() / ref32.abs().max()).item()
+    assert e24 < 2e-5 and e32 < 4e-5, (e24, e32)
+    kgot, vgot = planes_to_f32(kc), planes_to_f32(vc)
+    assert (kgot[:B, :, pos] - kn).abs().max().item() <= 2.0 ** -15 * kn.abs().max().item()       # one rounding to 24 bits + the rotation's fma contraction
+    assert torch.equal(vgot[:B, :, pos], _round24(vn))
+    assert torch.equal(kgot[:, :, :pos], k24[:, :, :pos]), "cached rows must not be touched"
+    assert torch.equal(kc[B:], before_k[B:]), "rows of other trajectories must not be touched"
