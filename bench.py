@@ -471,6 +471,8 @@ def main():
     ap.add_argument("--llm-dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-mode", action="store_true", help="skip the extra fp32-arithmetic measurement")
+    ap.add_argument("--x3-lanes", type=int, default=4, help="batches in flight of the compliant_mode's second figure (round 6, 24-bit K / V cache: "
+                    "2 / 3 / 4 lanes = 2,599 / 2,718 / 2,742 frames/s, profiles/r06_x3_lanes.txt; with the fp32 cache two was the optimum)")
     ap.add_argument("--no-profile", action="store_true", help="skip the profiled pass (rooflines)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE configs 3, 4, 5 (default config, N = 1 only)")
     ap.add_argument("--cpu-sample", type=int, default=8)
@@ -665,13 +667,14 @@ def main():
     # ---- the arithmetic that meets the 1e-3 parity bar, same workload, short runs (N = 1 only):
     #   fp32_mode       fp32 decode + fp32 rollout on f32-input MFMAs (1/16 of the bf16 matrix rate)
     #   compliant_mode  "x3": fp32 tensors, every matrix product of decode and prompt pass in split-bf16 arithmetic (bf16 hi + lo per
-    #                   operand, fp32 accumulate; conv3x3.hip / igemm.hip X3) -- the same 1e-3 bars (tests/test_gpu_x3.py)
+    #                   operand, fp32 accumulate; conv3x3.hip / igemm.hip / gemm256.hip X3), K / V cache at 24 bits per element in two
+    #                   planes (round 6, llama_ops.hip) -- the same 1e-3 bars (tests/test_gpu_x3.py)
     alt = {}
     if world == 1 and not a.no_fp32_mode and (a.decode_dtype, a.llm_dtype) != ("fp32", "fp32"):
         del model, tok
         torch.cuda.empty_cache()
         for key, dec, llm, note in (("fp32_mode", "fp32", "fp32", "pixels / logits within 1e-3 of the fp32 reference, token-identical rollouts (tests/test_gpu_models.py)"),
-                                    ("compliant_mode", "x3", "x3", "split-bf16 arithmetic on fp32 tensors: pixels / logits within 1e-3 of the fp32 reference, "
+                                    ("compliant_mode", "x3", "x3", "split-bf16 arithmetic on fp32 tensors, 24-bit K / V cache: pixels / logits within 1e-3 of the fp32 reference, "
                                                                    "token-identical greedy rollouts (tests/test_gpu_x3.py)")):
             _, _, _, _, tok_a, model_a = build_models(dev, a.res, a.medium, a.encode_dtype, dec, llm, a.action_dim, a.ctx or None, a.frames)
             n_a = max(1, min(5, a.steps))
@@ -679,8 +682,8 @@ def main():
             assert torch.isfinite(fr_a).all()
             alt[key] = {"value": B * F * n_a / e_a, "unit": "predicted frames/s", "ms_per_step": e_a / n_a * 1e3, "ms_per_step_median": median(t_a) * 1e3,
                         "steps": n_a, "lanes": 1, "arith": {"encode": a.encode_dtype, "rollout": llm, "decode": dec}, "note": note}
-            if key == "compliant_mode" and a.lanes > 1:   # the same mode with two batches in flight (more do not pay with fp32 tensors: r04_lanes.txt)
-                n_x3 = min(a.lanes, 2)
+            if key == "compliant_mode" and a.lanes > 1:   # the same mode with batches in flight, as the headline
+                n_x3 = min(a.lanes, a.x3_lanes)
                 lanes_a = [dict(tok=tok_a, model=model_a, pixels=pixels, actions=actions, gen=sample_gen, stream=main_stream)]
                 for i in range(1, n_x3):
                     gi = torch.Generator(device=dev).manual_seed(1000 + rank + 7919 * i)
