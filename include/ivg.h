@@ -291,6 +291,8 @@ typedef struct {
   int32_t nb0, nb1, nb2;
   int64_t sa[3], sw[3], sy[3];
 } ivg_igemm_args;
+/* dtype IVG_F32X3: fp32 tensors, split-bf16 arithmetic (what an x3 engine's GEMMs run: gemm256x3_kernel where it covers the shape,
+ * else igemm_kernel<float, ..., X3>); flags = IG_* of csrc/igemm.h */
 int ivg_op_igemm(const ivg_igemm_args* a, int dtype, ivg_stream stream);
 /* 3x3 convolution whose epilogue also reduces the GroupNorm statistics of its output into gn_part (double2 [Nimg][chunks][groups],
  * at least Nimg * ceil(Hout*Wout/256) * ceil(N/64) * groups entries), then GroupNorm(+SiLU) of that output from those statistics
