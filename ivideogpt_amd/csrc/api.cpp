@@ -871,6 +871,7 @@ int ivg_op_conv_x3(const ivg_igemm_args* a, const void* w_x3, int groups, const 
 int64_t ivg_debug_counter(const char* name) {
   if (name && !strcmp(name, "conv3x3_subpixel")) return conv3x3_subpixel_launches();
   if (name && !strcmp(name, "gemm256x3")) return gemm256x3_launches();
+  if (name && !strcmp(name, "decode_attn24")) return decode_attn24_launches();
   if (name && !strcmp(name, "decode_gemm_gen3")) return decode_gemm_launches(3);
   if (name && !strcmp(name, "decode_gemm_gen2")) return decode_gemm_launches(2);
   return -1;

@@ -7,6 +7,7 @@
 #include <cstdlib>
 
 #include "ops.h"
+#include <atomic>
 #include "switches.h"
 
 namespace ivg {
@@ -975,8 +976,12 @@ __global__ __launch_bounds__(256) void decode_attn24_kernel(const float* __restr
   }
 }
 
+static std::atomic<long long> g_attn24_launches{0};
+long long decode_attn24_launches() { return g_attn24_launches.load(); }
+
 int launch_decode_attn24(const void* qkv, void* kc, void* vc, void* out, const float* cosT, const float* sinT, int B, int heads, int Lmax,
                          const StepState* state, unsigned long long* prof, hipStream_t st, int sh_P, int sh_G, int sh_row0) {
+  g_attn24_launches.fetch_add(1, std::memory_order_relaxed);
   const size_t smem = (size_t)(3 * 64 + Lmax + 32 * 64) * sizeof(float);
   dim3 g(B * heads);
   if (sh_G > 1) {

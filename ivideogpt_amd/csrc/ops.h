@@ -82,6 +82,7 @@ int launch_decode_attn(const void* qkv, void* kc, void* vc, void* out, const flo
 // head_dim 64, fp32 q / output.  launch_kv24_pack: fp32 rows [0, L) of [BH][Lmax][64] K and V (the prefill's scratch) -> the planes
 int launch_decode_attn24(const void* qkv, void* kc, void* vc, void* out, const float* cosT, const float* sinT, int B, int heads, int Lmax,
                          const StepState* state, unsigned long long* prof, hipStream_t st, int sh_P = 0, int sh_G = 1, int sh_row0 = 0);
+long long decode_attn24_launches();   // launches over the 24-bit cache since load (test hook: which cache format an x3 engine really ran)
 int launch_kv24_pack(const void* k32, const void* v32, void* kc, void* vc, int BH, int L, int Lmax, hipStream_t st);
 int launch_expand_prompt_rows(const int64_t* prompts, long pstride, int64_t* ids, long ids_ld, int rows, int L, int G, int b0, hipStream_t st);
 // token decision + embedding of the decided token (+ action embedding on forced sdf slots) + state advance

@@ -118,7 +118,10 @@ def test_x3_decode_path_at_released_widths_vs_oracle(width, lds_kb):
     u = torch.rand(2, n_new, generator=g)
     ora = oracle_llama(cfg, sd)
     m = make_llm(cfg, sd, "x3", lds_kb)
+    from ivideogpt_amd import _lib
+    a24 = _lib.load().ivg_debug_counter(b"decode_attn24")
     out_g = m.generate(prompt.to(DEV), do_sample=False, max_new_tokens=n_new).cpu()
+    assert _lib.load().ivg_debug_counter(b"decode_attn24") - a24 == cfg["num_hidden_layers"] * (n_new - 1), "the x3 rollout did not run over the 24-bit K / V cache"
     ref_g = generate_cached(ora, prompt, n_new)
     assert torch.equal(out_g, ref_g), f"greedy: {(out_g != ref_g).sum().item()} of {2 * n_new} tokens differ from the oracle"
     out_s = m.generate(prompt.to(DEV), do_sample=True, top_k=100, max_new_tokens=n_new, uniforms=u.to(DEV)).cpu()
@@ -159,7 +162,10 @@ def test_x3_shared_context_rollout_over_the_24_bit_cache(switches):
     assert torch.equal(og, ref_g)
     switches(IVG_KV24="0")
     m32 = make_llm(cfg, sd, "x3")
+    from ivideogpt_amd import _lib
+    a24 = _lib.load().ivg_debug_counter(b"decode_attn24")
     assert torch.equal(m32.generate(prompt.repeat(2, 1).to(DEV), do_sample=False, max_new_tokens=n_new, shared_context=2).cpu(), ref_g)
+    assert _lib.load().ivg_debug_counter(b"decode_attn24") == a24, "IVG_KV24=0 must keep the fp32 cache"
 
 
 def test_x3_switch_off_is_the_fp32_path(switches):
