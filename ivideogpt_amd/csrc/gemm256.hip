@@ -197,9 +197,10 @@ __global__ __launch_bounds__(1024) void gemm256l_kernel(const G256Dev p) {
   g256_epilogue<BN>(p, acc, smem, m0, n0, wm, wn, lr, lg, tid);
 }
 
-// ---- split-bf16 ("x3") instance (round 6): fp32 operands in HBM and in LDS, 256 x 256 output tile.  The prompt pass of the
-// 1e-3-compliant rollout mode (IVG_F32X3) ran on the 128 x 128 implicit GEMM (igemm_kernel<float, ..., X3>): 57 of the mode's 437 ms per
-// step.  Same whole-line staging as gemm256l_kernel -- a step is one 128-byte line per row = 32 fp32 elements of K, two stages of
+// ---- split-bf16 ("x3") instance (round 6): fp32 operands in HBM and in LDS, 256 x 256 output tile.  The prompt pass and the dense 1 x 1
+// layers of the 1e-3-compliant mode (IVG_F32X3) ran on the 128 x 128 implicit GEMM (igemm_kernel<float, ..., X3>); on this tile the
+// mode's rollout takes 285.4 instead of 292.5 ms and its decode stage 118.1 instead of 120.6 (ABAB, NOTES_r06.md 9b); the launches run
+// at ~1.05 PFLOP/s of bf16 MFMA work.  Same whole-line staging as gemm256l_kernel -- a step is one 128-byte line per row = 32 fp32 elements of K, two stages of
 // 64 KiB (A | W) -- and the arithmetic of the other X3 kernels: a fragment slot (4 fp32 of K) is split in registers into
 // [bf16 hi(4) | bf16 lo(4)], the weight slot is duplicated into [w_hi | w_hi] and [w_lo | w_lo], and two K = 32 bf16 MFMAs produce all
 // four partial products with fp32 accumulation.  64 MFMAs per wave and stage (four per fragment pair) against the bf16 kernel's 32:

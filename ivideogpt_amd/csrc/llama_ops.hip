@@ -781,7 +781,7 @@ int launch_decode_attn(const void* qkv, void* kc, void* vc, void* out, const flo
 
 // ------------------------------------------------------------------------------------------------ 24-bit K / V cache of the x3 rollout
 // The 1e-3-compliant rollout mode (IVG_F32X3) keeps fp32 tensors, and its decode attention streamed an fp32 cache: 249 MB per layer
-// and step at config 2, 130 of the mode's 425 ms per step.  The arithmetic of that mode carries 2^-17 per operand anyway (bf16 hi +
+// and step at config 2, 130 of the mode's 425 ms per step (45.8 us per launch; over the planes below: 32.8 us, 93 ms).  The arithmetic of that mode carries 2^-17 per operand anyway (bf16 hi +
 // bf16 lo), so the cache keeps 24 of the 32 bits: sign, exponent and 15 mantissa bits, rounded to nearest even -- 2^-17 relative --
 // as TWO PLANES per (trajectory, head): the upper 16 bits of every element ([Lmax][64] uint16, a bf16 image of the row) followed by
 // the next 8 bits ([Lmax][64] uint8).  A key row is 128 + 64 bytes instead of 256; a lane reads 16 + 8 bytes (8 elements) and
